@@ -1,0 +1,134 @@
+/*
+ * loco_hip.h -- C ABI of libloco_hip.so, the MI355X (gfx950) engine behind the
+ * LOCO-Edit null-space-projection hot path.
+ *
+ * The reference (ChicyChen/LOCO-Edit) has no FFI layer: its boundary is Python
+ * duck typing.  Each entry point below names the
+ * reference interface it replaces; the Python host (loco-edit_amd/) binds them
+ * with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions: every tensor pointer is a DEVICE pointer owned by the caller
+ * (torch `tensor.data_ptr()`), fp32, contiguous NCHW unless stated.  The ctx
+ * owns only its parameter copies, workspace and activation caches.  All work is
+ * enqueued on the caller-supplied hipStream_t (passed as void*).  Return 0 on
+ * success, negative on error (message via loco_last_error).  One ctx per
+ * (process, GPU); not thread-safe.  No exceptions cross the ABI.
+ */
+#ifndef LOCO_HIP_H
+#define LOCO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct loco_ctx loco_ctx;
+
+/* Architecture of the denoiser: reference src/configs/custom_celeba_ddpm.yml
+ * `model:` block + DDPM.__init__ (src/models/ddpm/diffusion.py:22-126). */
+typedef struct loco_unet_cfg {
+    int32_t resolution;        /* data.image_size */
+    int32_t in_channels;       /* model.in_channels */
+    int32_t out_ch;            /* model.out_ch */
+    int32_t ch;                /* model.ch */
+    int32_t num_levels;        /* len(model.ch_mult) */
+    int32_t ch_mult[8];        /* model.ch_mult */
+    int32_t num_res_blocks;    /* model.num_res_blocks */
+    int32_t num_attn_res;      /* len(model.attn_resolutions) */
+    int32_t attn_resolutions[8];
+    int32_t gn_groups;         /* 32  (diffusion.py:810) */
+    float   gn_eps;            /* 1e-6 */
+    int32_t max_batch;         /* largest image / probe batch one call may carry */
+} loco_unet_cfg;
+
+/* Library / device probes (no ctx). */
+const char* loco_version(void);
+int  loco_device_count(void);
+
+/* Replaces PullBackDDPM(args) construction (diffusion.py:128-143). */
+int  loco_create(const loco_unet_cfg* cfg, loco_ctx** out);
+void loco_destroy(loco_ctx* ctx);
+const char* loco_last_error(loco_ctx* ctx);
+
+/* Replaces model.load_state_dict (src/utils/utils.py:102-105): one call per
+ * state_dict entry, names exactly as in the reference module tree.  `data` is a
+ * host OR device pointer to fp32 values (is_device says which). */
+int  loco_load_param(loco_ctx* ctx, const char* name, const void* data,
+                     const int64_t* shape, int32_t ndim, int32_t is_device);
+/* 0 when every parameter of the architecture has been loaded, else the count
+ * still missing (first missing name in loco_last_error). */
+int  loco_params_missing(loco_ctx* ctx);
+
+/* eps = unet(x, t): PullBackDDPM.forward (diffusion.py:145-200) as called at
+ * edit.py:2151, 2375, 2572.  x, eps: [B,C,H,W].  t is the float timestep fed
+ * to the time embedding. */
+int  loco_unet_forward(loco_ctx* ctx, const float* x, float t, int32_t B,
+                       float* eps, void* stream);
+
+/* One DDIM update fused with the denoiser call: scheduler.step
+ * (src/utils/utils.py:342-383) after unet(xt,t), the body of HOT LOOPs A/A'/C
+ * (edit.py:2146-2160, 2568-2584).  at/at_next are alpha-bar at floor(t),
+ * floor(t_next) (utils.py:444-461).  eta==0: deterministic; eta!=0 needs
+ * `noise` [B,C,H,W] (the randn_like draw of utils.py:374).  x_next may alias x. */
+int  loco_ddim_step(loco_ctx* ctx, const float* x, float t, float at, float at_next,
+                    float eta, const float* noise, int32_t B, float* x_next, void* stream);
+
+/* --- PMP-Jacobian operator J = d x0_hat[mask] / d x_t  (edit.py:2369-2391) ---
+ * loco_pmp_primal evaluates the denoiser once at (x,t), caching what the
+ * tangent and cotangent passes need; `mask` is uint8 [C*H*W] (nullptr = all
+ * ones), use_et!=0 selects get_et (edit.py:2394-2403) instead of get_x0. */
+int  loco_pmp_primal(loco_ctx* ctx, const float* x, float t, float at,
+                     const uint8_t* mask, int32_t use_et, void* stream);
+/* U = J V  (replaces torch.func.jacfwd at edit.py:2451-2455).  V: [k, n];
+ * U: dense [k, n] with zeros outside the mask. */
+int  loco_pmp_jvp(loco_ctx* ctx, const float* V, int32_t k, float* U, void* stream);
+/* A = U^T J (replaces torch.autograd.functional.jacobian at edit.py:2460-2480).
+ * U: dense [k, n] (entries outside the mask are ignored); A: [k, n]. */
+int  loco_pmp_vjp(loco_ctx* ctx, const float* U, int32_t k, float* A, void* stream);
+
+/* Thin SVD re-orthonormalisation of the k x n block (replaces torch.linalg.svd
+ * at edit.py:2482): on return A holds Vh (orthonormal rows, descending
+ * singular value, sign: largest-|.| entry of each row positive), s[k] the
+ * singular values of the input. k <= 64. */
+int  loco_orthonormalize(loco_ctx* ctx, float* A, int32_t k, int64_t n, float* s, void* stream);
+/* Q = thin-QR orthonormal basis of the rows of A (replaces torch.linalg.qr at
+ * edit.py:2436 on the transposed layout): A [k,n] in, orthonormal rows out,
+ * row i in span(rows 0..i) with positive pivot. */
+int  loco_qr_rows(loco_ctx* ctx, float* A, int32_t k, int64_t n, void* stream);
+/* Convergence test of edit.py:2489-2492: out[0] = ||Vp - V||_F,
+ * out[1] = 1.0 if allclose(Vp, V, atol, rtol=1e-5) else 0.0 (device floats). */
+int  loco_convergence(loco_ctx* ctx, const float* Vprev, const float* V, int64_t count,
+                      float atol, float* out2, void* stream);
+
+/* Null-space projection + row normalisation (edit.py:2317-2323):
+ * out = normalize_rows(Vm - (Vn^T (Vn Vm^T))^T); Vn==nullptr: normalise only. */
+int  loco_null_project(loco_ctx* ctx, const float* Vm, int32_t k, const float* Vn, int32_t k0,
+                       int64_t n, float* out, void* stream);
+/* Edit step x + alpha*v (x_space_guidance_direct, edit.py:2618-2625), batched:
+ * out[b] = x + alphas[b]*v for b < B (alphas on host). */
+int  loco_edit_axpy(loco_ctx* ctx, const float* x, const float* v, const float* alphas,
+                    int32_t B, int64_t n, float* out, void* stream);
+/* Compact the masked entries: out[k, L] = U[k, mask] (P_xt[:, mask], edit.py:2390). */
+int  loco_mask_gather(loco_ctx* ctx, const float* U, int32_t k, float* out, void* stream);
+int64_t loco_mask_count(loco_ctx* ctx);
+
+/* Work model helpers for bench.py: 2*MAC of one denoiser evaluation (B=1). */
+double loco_unet_flops(loco_ctx* ctx);
+/* Bytes of device memory the ctx holds. */
+int64_t loco_workspace_bytes(loco_ctx* ctx);
+
+/* HIP-event timing on the stream the kernels run on (bench.py roofline leg):
+ * average duration in ms of kernels whose name contains `substr` is not
+ * available from the API; instead these bracket a region. */
+int  loco_timer_start(loco_ctx* ctx, void* stream);
+int  loco_timer_stop(loco_ctx* ctx, void* stream, float* ms);
+
+/* Debug / test hook: copy an internal primal activation ("down.0.block.0" ...)
+ * of the last forward/primal call into dst (device), returns element count or <0. */
+int64_t loco_debug_tensor(loco_ctx* ctx, const char* name, float* dst, int64_t cap, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCO_HIP_H */

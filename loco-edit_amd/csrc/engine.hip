@@ -1,0 +1,1211 @@
+// loco_ctx: the U-Net program (op list), parameter store, activation arenas and
+// the three passes (forward / tangent / cotangent) of the PMP-Jacobian operator,
+// plus the C ABI of include/loco_hip.h.
+//
+// Memory plan (HBM): every logical tensor of the network has a fixed offset in
+// a per-sample layout; an arena holds max_batch samples of that layout, so all
+// tensors share one batch stride.  Skip tensors are placed directly inside the
+// concatenation buffer of the up-block that consumes them (torch.cat of
+// reference diffusion.py:186 is never materialised).  Arena P holds the primal
+// pass (B images for DDIM loops, B=1 cached for the Jacobian), arena T is shared
+// by the tangent and the cotangent pass of a probe batch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/loco_hip.h"
+#include "kernels.h"
+
+using namespace loco;
+
+#define HIPCHK(ctx, call)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return -1;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+struct Tens { long off; int C, H, W; };
+
+struct ConvP {       // one convolution's parameters in kernel layouts
+    float* wf = nullptr;    // forward  [Cin][taps][CoutP]
+    float* wd = nullptr;    // dgrad    [Cout][taps][CinP]  (flipped taps)
+    float* bias = nullptr;
+    int cin = 0, cout = 0, taps = 0;
+};
+struct NormP { float* gamma = nullptr; float* beta = nullptr; int C = 0; long soff = 0; };   // soff: stats offset
+
+enum OpKind { OP_CONV_IN, OP_RES, OP_ATTN, OP_DOWN, OP_UP, OP_OUT };
+
+struct Op {
+    OpKind kind;
+    std::string name;
+    int in = -1, out = -1;        // tensor ids
+    int h1 = -1, a1 = -1;         // RES: conv1 output; cotangent scratch with the input's shape
+    int hn = -1, qkv = -1, S = -1, o = -1;   // ATTN
+    int up = -1;                  // UP: cotangent scratch at the upsampled size
+    bool in_is_skip = false;
+    bool has_nin = false;
+    ConvP c1, c2, nin, qkvc, proj, conv;     // conv: CONV_IN / DOWN / UP / OUT
+    NormP n1, n2;                 // RES norm1/norm2, ATTN norm (n1), OUT norm_out (n1)
+    long tproj_off = 0;           // RES: offset into the concatenated temb projections
+};
+
+struct HostParam { std::vector<float> data; std::vector<int64_t> shape; bool loaded = false; };
+
+}  // namespace
+
+struct loco_ctx {
+    loco_unet_cfg cfg;
+    std::string err;
+    std::map<std::string, HostParam> params;
+    std::vector<std::string> param_order;
+    bool finalized = false;
+
+    std::vector<Tens> tens;
+    std::vector<Op> ops;
+    long per_sample = 0;       // floats per sample in an activation arena
+    long stats_per_sample = 0; // floats per sample in a stats arena
+    long tproj_total = 0;
+    int n_in = 0;              // C*H*W of the image
+    int eps_t = -1;            // tensor id of the network output
+
+    float *arenaP = nullptr, *arenaT = nullptr;
+    float *statsP = nullptr, *statsT = nullptr;
+    double* red = nullptr;         // reduction scratch (doubles)
+    float* partial = nullptr;      // split-K workspace
+    size_t partial_floats = 0;
+    float *tact = nullptr, *tproj = nullptr, *freq = nullptr;
+    float *tp_w = nullptr, *tp_b = nullptr;          // concatenated temb_proj
+    float *td0w = nullptr, *td0b = nullptr, *td1w = nullptr, *td1b = nullptr;
+    float* eps_buf = nullptr;      // [max_batch][n]
+    float* gx0 = nullptr;          // [max_batch][n] direct cotangent term
+    float* ge = nullptr;           // [max_batch][n] cotangent seed of eps
+    float* tmpA = nullptr;         // [64][n] temp for solver rotations
+    double *G = nullptr, *Q = nullptr, *W = nullptr, *gscratch = nullptr;
+    float* alphas = nullptr;
+    std::vector<float*> owned;     // everything to hipFree
+    size_t bytes = 0;
+
+    // PMP state
+    bool primal_ok = false;
+    float p_cv = 0.f, p_ce = 0.f;
+    uint8_t* mask = nullptr;       // device, [n] (owned copy)
+    bool has_mask = false;
+    int* mask_idx = nullptr;
+    long mask_L = 0;
+    int primal_B = 0;
+    double flops = 0.0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dalloc(loco_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    HIPCHK(c, hipMalloc(&q, count * sizeof(T)));
+    *p = reinterpret_cast<T*>(q);
+    c->owned.push_back(reinterpret_cast<float*>(q));
+    c->bytes += count * sizeof(T);
+    return 0;
+}
+
+long align4(long v) { return (v + 63) & ~63L; }
+
+int new_tensor(loco_ctx* c, int C, int H, int W, long off = -1) {
+    Tens t;
+    t.C = C; t.H = H; t.W = W;
+    if (off < 0) {
+        t.off = c->per_sample;
+        c->per_sample += align4((long)C * H * W);
+    } else {
+        t.off = off;
+    }
+    c->tens.push_back(t);
+    return (int)c->tens.size() - 1;
+}
+NormP new_norm(loco_ctx* c, int C) {
+    NormP n;
+    n.C = C;
+    n.soff = c->stats_per_sample;
+    // layout per norm: sc[C], sh[C], mr[2G], tst[2G]
+    c->stats_per_sample += align4(2L * C + 4L * c->cfg.gn_groups);
+    return n;
+}
+bool attn_at(const loco_unet_cfg& cfg, int res) {
+    for (int i = 0; i < cfg.num_attn_res; ++i)
+        if (cfg.attn_resolutions[i] == res) return true;
+    return false;
+}
+
+// Build the op list + memory plan (mirrors DDPM.__init__/forward, reference diffusion.py:22-200)
+int build_program(loco_ctx* c) {
+    const loco_unet_cfg& cfg = c->cfg;
+    const int ch = cfg.ch, nres = cfg.num_levels, R = cfg.resolution;
+    c->n_in = cfg.in_channels * R * R;
+    auto add_attn = [&](const std::string& name, int in_t, int out_t) {
+        Op a; a.kind = OP_ATTN; a.name = name; a.in = in_t; a.out = out_t;
+        const Tens& t = c->tens[in_t];
+        int T = t.H * t.W;
+        a.hn = new_tensor(c, t.C, t.H, t.W);
+        a.qkv = new_tensor(c, 3 * t.C, t.H, t.W);
+        a.S = new_tensor(c, 1, T, T);
+        a.o = new_tensor(c, t.C, t.H, t.W);
+        a.n1 = new_norm(c, t.C);
+        c->ops.push_back(a);
+    };
+    // ---- pass 1: shapes of the skip stack, to place skips inside concat buffers
+    struct Skip { int C, H; };
+    std::vector<Skip> hs;
+    {
+        int res = R;
+        hs.push_back({ch, res});
+        for (int l = 0; l < nres; ++l) {
+            for (int b = 0; b < cfg.num_res_blocks; ++b) hs.push_back({ch * cfg.ch_mult[l], res});
+            if (l != nres - 1) { res /= 2; hs.push_back({ch * cfg.ch_mult[l], res}); }
+        }
+    }
+    // up path consumption order: pops from the back
+    // concat buffer j (j-th up block) = [h_prev (C1) | skip hs[n-1-j] (C2)]
+    const int nskip = (int)hs.size();
+    std::vector<int> cat_t(nskip), skip_t(nskip), hprev_t(nskip);
+    {
+        int res = hs.back().H;
+        int block_in = ch * cfg.ch_mult[nres - 1];
+        int j = 0;
+        for (int l = nres - 1; l >= 0; --l) {
+            int block_out = ch * cfg.ch_mult[l];
+            for (int b = 0; b < cfg.num_res_blocks + 1; ++b) {
+                const Skip& sk = hs[nskip - 1 - j];
+                int C1 = block_in, C2 = sk.C;
+                if (sk.H != res) { c->err = "internal: skip resolution mismatch"; return -1; }
+                int cat = new_tensor(c, C1 + C2, res, res);
+                long base = c->tens[cat].off;
+                cat_t[j] = cat;
+                hprev_t[j] = new_tensor(c, C1, res, res, base);
+                skip_t[nskip - 1 - j] = new_tensor(c, C2, res, res, base + (long)C1 * res * res);
+                block_in = block_out;
+                ++j;
+            }
+            if (l != 0) res *= 2;
+        }
+    }
+    // ---- pass 2: ops
+    int res = R;
+    int si = 0;   // skip index
+    {
+        Op o; o.kind = OP_CONV_IN; o.name = "conv_in"; o.in = -1; o.out = skip_t[si++];
+        c->ops.push_back(o);
+    }
+    int block_in = ch;
+    int cur = skip_t[0];
+    for (int l = 0; l < nres; ++l) {
+        int block_out = ch * cfg.ch_mult[l];
+        for (int b = 0; b < cfg.num_res_blocks; ++b) {
+            Op r; r.kind = OP_RES; r.name = "down." + std::to_string(l) + ".block." + std::to_string(b);
+            r.in = cur; r.in_is_skip = true;
+            r.has_nin = (block_in != block_out);
+            bool at = attn_at(cfg, res);
+            int out_t = at ? new_tensor(c, block_out, res, res) : skip_t[si];
+            r.out = out_t;
+            r.h1 = new_tensor(c, block_out, res, res);
+            r.a1 = new_tensor(c, block_in, res, res);
+            r.n1 = new_norm(c, block_in); r.n2 = new_norm(c, block_out);
+            c->ops.push_back(r);
+            if (at) add_attn("down." + std::to_string(l) + ".attn." + std::to_string(b), out_t, skip_t[si]);
+            cur = skip_t[si++];
+            block_in = block_out;
+        }
+        if (l != nres - 1) {
+            Op d; d.kind = OP_DOWN; d.name = "down." + std::to_string(l) + ".downsample.conv";
+            d.in = cur; d.in_is_skip = true; d.out = skip_t[si];
+            c->ops.push_back(d);
+            cur = skip_t[si++];
+            res /= 2;
+        }
+    }
+    // middle
+    {
+        Op r; r.kind = OP_RES; r.name = "mid.block_1"; r.in = cur; r.in_is_skip = true; r.has_nin = false;
+        r.out = new_tensor(c, block_in, res, res);
+        r.h1 = new_tensor(c, block_in, res, res); r.a1 = new_tensor(c, block_in, res, res);
+        r.n1 = new_norm(c, block_in); r.n2 = new_norm(c, block_in);
+        c->ops.push_back(r);
+        int a_out = new_tensor(c, block_in, res, res);
+        add_attn("mid.attn_1", r.out, a_out);
+        Op r2; r2.kind = OP_RES; r2.name = "mid.block_2"; r2.in = a_out; r2.has_nin = false;
+        r2.out = hprev_t[0];
+        r2.h1 = new_tensor(c, block_in, res, res); r2.a1 = new_tensor(c, block_in, res, res);
+        r2.n1 = new_norm(c, block_in); r2.n2 = new_norm(c, block_in);
+        c->ops.push_back(r2);
+    }
+    // up path
+    {
+        int j = 0;
+        for (int l = nres - 1; l >= 0; --l) {
+            int block_out = ch * cfg.ch_mult[l];
+            for (int b = 0; b < cfg.num_res_blocks + 1; ++b) {
+                Op r; r.kind = OP_RES; r.name = "up." + std::to_string(l) + ".block." + std::to_string(b);
+                r.in = cat_t[j];
+                int cin = c->tens[cat_t[j]].C;
+                r.has_nin = (cin != block_out);
+                bool at = attn_at(cfg, res);
+                bool last_of_level = (b == cfg.num_res_blocks);
+                bool final_block = (l == 0 && last_of_level);
+                // where does the block's (or its attention's) output go?
+                int dest;
+                if (final_block) dest = new_tensor(c, block_out, res, res);
+                else if (last_of_level) dest = new_tensor(c, block_out, res, res);   // feeds the upsample conv
+                else dest = hprev_t[j + 1];
+                int out_t = at ? new_tensor(c, block_out, res, res) : dest;
+                r.out = out_t;
+                r.h1 = new_tensor(c, block_out, res, res);
+                r.a1 = new_tensor(c, cin, res, res);
+                r.n1 = new_norm(c, cin); r.n2 = new_norm(c, block_out);
+                c->ops.push_back(r);
+                if (at) add_attn("up." + std::to_string(l) + ".attn." + std::to_string(b), out_t, dest);
+                cur = dest;
+                ++j;
+                if (last_of_level && l != 0) {
+                    Op u; u.kind = OP_UP; u.name = "up." + std::to_string(l) + ".upsample.conv";
+                    u.in = cur; u.out = hprev_t[j];
+                    u.up = new_tensor(c, block_out, res * 2, res * 2);
+                    c->ops.push_back(u);
+                    cur = u.out;
+                    res *= 2;
+                }
+            }
+        }
+    }
+    {
+        Op o; o.kind = OP_OUT; o.name = "conv_out"; o.in = cur;
+        o.out = new_tensor(c, cfg.out_ch, R, R);
+        o.a1 = new_tensor(c, c->tens[cur].C, R, R);
+        o.n1 = new_norm(c, c->tens[cur].C);
+        c->ops.push_back(o);
+        c->eps_t = o.out;
+    }
+    return 0;
+}
+
+void declare_param(loco_ctx* c, const std::string& name, std::vector<int64_t> shape) {
+    HostParam hp; hp.shape = shape;
+    c->params[name] = hp;
+    c->param_order.push_back(name);
+}
+void declare_conv(loco_ctx* c, const std::string& n, int cin, int cout, int k) {
+    declare_param(c, n + ".weight", {cout, cin, k, k});
+    declare_param(c, n + ".bias", {cout});
+}
+void declare_norm(loco_ctx* c, const std::string& n, int C) {
+    declare_param(c, n + ".weight", {C});
+    declare_param(c, n + ".bias", {C});
+}
+void declare_lin(loco_ctx* c, const std::string& n, int cin, int cout) {
+    declare_param(c, n + ".weight", {cout, cin});
+    declare_param(c, n + ".bias", {cout});
+}
+
+void declare_all(loco_ctx* c) {
+    const loco_unet_cfg& cfg = c->cfg;
+    int temb_ch = cfg.ch * 4;
+    declare_lin(c, "temb.dense.0", cfg.ch, temb_ch);
+    declare_lin(c, "temb.dense.1", temb_ch, temb_ch);
+    for (auto& op : c->ops) {
+        switch (op.kind) {
+            case OP_CONV_IN: declare_conv(c, "conv_in", cfg.in_channels, cfg.ch, 3); break;
+            case OP_RES: {
+                int cin = c->tens[op.in].C, cout = c->tens[op.out].C;
+                declare_norm(c, op.name + ".norm1", cin);
+                declare_conv(c, op.name + ".conv1", cin, cout, 3);
+                declare_lin(c, op.name + ".temb_proj", temb_ch, cout);
+                declare_norm(c, op.name + ".norm2", cout);
+                declare_conv(c, op.name + ".conv2", cout, cout, 3);
+                if (op.has_nin) declare_conv(c, op.name + ".nin_shortcut", cin, cout, 1);
+                break;
+            }
+            case OP_ATTN: {
+                int C = c->tens[op.in].C;
+                declare_norm(c, op.name + ".norm", C);
+                for (const char* p : {"q", "k", "v", "proj_out"}) declare_conv(c, op.name + "." + p, C, C, 1);
+                break;
+            }
+            case OP_DOWN: case OP_UP: {
+                int C = c->tens[op.in].C;
+                declare_conv(c, op.name, C, C, 3);
+                break;
+            }
+            case OP_OUT:
+                declare_norm(c, "norm_out", c->tens[op.in].C);
+                declare_conv(c, "conv_out", c->tens[op.in].C, cfg.out_ch, 3);
+                break;
+        }
+    }
+}
+
+int upload(loco_ctx* c, float** dst, const std::vector<float>& h) {
+    if (dalloc(c, dst, h.size() ? h.size() : 1)) return -1;
+    HIPCHK(c, hipMemcpy(*dst, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// weights [cout][cin][k][k] -> forward [cin][taps][coutP], dgrad [cout][taps][cinP] with flipped taps
+int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::vector<const HostParam*>& bs,
+              ConvP* out) {
+    int cin = (int)ws[0]->shape[1], k = (int)ws[0]->shape[2], taps = k * k;
+    int cout = 0;
+    for (auto* w : ws) cout += (int)w->shape[0];
+    int coutP = (cout + 31) & ~31, cinP = (cin + 31) & ~31;
+    std::vector<float> wf((size_t)cin * taps * coutP, 0.f), wd((size_t)cout * taps * cinP, 0.f), bias(cout);
+    int co0 = 0;
+    for (size_t wi = 0; wi < ws.size(); ++wi) {
+        const HostParam* w = ws[wi];
+        int co_n = (int)w->shape[0];
+        for (int co = 0; co < co_n; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < taps; ++t) {
+                    float v = w->data[((size_t)co * cin + ci) * taps + t];
+                    wf[((size_t)ci * taps + t) * coutP + co0 + co] = v;
+                    wd[((size_t)(co0 + co) * taps + (taps - 1 - t)) * cinP + ci] = v;
+                }
+        for (int co = 0; co < co_n; ++co) bias[co0 + co] = bs[wi]->data[co];
+        co0 += co_n;
+    }
+    out->cin = cin; out->cout = cout; out->taps = taps;
+    if (upload(c, &out->wf, wf) || upload(c, &out->wd, wd) || upload(c, &out->bias, bias)) return -1;
+    return 0;
+}
+int make_conv1(loco_ctx* c, const std::string& name, ConvP* out) {
+    return make_conv(c, {&c->params[name + ".weight"]}, {&c->params[name + ".bias"]}, out);
+}
+int make_norm(loco_ctx* c, const std::string& name, NormP* n) {
+    if (upload(c, &n->gamma, c->params[name + ".weight"].data)) return -1;
+    if (upload(c, &n->beta, c->params[name + ".bias"].data)) return -1;
+    return 0;
+}
+
+int finalize_params(loco_ctx* c) {
+    if (c->finalized) return 0;
+    for (auto& n : c->param_order)
+        if (!c->params[n].loaded) { c->err = "parameter not loaded: " + n; return -1; }
+    const loco_unet_cfg& cfg = c->cfg;
+    int temb_ch = cfg.ch * 4;
+    if (upload(c, &c->td0w, c->params["temb.dense.0.weight"].data)) return -1;
+    if (upload(c, &c->td0b, c->params["temb.dense.0.bias"].data)) return -1;
+    if (upload(c, &c->td1w, c->params["temb.dense.1.weight"].data)) return -1;
+    if (upload(c, &c->td1b, c->params["temb.dense.1.bias"].data)) return -1;
+    // sinusoid frequencies exactly as torch: exp(float32(i) * float32(-ln(1e4)/(half-1)))  (diffusion.py:797-798)
+    {
+        int half = cfg.ch / 2;
+        std::vector<float> f(half);
+        float e = (float)(-(std::log(10000.0) / (double)(half - 1)));
+        for (int i = 0; i < half; ++i) {
+            float x = (float)i * e;
+            f[i] = (float)std::exp((double)x);
+        }
+        if (upload(c, &c->freq, f)) return -1;
+    }
+    std::vector<float> tpw, tpb;
+    for (auto& op : c->ops) {
+        switch (op.kind) {
+            case OP_CONV_IN: if (make_conv1(c, "conv_in", &op.conv)) return -1; break;
+            case OP_RES: {
+                if (make_norm(c, op.name + ".norm1", &op.n1) || make_norm(c, op.name + ".norm2", &op.n2)) return -1;
+                if (make_conv1(c, op.name + ".conv1", &op.c1) || make_conv1(c, op.name + ".conv2", &op.c2)) return -1;
+                if (op.has_nin && make_conv1(c, op.name + ".nin_shortcut", &op.nin)) return -1;
+                op.tproj_off = (long)tpb.size();
+                auto& w = c->params[op.name + ".temb_proj.weight"].data;
+                auto& b = c->params[op.name + ".temb_proj.bias"].data;
+                tpw.insert(tpw.end(), w.begin(), w.end());
+                tpb.insert(tpb.end(), b.begin(), b.end());
+                break;
+            }
+            case OP_ATTN: {
+                if (make_norm(c, op.name + ".norm", &op.n1)) return -1;
+                if (make_conv(c, {&c->params[op.name + ".q.weight"], &c->params[op.name + ".k.weight"],
+                                  &c->params[op.name + ".v.weight"]},
+                              {&c->params[op.name + ".q.bias"], &c->params[op.name + ".k.bias"],
+                               &c->params[op.name + ".v.bias"]}, &op.qkvc)) return -1;
+                if (make_conv1(c, op.name + ".proj_out", &op.proj)) return -1;
+                break;
+            }
+            case OP_DOWN: case OP_UP: if (make_conv1(c, op.name, &op.conv)) return -1; break;
+            case OP_OUT:
+                if (make_norm(c, "norm_out", &op.n1) || make_conv1(c, "conv_out", &op.conv)) return -1;
+                break;
+        }
+    }
+    c->tproj_total = (long)tpb.size();
+    if (upload(c, &c->tp_w, tpw) || upload(c, &c->tp_b, tpb)) return -1;
+    if (dalloc(c, &c->tact, (size_t)temb_ch) || dalloc(c, &c->tproj, (size_t)c->tproj_total)) return -1;
+    // FLOP model (2*MAC): convolutions + attention products
+    double fl = 0.0;
+    for (auto& op : c->ops) {
+        auto convf = [&](const ConvP& p, int H, int W) { fl += 2.0 * p.cin * p.cout * p.taps * (double)H * W; };
+        const Tens& to = c->tens[op.out];
+        switch (op.kind) {
+            case OP_CONV_IN: case OP_DOWN: case OP_UP: case OP_OUT: convf(op.conv, to.H, to.W); break;
+            case OP_RES:
+                convf(op.c1, to.H, to.W); convf(op.c2, to.H, to.W);
+                if (op.has_nin) convf(op.nin, to.H, to.W);
+                break;
+            case OP_ATTN: {
+                convf(op.qkvc, to.H, to.W); convf(op.proj, to.H, to.W);
+                double T = (double)to.H * to.W;
+                fl += 2.0 * 2.0 * T * T * to.C;
+                break;
+            }
+        }
+    }
+    c->flops = fl;
+    // host copies are no longer needed
+    for (auto& kv : c->params) { std::vector<float>().swap(kv.second.data); }
+    c->finalized = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+struct Pass {
+    loco_ctx* c;
+    hipStream_t st;
+    int B;
+    float* arena;      // activation arena of this pass
+    float* stats;      // stats arena of this pass
+    float* T(int id) const { return arena + c->tens[id].off; }
+    long bs() const { return c->per_sample; }
+};
+
+void conv_defaults(ConvArgs& a) {
+    std::memset(&a, 0, sizeof(a));
+    a.stride = 1; a.pad = 1; a.nsplit = 1; a.mode = CM_NONE;
+}
+
+// run a conv with automatic split-K selection
+void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
+    a.nsplit = conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
+    while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
+    if (a.nsplit < 1) a.nsplit = 1;
+    a.partial = c->partial;
+    launch_conv(a, taps, st);
+}
+
+// sc / sh / mr / tst pointers of a norm inside a stats arena
+struct NS { float *sc, *sh, *mr, *tst; };
+NS nstats(const loco_ctx* c, float* base, const NormP& n) {
+    NS s;
+    s.sc = base + n.soff; s.sh = s.sc + n.C; s.mr = s.sh + n.C; s.tst = s.mr + 2 * c->cfg.gn_groups;
+    return s;
+}
+
+void gn_forward_stats(const Pass& p, const NormP& n, const float* x, long xbs, int HW) {
+    NS s = nstats(p.c, p.stats, n);
+    launch_gn_stats(x, xbs, p.B, n.C, HW, p.c->cfg.gn_groups, p.c->cfg.gn_eps, n.gamma, n.beta, s.mr, s.sc, s.sh,
+                    p.c->stats_per_sample, p.c->red, p.st);
+}
+
+// ------------------------------ forward ------------------------------------
+int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, float* stats, hipStream_t st) {
+    const loco_unet_cfg& cfg = c->cfg;
+    Pass p{c, st, B, arena, stats};
+    const long SB = c->stats_per_sample;
+    launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st);
+    launch_temb_proj(c->tact, cfg.ch * 4, c->tp_w, c->tp_b, (int)c->tproj_total, c->tproj, st);
+    for (auto& op : c->ops) {
+        const Tens& to = c->tens[op.out];
+        const int HW = to.H * to.W;
+        switch (op.kind) {
+            case OP_CONV_IN: {
+                ConvArgs a; conv_defaults(a);
+                a.in = x; a.in_bs = c->n_in; a.Cin = cfg.in_channels; a.Hin = cfg.resolution; a.Win = cfg.resolution;
+                a.w = op.conv.wf; a.bias = op.conv.bias;
+                a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                break;
+            }
+            case OP_RES: {
+                const Tens& ti = c->tens[op.in];
+                gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HW);
+                NS s1 = nstats(c, stats, op.n1);
+                ConvArgs a; conv_defaults(a);
+                a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
+                a.w = op.c1.wf; a.bias = op.c1.bias; a.bias2 = c->tproj + op.tproj_off; a.bias2_bs = 0;
+                a.mode = CM_GN_SILU; a.sc = s1.sc; a.sh = s1.sh; a.scsh_bs = SB;
+                a.out = p.T(op.h1); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                gn_forward_stats(p, op.n2, p.T(op.h1), p.bs(), HW);
+                NS s2 = nstats(c, stats, op.n2);
+                const float* res = p.T(op.in);
+                if (op.has_nin) {
+                    ConvArgs n; conv_defaults(n);
+                    n.in = p.T(op.in); n.in_bs = p.bs(); n.Cin = ti.C; n.Hin = ti.H; n.Win = ti.W;
+                    n.w = op.nin.wf; n.bias = op.nin.bias; n.pad = 0;
+                    n.out = p.T(op.out); n.out_bs = p.bs(); n.Cout = to.C; n.Hout = to.H; n.Wout = to.W; n.B = B;
+                    run_conv(c, n, 1, st);
+                    res = p.T(op.out);
+                }
+                ConvArgs b; conv_defaults(b);
+                b.in = p.T(op.h1); b.in_bs = p.bs(); b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
+                b.w = op.c2.wf; b.bias = op.c2.bias; b.res = res; b.res_bs = p.bs();
+                b.mode = CM_GN_SILU; b.sc = s2.sc; b.sh = s2.sh; b.scsh_bs = SB;
+                b.out = p.T(op.out); b.out_bs = p.bs(); b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
+                run_conv(c, b, 9, st);
+                break;
+            }
+            case OP_ATTN: {
+                const int C = to.C, T = HW;
+                gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HW);
+                NS s = nstats(c, stats, op.n1);
+                ConvArgs a; conv_defaults(a);
+                a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = C; a.Hin = to.H; a.Win = to.W;
+                a.w = op.qkvc.wf; a.bias = op.qkvc.bias; a.pad = 0;
+                a.mode = CM_GN; a.sc = s.sc; a.sh = s.sh; a.scsh_bs = SB;
+                a.out = p.T(op.qkv); a.out_bs = p.bs(); a.Cout = 3 * C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 1, st);
+                float* q = p.T(op.qkv); float* k = q + (long)C * T; float* v = k + (long)C * T;
+                GemmArgs g; std::memset(&g, 0, sizeof(g));
+                g.A = q; g.sam = 1; g.sak = T; g.sab = p.bs();
+                g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = p.bs();
+                g.C = p.T(op.S); g.scm = T; g.scn = 1; g.scb = p.bs();
+                g.M = T; g.N = T; g.K = C; g.batch = B; g.alpha = 1.0f / std::sqrt((float)C); g.beta = 0.f;
+                launch_gemm(g, st);
+                // softmax rows: per-sample S blocks are not contiguous across the batch
+                for (int b = 0; b < B; ++b) launch_softmax_rows(p.T(op.S) + (long)b * p.bs(), T, T, st);
+                GemmArgs h; std::memset(&h, 0, sizeof(h));
+                h.A = v; h.sam = T; h.sak = 1; h.sab = p.bs();
+                h.Bm = p.T(op.S); h.sbk = 1; h.sbn = T; h.sbb = p.bs();
+                h.C = p.T(op.o); h.scm = T; h.scn = 1; h.scb = p.bs();
+                h.M = C; h.N = T; h.K = T; h.batch = B; h.alpha = 1.f; h.beta = 0.f;
+                launch_gemm(h, st);
+                ConvArgs pr; conv_defaults(pr);
+                pr.in = p.T(op.o); pr.in_bs = p.bs(); pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
+                pr.w = op.proj.wf; pr.bias = op.proj.bias; pr.pad = 0;
+                pr.res = p.T(op.in); pr.res_bs = p.bs();
+                pr.out = p.T(op.out); pr.out_bs = p.bs(); pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
+                run_conv(c, pr, 1, st);
+                break;
+            }
+            case OP_DOWN: case OP_UP: {
+                const Tens& ti = c->tens[op.in];
+                ConvArgs a; conv_defaults(a);
+                a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
+                a.w = op.conv.wf; a.bias = op.conv.bias;
+                if (op.kind == OP_DOWN) { a.stride = 2; a.pad = 0; } else { a.upsample = 1; }
+                a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                break;
+            }
+            case OP_OUT: {
+                const Tens& ti = c->tens[op.in];
+                gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), ti.H * ti.W);
+                NS s = nstats(c, stats, op.n1);
+                ConvArgs a; conv_defaults(a);
+                a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
+                a.w = op.conv.wf; a.bias = op.conv.bias;
+                a.mode = CM_GN_SILU; a.sc = s.sc; a.sh = s.sh; a.scsh_bs = SB;
+                a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                break;
+            }
+        }
+    }
+    return 0;
+}
+
+// ------------------------------ tangent ------------------------------------
+// primal: arenaP/statsP with B = 1 (broadcast); tangents: arenaT/statsT with B = k
+void tangent_stats(loco_ctx* c, const NormP& n, const float* d, long dbs, const float* x, int HW, int B,
+                   hipStream_t st) {
+    NS sp = nstats(c, c->statsP, n);
+    NS stt = nstats(c, c->statsT, n);
+    launch_gn_tstats(d, dbs, x, 0, B, n.C, HW, c->cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, 0, stt.tst,
+                     c->stats_per_sample, c->red, st);
+}
+void set_tan(loco_ctx* c, ConvArgs& a, const NormP& n, const float* prim) {
+    NS sp = nstats(c, c->statsP, n);
+    NS stt = nstats(c, c->statsT, n);
+    a.mode = CM_TAN_SILU; a.prim = prim; a.prim_bs = 0;
+    a.sc = sp.sc; a.sh = sp.sh; a.scsh_bs = 0; a.mr = sp.mr; a.mr_bs = 0; a.gamma_ = n.gamma;
+    a.tst = stt.tst; a.tst_bs = c->stats_per_sample; a.cpg = n.C / c->cfg.gn_groups;
+}
+
+int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
+    const loco_unet_cfg& cfg = c->cfg;
+    const long PS = c->per_sample;
+    auto TP = [&](int id) { return c->arenaP + c->tens[id].off; };   // primal
+    auto TT = [&](int id) { return c->arenaT + c->tens[id].off; };   // tangent
+    for (auto& op : c->ops) {
+        const Tens& to = c->tens[op.out];
+        const int HW = to.H * to.W;
+        switch (op.kind) {
+            case OP_CONV_IN: {
+                ConvArgs a; conv_defaults(a);
+                a.in = V; a.in_bs = c->n_in; a.Cin = cfg.in_channels; a.Hin = cfg.resolution; a.Win = cfg.resolution;
+                a.w = op.conv.wf;
+                a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                break;
+            }
+            case OP_RES: {
+                const Tens& ti = c->tens[op.in];
+                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
+                ConvArgs a; conv_defaults(a);
+                a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
+                a.w = op.c1.wf;
+                set_tan(c, a, op.n1, TP(op.in));
+                a.out = TT(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                tangent_stats(c, op.n2, TT(op.h1), PS, TP(op.h1), HW, B, st);
+                const float* res = TT(op.in);
+                if (op.has_nin) {
+                    ConvArgs n; conv_defaults(n);
+                    n.in = TT(op.in); n.in_bs = PS; n.Cin = ti.C; n.Hin = ti.H; n.Win = ti.W;
+                    n.w = op.nin.wf; n.pad = 0;
+                    n.out = TT(op.out); n.out_bs = PS; n.Cout = to.C; n.Hout = to.H; n.Wout = to.W; n.B = B;
+                    run_conv(c, n, 1, st);
+                    res = TT(op.out);
+                }
+                ConvArgs b; conv_defaults(b);
+                b.in = TT(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
+                b.w = op.c2.wf; b.res = res; b.res_bs = PS;
+                set_tan(c, b, op.n2, TP(op.h1));
+                b.out = TT(op.out); b.out_bs = PS; b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
+                run_conv(c, b, 9, st);
+                break;
+            }
+            case OP_ATTN: {
+                const int C = to.C, T = HW;
+                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
+                NS sp = nstats(c, c->statsP, op.n1);
+                NS stt = nstats(c, c->statsT, op.n1);
+                launch_gn_apply(1, TT(op.in), PS, TP(op.in), 0, nullptr, 0, TT(op.hn), PS, 0, B, C, HW,
+                                cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                ConvArgs a; conv_defaults(a);
+                a.in = TT(op.hn); a.in_bs = PS; a.Cin = C; a.Hin = to.H; a.Win = to.W;
+                a.w = op.qkvc.wf; a.pad = 0;
+                a.out = TT(op.qkv); a.out_bs = PS; a.Cout = 3 * C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 1, st);
+                float* q = TP(op.qkv); float* k = q + (long)C * T; float* v = k + (long)C * T;
+                float* dq = TT(op.qkv); float* dk = dq + (long)C * T; float* dv = dk + (long)C * T;
+                GemmArgs g; std::memset(&g, 0, sizeof(g));
+                g.A = dq; g.sam = 1; g.sak = T; g.sab = PS;
+                g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = 0;
+                g.C = TT(op.S); g.scm = T; g.scn = 1; g.scb = PS;
+                g.M = T; g.N = T; g.K = C; g.batch = B; g.alpha = 1.f; g.beta = 0.f;
+                launch_gemm(g, st);
+                g.A = q; g.sab = 0; g.Bm = dk; g.sbb = PS; g.beta = 1.f;
+                launch_gemm(g, st);
+                for (int b = 0; b < B; ++b)
+                    launch_softmax_jac(TT(op.S) + (long)b * PS, TP(op.S), T, T, T, 1.0f / std::sqrt((float)C), st);
+                GemmArgs h; std::memset(&h, 0, sizeof(h));
+                h.A = dv; h.sam = T; h.sak = 1; h.sab = PS;
+                h.Bm = TP(op.S); h.sbk = 1; h.sbn = T; h.sbb = 0;
+                h.C = TT(op.o); h.scm = T; h.scn = 1; h.scb = PS;
+                h.M = C; h.N = T; h.K = T; h.batch = B; h.alpha = 1.f; h.beta = 0.f;
+                launch_gemm(h, st);
+                h.A = v; h.sab = 0; h.Bm = TT(op.S); h.sbb = PS; h.beta = 1.f;
+                launch_gemm(h, st);
+                ConvArgs pr; conv_defaults(pr);
+                pr.in = TT(op.o); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
+                pr.w = op.proj.wf; pr.pad = 0; pr.res = TT(op.in); pr.res_bs = PS;
+                pr.out = TT(op.out); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
+                run_conv(c, pr, 1, st);
+                break;
+            }
+            case OP_DOWN: case OP_UP: {
+                const Tens& ti = c->tens[op.in];
+                ConvArgs a; conv_defaults(a);
+                a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
+                a.w = op.conv.wf;
+                if (op.kind == OP_DOWN) { a.stride = 2; a.pad = 0; } else { a.upsample = 1; }
+                a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                break;
+            }
+            case OP_OUT: {
+                const Tens& ti = c->tens[op.in];
+                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), ti.H * ti.W, B, st);
+                ConvArgs a; conv_defaults(a);
+                a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
+                a.w = op.conv.wf;
+                set_tan(c, a, op.n1, TP(op.in));
+                a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                break;
+            }
+        }
+    }
+    return 0;
+}
+
+// ------------------------------ cotangent ----------------------------------
+void cot_stats(loco_ctx* c, const NormP& n, const float* d, long dbs, const float* x, int HW, int B, int kind,
+               hipStream_t st) {
+    NS sp = nstats(c, c->statsP, n);
+    NS stt = nstats(c, c->statsT, n);
+    launch_gn_tstats(d, dbs, x, 0, B, n.C, HW, c->cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, kind, stt.tst,
+                     c->stats_per_sample, c->red, st);
+}
+
+// ge: cotangent of eps [B][n]; result A[B][n] = conv_in^T(...) + gx0
+int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, int B, hipStream_t st) {
+    const loco_unet_cfg& cfg = c->cfg;
+    const long PS = c->per_sample;
+    const int G = cfg.gn_groups;
+    auto TP = [&](int id) { return c->arenaP + c->tens[id].off; };
+    auto TG = [&](int id) { return c->arenaT + c->tens[id].off; };   // cotangent of tensor id
+    for (int oi = (int)c->ops.size() - 1; oi >= 0; --oi) {
+        Op& op = c->ops[oi];
+        const Tens& to = c->tens[op.out];
+        const int HW = to.H * to.W;
+        switch (op.kind) {
+            case OP_OUT: {
+                const Tens& ti = c->tens[op.in];
+                ConvArgs a; conv_defaults(a);
+                a.in = ge; a.in_bs = c->n_in; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
+                a.w = op.conv.wd;
+                a.out = TG(op.a1); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
+                run_conv(c, a, 9, st);
+                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), ti.H * ti.W, B, 1, st);
+                NS sp = nstats(c, c->statsP, op.n1);
+                NS stt = nstats(c, c->statsT, op.n1);
+                launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 0, B, ti.C, ti.H * ti.W, G,
+                                sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                break;
+            }
+            case OP_UP: {
+                const Tens& ti = c->tens[op.in];
+                ConvArgs a; conv_defaults(a);
+                a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
+                a.w = op.conv.wd;
+                a.out = TG(op.up); a.out_bs = PS; a.Cout = ti.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                launch_pool2x2_sum(TG(op.up), PS, TG(op.in), PS, 0, B, ti.C, ti.H, ti.W, st);
+                break;
+            }
+            case OP_DOWN: {
+                const Tens& ti = c->tens[op.in];
+                ConvArgs a; conv_defaults(a);
+                a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
+                a.w = op.conv.wd; a.zins = 1; a.pad = 2; a.accumulate = op.in_is_skip ? 1 : 0;
+                a.out = TG(op.in); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
+                run_conv(c, a, 9, st);
+                break;
+            }
+            case OP_RES: {
+                const Tens& ti = c->tens[op.in];
+                // g_a2 = dgrad conv2 (g_out)  -> slot h1
+                ConvArgs a; conv_defaults(a);
+                a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
+                a.w = op.c2.wd;
+                a.out = TG(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 9, st);
+                cot_stats(c, op.n2, TG(op.h1), PS, TP(op.h1), HW, B, 1, st);
+                // g_a1 = dgrad conv1 ( norm2/silu cotangent of g_a2 )  -> slot a1
+                ConvArgs b; conv_defaults(b);
+                b.in = TG(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
+                b.w = op.c1.wd;
+                set_tan(c, b, op.n2, TP(op.h1));
+                b.mode = CM_COT_SILU;
+                b.out = TG(op.a1); b.out_bs = PS; b.Cout = ti.C; b.Hout = ti.H; b.Wout = ti.W; b.B = B;
+                run_conv(c, b, 9, st);
+                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), HW, B, 1, st);
+                NS sp = nstats(c, c->statsP, op.n1);
+                NS stt = nstats(c, c->statsT, op.n1);
+                int acc = op.in_is_skip ? 1 : 0;
+                if (op.has_nin) {
+                    ConvArgs n; conv_defaults(n);
+                    n.in = TG(op.out); n.in_bs = PS; n.Cin = to.C; n.Hin = to.H; n.Win = to.W;
+                    n.w = op.nin.wd; n.pad = 0; n.accumulate = acc;
+                    n.out = TG(op.in); n.out_bs = PS; n.Cout = ti.C; n.Hout = ti.H; n.Wout = ti.W; n.B = B;
+                    run_conv(c, n, 1, st);
+                    launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 1, B, ti.C, HW, G,
+                                    sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                } else {
+                    launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, TG(op.out), PS, TG(op.in), PS, acc, B, ti.C, HW,
+                                    G, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                }
+                break;
+            }
+            case OP_ATTN: {
+                const int C = to.C, T = HW;
+                float* q = TP(op.qkv); float* k = q + (long)C * T; float* v = k + (long)C * T;
+                float* gq = TG(op.qkv); float* gk = gq + (long)C * T; float* gv = gk + (long)C * T;
+                // g_o = proj^T g_out
+                ConvArgs pr; conv_defaults(pr);
+                pr.in = TG(op.out); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
+                pr.w = op.proj.wd; pr.pad = 0;
+                pr.out = TG(op.o); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
+                run_conv(c, pr, 1, st);
+                // g_v[c][j] = sum_i g_o[c][i] P[i][j]
+                GemmArgs g; std::memset(&g, 0, sizeof(g));
+                g.A = TG(op.o); g.sam = T; g.sak = 1; g.sab = PS;
+                g.Bm = TP(op.S); g.sbk = T; g.sbn = 1; g.sbb = 0;
+                g.C = gv; g.scm = T; g.scn = 1; g.scb = PS;
+                g.M = C; g.N = T; g.K = T; g.batch = B; g.alpha = 1.f; g.beta = 0.f;
+                launch_gemm(g, st);
+                // g_P[i][j] = sum_c g_o[c][i] v[c][j]
+                GemmArgs h; std::memset(&h, 0, sizeof(h));
+                h.A = TG(op.o); h.sam = 1; h.sak = T; h.sab = PS;
+                h.Bm = v; h.sbk = T; h.sbn = 1; h.sbb = 0;
+                h.C = TG(op.S); h.scm = T; h.scn = 1; h.scb = PS;
+                h.M = T; h.N = T; h.K = C; h.batch = B; h.alpha = 1.f; h.beta = 0.f;
+                launch_gemm(h, st);
+                for (int b = 0; b < B; ++b)
+                    launch_softmax_jac(TG(op.S) + (long)b * PS, TP(op.S), T, T, T, 1.0f / std::sqrt((float)C), st);
+                // g_q[c][i] = sum_j k[c][j] g_S[i][j]
+                GemmArgs gq_; std::memset(&gq_, 0, sizeof(gq_));
+                gq_.A = k; gq_.sam = T; gq_.sak = 1; gq_.sab = 0;
+                gq_.Bm = TG(op.S); gq_.sbk = 1; gq_.sbn = T; gq_.sbb = PS;
+                gq_.C = gq; gq_.scm = T; gq_.scn = 1; gq_.scb = PS;
+                gq_.M = C; gq_.N = T; gq_.K = T; gq_.batch = B; gq_.alpha = 1.f; gq_.beta = 0.f;
+                launch_gemm(gq_, st);
+                // g_k[c][j] = sum_i q[c][i] g_S[i][j]
+                GemmArgs gk_ = gq_;
+                gk_.A = q; gk_.Bm = TG(op.S); gk_.sbk = T; gk_.sbn = 1; gk_.C = gk;
+                launch_gemm(gk_, st);
+                // g_hn = Wqkv^T g_qkv
+                ConvArgs a; conv_defaults(a);
+                a.in = TG(op.qkv); a.in_bs = PS; a.Cin = 3 * C; a.Hin = to.H; a.Win = to.W;
+                a.w = op.qkvc.wd; a.pad = 0;
+                a.out = TG(op.hn); a.out_bs = PS; a.Cout = C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                run_conv(c, a, 1, st);
+                cot_stats(c, op.n1, TG(op.hn), PS, TP(op.in), HW, B, 2, st);
+                NS sp = nstats(c, c->statsP, op.n1);
+                NS stt = nstats(c, c->statsT, op.n1);
+                launch_gn_apply(3, TG(op.hn), PS, TP(op.in), 0, TG(op.out), PS, TG(op.in), PS,
+                                op.in_is_skip ? 1 : 0, B, C, HW, G, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                break;
+            }
+            case OP_CONV_IN: {
+                ConvArgs a; conv_defaults(a);
+                a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
+                a.w = op.conv.wd; a.res = gx0; a.res_bs = c->n_in;
+                a.out = Aout; a.out_bs = c->n_in; a.Cout = cfg.in_channels; a.Hout = cfg.resolution;
+                a.Wout = cfg.resolution; a.B = B;
+                run_conv(c, a, 9, st);
+                break;
+            }
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =============================== C ABI =======================================
+extern "C" {
+
+const char* loco_version(void) { return "loco_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int loco_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
+    if (!cfg || !out) return -2;
+    loco_ctx* c = new loco_ctx();
+    c->cfg = *cfg;
+    *out = c;
+    if (cfg->max_batch < 1 || cfg->num_levels < 1 || cfg->num_levels > 8) { c->err = "bad config"; return -2; }
+    {
+        int r = cfg->resolution;
+        for (int l = 0; l < cfg->num_levels - 1; ++l) r /= 2;
+        if (r < 8 || (cfg->resolution & (cfg->resolution - 1))) {
+            c->err = "resolution must be a power of two with >= 8x8 at the coarsest level";
+            return -2;
+        }
+        if (cfg->ch % 32) { c->err = "ch must be a multiple of 32"; return -2; }
+    }
+    if (build_program(c)) return -2;
+    declare_all(c);
+    const size_t MB = (size_t)cfg->max_batch;
+    if (dalloc(c, &c->arenaP, MB * c->per_sample) || dalloc(c, &c->arenaT, MB * c->per_sample)) return -1;
+    if (dalloc(c, &c->statsP, MB * c->stats_per_sample) || dalloc(c, &c->statsT, MB * c->stats_per_sample)) return -1;
+    if (dalloc(c, &c->red, (size_t)1 << 20)) return -1;
+    c->partial_floats = (size_t)64 << 20;   // 256 MB split-K workspace
+    if (dalloc(c, &c->partial, c->partial_floats)) return -1;
+    if (dalloc(c, &c->eps_buf, MB * c->n_in) || dalloc(c, &c->gx0, MB * c->n_in) || dalloc(c, &c->ge, MB * c->n_in))
+        return -1;
+    if (dalloc(c, &c->tmpA, (size_t)64 * c->n_in)) return -1;
+    if (dalloc(c, &c->G, 64 * 64) || dalloc(c, &c->Q, 64 * 64) || dalloc(c, &c->W, 64)) return -1;
+    {
+        size_t nblk = ((size_t)c->n_in + 255) / 256;
+        if (dalloc(c, &c->gscratch, nblk * 64 * 64 + 4096)) return -1;
+    }
+    if (dalloc(c, &c->alphas, 256)) return -1;
+    if (dalloc(c, &c->mask, (size_t)c->n_in) || dalloc(c, &c->mask_idx, (size_t)c->n_in)) return -1;
+    HIPCHK(c, hipEventCreate(&c->ev0));
+    HIPCHK(c, hipEventCreate(&c->ev1));
+    return 0;
+}
+
+void loco_destroy(loco_ctx* c) {
+    if (!c) return;
+    for (float* p : c->owned) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+const char* loco_last_error(loco_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int loco_load_param(loco_ctx* c, const char* name, const void* data, const int64_t* shape, int32_t ndim,
+                    int32_t is_device) {
+    if (!c) return -2;
+    if (c->finalized) { c->err = "parameters already finalised"; return -2; }
+    auto it = c->params.find(name);
+    if (it == c->params.end()) { c->err = std::string("unknown parameter: ") + name; return -3; }
+    HostParam& hp = it->second;
+    if ((int)hp.shape.size() != ndim) { c->err = std::string("rank mismatch for ") + name; return -3; }
+    size_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (hp.shape[i] != shape[i]) { c->err = std::string("shape mismatch for ") + name; return -3; }
+        cnt *= (size_t)shape[i];
+    }
+    hp.data.resize(cnt);
+    if (is_device) HIPCHK(c, hipMemcpy(hp.data.data(), data, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    else std::memcpy(hp.data.data(), data, cnt * sizeof(float));
+    hp.loaded = true;
+    return 0;
+}
+
+int loco_params_missing(loco_ctx* c) {
+    if (!c) return -2;
+    if (c->finalized) return 0;
+    int miss = 0;
+    for (auto& n : c->param_order)
+        if (!c->params[n].loaded) { if (!miss) c->err = "missing parameter: " + n; ++miss; }
+    return miss;
+}
+
+int loco_unet_forward(loco_ctx* c, const float* x, float t, int32_t B, float* eps, void* stream) {
+    if (!c) return -2;
+    if (B < 1 || B > c->cfg.max_batch) { c->err = "batch exceeds max_batch"; return -2; }
+    if (finalize_params(c)) return -3;
+    hipStream_t st = (hipStream_t)stream;
+    c->primal_ok = false;
+    if (forward_pass(c, x, t, B, c->arenaP, c->statsP, st)) return -1;
+    c->primal_B = B;
+    launch_copy(c->arenaP + c->tens[c->eps_t].off, c->per_sample, eps, c->n_in, 0, B, c->n_in, st);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_ddim_step(loco_ctx* c, const float* x, float t, float at, float at_next, float eta, const float* noise,
+                   int32_t B, float* x_next, void* stream) {
+    if (!c) return -2;
+    if (eta != 0.f && !noise) { c->err = "eta != 0 needs a noise tensor"; return -2; }
+    int rc = loco_unet_forward(c, x, t, B, c->eps_buf, stream);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float s1 = std::sqrt(1.0f - at), s2 = std::sqrt(at), s3 = std::sqrt(at_next);
+    float ce, cn = 0.f;
+    if (eta == 0.f) {
+        ce = std::sqrt(1.0f - at_next);
+    } else {
+        float sigma = std::sqrt((1.0f - at / at_next) * (1.0f - at_next) / (1.0f - at));
+        ce = std::sqrt(1.0f - at_next - eta * sigma * sigma);
+        cn = eta * sigma;
+    }
+    launch_ddim_step(x, c->eps_buf, eta == 0.f ? nullptr : noise, x_next, (long)B * c->n_in, s2, s1, s3, ce, cn, st);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_t* mask, int32_t use_et,
+                    void* stream) {
+    if (!c) return -2;
+    if (finalize_params(c)) return -3;
+    hipStream_t st = (hipStream_t)stream;
+    if (forward_pass(c, x, t, 1, c->arenaP, c->statsP, st)) return -1;
+    c->primal_B = 1;
+    if (use_et) { c->p_cv = 0.f; c->p_ce = 1.f; }
+    else { c->p_cv = 1.0f / std::sqrt(at); c->p_ce = -std::sqrt(1.0f - at) / std::sqrt(at); }
+    c->has_mask = (mask != nullptr);
+    c->mask_L = c->n_in;
+    if (mask) {
+        HIPCHK(c, hipMemcpyAsync(c->mask, mask, (size_t)c->n_in, hipMemcpyDeviceToDevice, st));
+        std::vector<uint8_t> hm((size_t)c->n_in);
+        HIPCHK(c, hipMemcpyAsync(hm.data(), mask, (size_t)c->n_in, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        std::vector<int> idx;
+        idx.reserve(c->n_in);
+        for (int i = 0; i < c->n_in; ++i)
+            if (hm[i]) idx.push_back(i);
+        c->mask_L = (long)idx.size();
+        if (!idx.empty())
+            HIPCHK(c, hipMemcpyAsync(c->mask_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    HIPCHK(c, hipGetLastError());
+    c->primal_ok = true;
+    return 0;
+}
+
+int loco_pmp_jvp(loco_ctx* c, const float* V, int32_t k, float* U, void* stream) {
+    if (!c) return -2;
+    if (!c->primal_ok) { c->err = "loco_pmp_primal has not been called"; return -2; }
+    hipStream_t st = (hipStream_t)stream;
+    const int MB = c->cfg.max_batch;
+    for (int b0 = 0; b0 < k; b0 += MB) {
+        int B = (k - b0 < MB) ? k - b0 : MB;
+        const float* Vc = V + (long)b0 * c->n_in;
+        if (tangent_pass(c, Vc, B, st)) return -1;
+        // U = mask * (cv*V + ce*dEps); dEps lives strided in arena T -> gather through eps_buf
+        launch_copy(c->arenaT + c->tens[c->eps_t].off, c->per_sample, c->eps_buf, c->n_in, 0, B, c->n_in, st);
+        launch_masked_axpby(Vc, c->eps_buf, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce,
+                            U + (long)b0 * c->n_in, B, c->n_in, st);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_pmp_vjp(loco_ctx* c, const float* U, int32_t k, float* A, void* stream) {
+    if (!c) return -2;
+    if (!c->primal_ok) { c->err = "loco_pmp_primal has not been called"; return -2; }
+    hipStream_t st = (hipStream_t)stream;
+    const int MB = c->cfg.max_batch;
+    for (int b0 = 0; b0 < k; b0 += MB) {
+        int B = (k - b0 < MB) ? k - b0 : MB;
+        launch_cot_seed(U + (long)b0 * c->n_in, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce, c->ge, c->gx0, B,
+                        c->n_in, st);
+        if (cotangent_pass(c, c->ge, c->gx0, A + (long)b0 * c->n_in, B, st)) return -1;
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_orthonormalize(loco_ctx* c, float* A, int32_t k, int64_t n, float* s, void* stream) {
+    if (!c) return -2;
+    if (k < 1 || k > 64 || n > c->n_in) { c->err = "orthonormalize: need k <= 64 and n <= C*H*W"; return -2; }
+    hipStream_t st = (hipStream_t)stream;
+    launch_gram(A, k, n, c->G, c->gscratch, st);
+    launch_jacobi_eig(c->G, k, c->W, c->Q, st);
+    launch_rotate_rows(A, c->tmpA, k, n, c->Q, c->W, 0, st);
+    // singular values of the input = sqrt(eigenvalues of A A^T)
+    HIPCHK(c, hipMemcpyAsync(A, c->tmpA, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    launch_sign_fix(A, k, n, s, c->W, st);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_qr_rows(loco_ctx* c, float* A, int32_t k, int64_t n, void* stream) {
+    if (!c) return -2;
+    if (k < 1 || k > 64 || n > c->n_in) { c->err = "qr_rows: need k <= 64 and n <= C*H*W"; return -2; }
+    hipStream_t st = (hipStream_t)stream;
+    for (int rep = 0; rep < 2; ++rep) {   // CholeskyQR2
+        launch_gram(A, k, n, c->G, c->gscratch, st);
+        launch_cholesky(c->G, k, st);
+        launch_trsm_rows(A, c->tmpA, k, n, c->G, st);
+        HIPCHK(c, hipMemcpyAsync(A, c->tmpA, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_convergence(loco_ctx* c, const float* Vprev, const float* V, int64_t count, float atol, float* out2,
+                     void* stream) {
+    if (!c) return -2;
+    launch_convergence(Vprev, V, count, atol, 1e-5f, out2, c->gscratch, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_null_project(loco_ctx* c, const float* Vm, int32_t k, const float* Vn, int32_t k0, int64_t n, float* out,
+                      void* stream) {
+    if (!c) return -2;
+    if (k < 1 || k > 64 || k0 > 64 || n > c->n_in) { c->err = "null_project: bad sizes"; return -2; }
+    hipStream_t st = (hipStream_t)stream;
+    if (Vn && k0 > 0) {
+        launch_cross_gram(Vn, k0, Vm, k, n, c->G, c->gscratch, st);
+        launch_project_rows(Vm, k, Vn, k0, n, c->G, out, st);
+    } else if (out != Vm) {
+        HIPCHK(c, hipMemcpyAsync(out, Vm, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    launch_normalize_rows(out, k, n, c->gscratch, st);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_edit_axpy(loco_ctx* c, const float* x, const float* v, const float* alphas, int32_t B, int64_t n, float* out,
+                   void* stream) {
+    if (!c) return -2;
+    if (B > 256) { c->err = "edit_axpy: B > 256"; return -2; }
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(c, hipMemcpyAsync(c->alphas, alphas, B * sizeof(float), hipMemcpyHostToDevice, st));
+    launch_edit_axpy(x, v, c->alphas, B, n, out, st);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int64_t loco_mask_count(loco_ctx* c) { return c ? c->mask_L : -1; }
+
+int loco_mask_gather(loco_ctx* c, const float* U, int32_t k, float* out, void* stream) {
+    if (!c) return -2;
+    if (!c->primal_ok) { c->err = "loco_pmp_primal has not been called"; return -2; }
+    hipStream_t st = (hipStream_t)stream;
+    if (!c->has_mask) {
+        HIPCHK(c, hipMemcpyAsync(out, U, (size_t)k * c->n_in * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    launch_mask_gather(U, c->mask_idx, c->mask_L, c->n_in, k, out, st);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+double loco_unet_flops(loco_ctx* c) {
+    if (!c) return 0.0;
+    if (!c->finalized && finalize_params(c)) return 0.0;
+    return c->flops;
+}
+int64_t loco_workspace_bytes(loco_ctx* c) { return c ? (int64_t)c->bytes : 0; }
+
+int loco_timer_start(loco_ctx* c, void* stream) {
+    if (!c) return -2;
+    HIPCHK(c, hipEventRecord(c->ev0, (hipStream_t)stream));
+    return 0;
+}
+int loco_timer_stop(loco_ctx* c, void* stream, float* ms) {
+    if (!c) return -2;
+    HIPCHK(c, hipEventRecord(c->ev1, (hipStream_t)stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+int64_t loco_debug_tensor(loco_ctx* c, const char* name, float* dst, int64_t cap, void* stream) {
+    if (!c) return -2;
+    std::string nm(name);
+    int arena = 0;   // "T:" prefix selects the tangent/cotangent arena, "h1:" the conv1 output of a block
+    if (nm.rfind("T:", 0) == 0) { arena = 1; nm = nm.substr(2); }
+    bool want_h1 = false;
+    if (nm.rfind("h1:", 0) == 0) { want_h1 = true; nm = nm.substr(3); }
+    for (auto& op : c->ops) {
+        if (op.name != nm) continue;
+        int id = want_h1 ? op.h1 : op.out;
+        if (id < 0) return -3;
+        const Tens& t = c->tens[id];
+        int64_t cnt = (int64_t)t.C * t.H * t.W;
+        int B = arena ? 1 : (c->primal_B > 0 ? c->primal_B : 1);
+        if (cnt * B > cap) { c->err = "debug buffer too small"; return -4; }
+        float* base = (arena ? c->arenaT : c->arenaP) + t.off;
+        launch_copy(base, c->per_sample, dst, cnt, 0, B, cnt, (hipStream_t)stream);
+        return cnt * B;
+    }
+    c->err = "no such op: " + nm;
+    return -3;
+}
+
+}  // extern "C"

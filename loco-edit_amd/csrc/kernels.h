@@ -1,0 +1,145 @@
+// Internal launch interface between the engine (engine.hip) and the gfx950
+// kernels.  All tensors are fp32 NCHW with an explicit batch stride so that a
+// tensor may live inside a wider (concatenated) buffer and a primal (B=1)
+// tensor can be broadcast over a probe batch with stride 0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace loco {
+
+enum ConvMode : int {
+    CM_NONE = 0,      // raw input
+    CM_GN_SILU = 1,   // a = silu(sc*x + sh)                         (forward, ResnetBlock norm->swish->conv)
+    CM_GN = 2,        // a = sc*x + sh                               (forward, AttnBlock norm->q/k/v)
+    CM_TAN_SILU = 3,  // a = silu'(y) * sc*(d - m1 - xh*m2)          (tangent of norm->swish)
+    CM_COT_SILU = 4,  // a = rstd*(gamma*silu'(y)*d - m1 - xh*m2)    (cotangent of norm->swish, fused into next dgrad)
+};
+
+struct ConvArgs {
+    // input activation (or tangent / cotangent) tensor
+    const float* in; long in_bs; int Cin, Hin, Win;
+    // primal tensor matching `in` (modes TAN/COT), broadcast with prim_bs = 0
+    const float* prim; long prim_bs;
+    // weights, layout [Cin][TAPS][Cout]
+    const float* w;
+    float* out; long out_bs; int Cout, Hout, Wout;
+    const float* bias;                   // [Cout] or nullptr
+    const float* bias2; long bias2_bs;   // [B][Cout] or nullptr (temb projection)
+    const float* res; long res_bs;       // residual, same geometry as out, or nullptr (may alias out)
+    // GroupNorm prologue data
+    const float* sc; const float* sh; long scsh_bs;   // per (b_prim, channel)
+    const float* mr; long mr_bs;                      // per (b_prim, group): {mean, rstd}
+    const float* gamma_;                              // per channel GroupNorm gain (mode COT)
+    const float* tst; long tst_bs;                    // per (b, group): {m1, m2}
+    int cpg;                                          // channels per group
+    int mode;
+    int stride;      // 1 or 2
+    int pad;         // top/left zero padding in input coords (1: 3x3 s1, 0: 3x3 s2 / 1x1, 2: zero-insert dgrad)
+    int upsample;    // input is read through a nearest x2 upsample
+    int zins;        // input is read through stride-2 zero insertion (dgrad of the stride-2 conv)
+    int accumulate;  // out += result
+    int nsplit;      // split-K factor (>1: raw partials go to `partial`, epilogue by conv_splitk_reduce)
+    float* partial;
+    int B;
+};
+
+void launch_conv(const ConvArgs& a, int taps, hipStream_t st);
+// workspace (floats) a conv launch with these args needs for split-K partials
+size_t conv_partial_floats(const ConvArgs& a);
+int conv_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int taps);
+
+// Generic strided batched GEMM  C[b](m,n) = alpha * sum_k A[b](m,k) B[b](k,n) + beta*C + bias[m] + R[b](m,n)
+struct GemmArgs {
+    const float* A; long sam, sak, sab;
+    const float* Bm; long sbk, sbn, sbb;
+    float* C; long scm, scn, scb;
+    const float* bias;           // per m or nullptr
+    const float* R; long srb;    // residual with C's (m,n) strides, batch stride srb; or nullptr
+    int M, N, K, batch;
+    float alpha, beta;
+};
+void launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// ---- GroupNorm statistics -------------------------------------------------
+// x: [B][C][HW] with batch stride bs; groups of cpg channels (contiguous cpg*HW floats)
+// writes mr[b][g] = {mean, rstd}, sc[b][c] = gamma*rstd, sh[b][c] = beta - mean*rstd*gamma
+void launch_gn_stats(const float* x, long bs, int B, int C, int HW, int G, float eps,
+                     const float* gamma, const float* beta,
+                     float* mr, float* sc, float* sh, long stats_bs, double* scratch, hipStream_t st);
+// tangent / cotangent group statistics:
+//   kind 0 (tangent):            z = d
+//   kind 1 (cotangent, silu):    z = gamma * silu'(y) * d
+//   kind 2 (cotangent, no silu): z = gamma * d
+//   tst[b][g] = { mean_g(z), mean_g(xh * z) },  xh = (x - mean)*rstd of the primal (prim_bs may be 0)
+void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int B, int C, int HW, int G,
+                      const float* sc, const float* sh, const float* mr, long pbs_c, long pbs_g,
+                      int kind, float* tst, long tst_bs, double* scratch, hipStream_t st);
+// elementwise GroupNorm applications (no conv behind them):
+//   kind 0: out = sc*x + sh                                    (attention norm forward)
+//   kind 1: out = sc*(d - m1 - xh*m2)                          (attention norm tangent)
+//   kind 2: out (+)= base + rstd*(gamma*silu'(y)*d - m1 - xh*m2)  (resblock norm1 cotangent)
+//   kind 3: out (+)= base + rstd*(gamma*d - m1 - xh*m2)           (attention norm cotangent)
+void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x_bs,
+                     const float* base, long base_bs, float* out, long out_bs, int accumulate,
+                     int B, int C, int HW, int G, const float* sc, const float* sh, const float* mr,
+                     long pbs_c, long pbs_g, const float* tst, long tst_bs, hipStream_t st);
+
+// ---- attention helpers ------------------------------------------------------
+// rows: [R][T] contiguous; softmax over T in place (S -> P)
+void launch_softmax_rows(float* S, long rows, int T, hipStream_t st);
+// dP = P * (dS - rowsum(P*dS)) * scale, in place on dS; P has prow rows broadcast: row r uses P row (r % prow_mod)
+void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows, float scale, hipStream_t st);
+
+// ---- small ops ---------------------------------------------------------------
+// temb pipeline: sinusoid(t) -> dense0 -> swish -> dense1 -> swish -> all per-block projections
+void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
+                 const float* w1, const float* b1, float* scratch, hipStream_t st);   // scratch: [temb_ch] swish(temb)
+void launch_temb_proj(const float* tact, int temb_ch, const float* w, const float* b, int cout,
+                      float* out, hipStream_t st);
+// out[b][c][y][x] = sum of the 2x2 block of in[b][c][2y..][2x..]   (adjoint of nearest x2)
+void launch_pool2x2_sum(const float* in, long in_bs, float* out, long out_bs, int accumulate,
+                        int B, int C, int Hout, int Wout, hipStream_t st);
+// strided copy / add of [B][C][HW] tensors
+void launch_copy(const float* in, long in_bs, float* out, long out_bs, int accumulate,
+                 int B, long per_sample, hipStream_t st);
+
+// ---- DDIM / x0 algebra --------------------------------------------------------
+void launch_ddim_step(const float* x, const float* eps, const float* noise, float* out, long count,
+                      float c_x0_x, float c_x0_e, float c_next_x0, float c_next_e, float c_noise,
+                      hipStream_t st);
+// U = mask * (cv*V + ce*dEps)
+void launch_masked_axpby(const float* V, const float* dE, const uint8_t* mask, float cv, float ce,
+                         float* U, int k, long n, hipStream_t st);
+// G = mask*U (cotangent seed); outputs gE = ce*G  and keeps cv*G in gX0
+void launch_cot_seed(const float* U, const uint8_t* mask, float cv, float ce, float* gE, float* gX0,
+                     int k, long n, hipStream_t st);
+void launch_add(const float* a, const float* b, float* out, long count, hipStream_t st);
+
+// ---- solver --------------------------------------------------------------------
+// G[k][k] (double) = A A^T, A: [k][n] fp32
+void launch_gram(const float* A, int k, long n, double* G, double* scratch, hipStream_t st);
+// cross Gram C[k1][k2] (double) = A B^T
+void launch_cross_gram(const float* A, int k1, const float* B, int k2, long n, double* C, double* scratch,
+                       hipStream_t st);
+// symmetric eigen-decomposition of G (k<=64, double, cyclic Jacobi in one workgroup):
+// evals descending in w[k], eigenvectors as rows of Q[k][k]
+void launch_jacobi_eig(double* G, int k, double* w, double* Q, hipStream_t st);
+// A <- diag(scale) * Q * A   (k x n, in place, via temp copy), scale from w: mode 0: 1/sqrt(max(w,tiny)); mode 1: none
+void launch_rotate_rows(const float* Ain, float* Aout, int k, long n, const double* Q, const double* w,
+                        int mode, hipStream_t st);
+void launch_sign_fix(float* A, int k, long n, float* s_out, const double* w, hipStream_t st);
+// Cholesky factor of G (k x k double, lower) in one workgroup, then A <- L^{-1} A
+void launch_cholesky(double* G, int k, hipStream_t st);
+void launch_trsm_rows(const float* Ain, float* Aout, int k, long n, const double* L, hipStream_t st);
+void launch_convergence(const float* a, const float* b, long count, float atol, float rtol, float* out2,
+                        double* scratch, hipStream_t st);
+// out = Vm - C^T Vn  (C: [k0][k] double = Vn Vm^T), then row-normalise
+void launch_project_rows(const float* Vm, int k, const float* Vn, int k0, long n, const double* C,
+                         float* out, hipStream_t st);
+void launch_normalize_rows(float* A, int k, long n, double* scratch, hipStream_t st);
+void launch_edit_axpy(const float* x, const float* v, const float* alphas_dev, int B, long n, float* out,
+                      hipStream_t st);
+void launch_mask_gather(const float* U, const int* idx, long L, long n, int k, float* out, hipStream_t st);
+
+}  // namespace loco

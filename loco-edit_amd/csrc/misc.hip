@@ -1,0 +1,498 @@
+// Bandwidth-bound kernels around the convolutions: GroupNorm statistics (wave
+// shuffle + LDS reductions, emitting only per-channel scale/shift for the conv
+// prologue), their tangent / cotangent forms, the attention softmax and its
+// Jacobian, time embedding, DDIM algebra.  All 16-byte vectorised, grid-strided.
+#include "kernels.h"
+
+namespace loco {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_maxf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+// block-wide sum of a double over 256 threads; result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
+    return r;
+}
+__device__ __forceinline__ float sigm(float y) { return 1.0f / (1.0f + __expf(-y)); }
+__device__ __forceinline__ float dsilu(float y) {
+    float sg = sigm(y);
+    return sg * (1.0f + y * (1.0f - sg));
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm statistics.  grid = (nsplit, G, B).  Each block reduces a 16B-aligned
+// slice of the group's contiguous cpg*HW floats with a two-pass (mean, then
+// centred M2) scheme; slices are merged with Chan's formula in double.
+// scratch[((b*G+g)*nsplit + s)*3 + {0,1,2}] = {n, mean, M2}
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, long bs, long len, double* scratch) {
+    __shared__ double sm[4];
+    const int s = blockIdx.x, nsplit = gridDim.x, g = blockIdx.y, b = blockIdx.z, G = gridDim.y;
+    const float* p = x + (long)b * bs + (long)g * len;
+    long per = ((len / 4 + nsplit - 1) / nsplit) * 4;
+    long beg = (long)s * per, end = beg + per < len ? beg + per : len;
+    if (beg > end) beg = end;
+    const long n4 = (end - beg) / 4;
+    const float4* p4 = reinterpret_cast<const float4*>(p + beg);
+    double sum = 0.0;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        float4 v = p4[i];
+        sum += (double)((v.x + v.y) + (v.z + v.w));
+    }
+    for (long i = beg + n4 * 4 + threadIdx.x; i < end; i += 256) sum += (double)p[i];
+    double tot = block_sum(sum, sm);
+    const double cnt = (double)(end - beg);
+    const float mean = cnt > 0 ? (float)(tot / cnt) : 0.f;
+    double m2 = 0.0;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        float4 v = p4[i];
+        float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+        m2 += (double)((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
+    }
+    for (long i = beg + n4 * 4 + threadIdx.x; i < end; i += 256) {
+        float a0 = p[i] - mean;
+        m2 += (double)(a0 * a0);
+    }
+    // exact correction for the float-rounded mean: sum (x-m)^2 = M2 + n*(mu-m)^2, handled by storing m itself
+    double M2 = block_sum(m2, sm);
+    if (threadIdx.x == 0) {
+        double* o = scratch + (((long)b * G + g) * nsplit + s) * 3;
+        double mu = cnt > 0 ? tot / cnt : 0.0;
+        // M2 about the float mean -> about the exact slice mean
+        double d = mu - (double)mean;
+        o[0] = cnt;
+        o[1] = mu;
+        o[2] = M2 - cnt * d * d;
+    }
+}
+
+__global__ void gn_finalize_kernel(const double* scratch, int nsplit, int G, int C, float eps,
+                                   const float* gamma, const float* beta, float* mr, float* sc, float* sh,
+                                   long sbs) {
+    const int b = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double* s = scratch + ((long)b * G + g) * nsplit * 3;
+    double n = 0, mean = 0, M2 = 0;
+    for (int i = 0; i < nsplit; ++i) {
+        double nb = s[3 * i], mb = s[3 * i + 1], Mb = s[3 * i + 2];
+        if (nb <= 0) continue;
+        double nn = n + nb, d = mb - mean;
+        mean += d * nb / nn;
+        M2 += Mb + d * d * n * nb / nn;
+        n = nn;
+    }
+    double var = M2 / n;
+    float meanf = (float)mean;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mr[(long)b * sbs + g * 2] = meanf;
+    mr[(long)b * sbs + g * 2 + 1] = rstd;
+    const int cpg = C / G;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        float gm = gamma[c];
+        sc[(long)b * sbs + c] = gm * rstd;
+        sh[(long)b * sbs + c] = beta[c] - meanf * rstd * gm;
+    }
+}
+
+static int gn_nsplit(long len, int BG) {
+    long s = len / 16384;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    while (s > 1 && s * BG > 8192) s >>= 1;
+    return (int)s;
+}
+
+void launch_gn_stats(const float* x, long bs, int B, int C, int HW, int G, float eps, const float* gamma,
+                     const float* beta, float* mr, float* sc, float* sh, long stats_bs, double* scratch,
+                     hipStream_t st) {
+    long len = (long)(C / G) * HW;
+    int ns = gn_nsplit(len, B * G);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(ns, G, B), dim3(256), 0, st, x, bs, len, scratch);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 63) / 64, B), dim3(64), 0, st, scratch, ns, G, C, eps,
+                       gamma, beta, mr, sc, sh, stats_bs);
+}
+
+// ---------------------------------------------------------------------------
+// tangent / cotangent statistics (see kernels.h).  scratch[(b*G+g)*nsplit+s][2]
+template <int KIND>
+__global__ __launch_bounds__(256) void gn_tstats_partial(const float* d, long d_bs, const float* x, long x_bs,
+                                                         int HW, int cpg, const float* sc, const float* sh,
+                                                         const float* mr, long pbs_c, long pbs_g,
+                                                         double* scratch) {
+    __shared__ double sm[4];
+    const int s = blockIdx.x, nsplit = gridDim.x, g = blockIdx.y, b = blockIdx.z, G = gridDim.y;
+    const long len = (long)cpg * HW;
+    const float* dp = d + (long)b * d_bs + (long)g * len;
+    const float* xp = x + (long)b * x_bs + (long)g * len;
+    const float* scb = sc + (long)b * pbs_c + g * cpg;
+    const float* shb = sh + (long)b * pbs_c + g * cpg;
+    const float mean = mr[(long)b * pbs_g + 2 * g], rstd = mr[(long)b * pbs_g + 2 * g + 1];
+    long per = ((len / 4 + nsplit - 1) / nsplit) * 4;
+    long beg = (long)s * per, end = beg + per < len ? beg + per : len;
+    if (beg > end) beg = end;
+    double s1 = 0.0, s2 = 0.0;
+    for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
+        float4 dv = *reinterpret_cast<const float4*>(dp + i);
+        float4 xv = *reinterpret_cast<const float4*>(xp + i);
+        int ci = (int)(i / HW);
+        float scc = scb[ci], shc = shb[ci];
+        float dd[4] = {dv.x, dv.y, dv.z, dv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float xh = (xx[j] - mean) * rstd;
+            float z;
+            if (KIND == 0) z = dd[j];
+            else if (KIND == 1) z = (scc / rstd) * dsilu(fmaf(scc, xx[j], shc)) * dd[j];
+            else z = (scc / rstd) * dd[j];
+            a1 += z;
+            a2 += xh * z;
+        }
+        s1 += (double)a1;
+        s2 += (double)a2;
+    }
+    double t1 = block_sum(s1, sm);
+    double t2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        double* o = scratch + (((long)b * G + g) * nsplit + s) * 2;
+        o[0] = t1;
+        o[1] = t2;
+    }
+}
+
+__global__ void gn_tstats_finalize(const double* scratch, int nsplit, long BG, int G, double inv_n, float* tst,
+                                   long tbs) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BG) return;
+    float* o = tst + (i / G) * tbs + 2 * (i % G);
+    double a = 0, c = 0;
+    for (int s = 0; s < nsplit; ++s) {
+        a += scratch[(i * nsplit + s) * 2];
+        c += scratch[(i * nsplit + s) * 2 + 1];
+    }
+    o[0] = (float)(a * inv_n);
+    o[1] = (float)(c * inv_n);
+}
+
+void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int B, int C, int HW, int G,
+                      const float* sc, const float* sh, const float* mr, long pbs_c, long pbs_g, int kind,
+                      float* tst, long tst_bs, double* scratch, hipStream_t st) {
+    int cpg = C / G;
+    long len = (long)cpg * HW;
+    int ns = gn_nsplit(len, B * G);
+    dim3 grid(ns, G, B);
+    if (kind == 0)
+        hipLaunchKernelGGL(gn_tstats_partial<0>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, HW, cpg, sc, sh, mr,
+                           pbs_c, pbs_g, scratch);
+    else if (kind == 1)
+        hipLaunchKernelGGL(gn_tstats_partial<1>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, HW, cpg, sc, sh, mr,
+                           pbs_c, pbs_g, scratch);
+    else
+        hipLaunchKernelGGL(gn_tstats_partial<2>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, HW, cpg, sc, sh, mr,
+                           pbs_c, pbs_g, scratch);
+    long BG = (long)B * G;
+    hipLaunchKernelGGL(gn_tstats_finalize, dim3((unsigned)((BG + 255) / 256)), dim3(256), 0, st, scratch, ns, BG,
+                       G, 1.0 / (double)len, tst, tst_bs);
+}
+
+// ---------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* d, long d_bs, const float* x, long x_bs,
+                                                       const float* base, long base_bs, float* out, long out_bs,
+                                                       int accumulate, int C, int HW, int cpg, const float* sc,
+                                                       const float* sh, const float* mr, long pbs_c, long pbs_g,
+                                                       const float* tst, long tbs) {
+    const int b = blockIdx.y;
+    const long per = (long)C * HW;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per; i += (long)gridDim.x * 1024) {
+        int c = (int)(i / HW);
+        int g = c / cpg;
+        float scc = sc[(long)b * pbs_c + c], shc = sh[(long)b * pbs_c + c];
+        float4 xv = *reinterpret_cast<const float4*>(x + (long)b * x_bs + i);
+        float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+        float r[4];
+        if (KIND == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = fmaf(scc, xx[j], shc);
+        } else {
+            float mean = mr[(long)b * pbs_g + 2 * g], rstd = mr[(long)b * pbs_g + 2 * g + 1];
+            float m1 = tst[(long)b * tbs + g * 2], m2 = tst[(long)b * tbs + g * 2 + 1];
+            float4 dv = *reinterpret_cast<const float4*>(d + (long)b * d_bs + i);
+            float dd[4] = {dv.x, dv.y, dv.z, dv.w};
+            float bb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (KIND >= 2 && base) {
+                float4 bv = *reinterpret_cast<const float4*>(base + (long)b * base_bs + i);
+                bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+            }
+            float gm = scc / rstd;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float xh = (xx[j] - mean) * rstd;
+                if (KIND == 1) r[j] = scc * (dd[j] - m1 - xh * m2);
+                else if (KIND == 2) r[j] = bb[j] + rstd * (gm * dsilu(fmaf(scc, xx[j], shc)) * dd[j] - m1 - xh * m2);
+                else r[j] = bb[j] + rstd * (gm * dd[j] - m1 - xh * m2);
+            }
+        }
+        float4* o = reinterpret_cast<float4*>(out + (long)b * out_bs + i);
+        if (accumulate) {
+            float4 ov = *o;
+            r[0] += ov.x; r[1] += ov.y; r[2] += ov.z; r[3] += ov.w;
+        }
+        *o = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x_bs, const float* base,
+                     long base_bs, float* out, long out_bs, int accumulate, int B, int C, int HW, int G,
+                     const float* sc, const float* sh, const float* mr, long pbs_c, long pbs_g, const float* tst,
+                     long tst_bs, hipStream_t st) {
+    long per = (long)C * HW;
+    int blocks = (int)((per / 4 + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid(blocks, B);
+    int cpg = C / G;
+#define GA(K) hipLaunchKernelGGL(gn_apply_kernel<K>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, base, base_bs, out, \
+                                 out_bs, accumulate, C, HW, cpg, sc, sh, mr, pbs_c, pbs_g, tst, tst_bs)
+    switch (kind) {
+        case 0: GA(0); break;
+        case 1: GA(1); break;
+        case 2: GA(2); break;
+        default: GA(3); break;
+    }
+#undef GA
+}
+
+// ---------------------------------------------------------------------------
+// softmax over rows of length T (T <= 1024, multiple of 64): one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, long rows, int T) {
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* p = S + row * T;
+    float v[16];
+    const int per = T / 64;
+    float mx = -INFINITY;
+    for (int i = 0; i < per; ++i) {
+        v[i] = p[lane + i * 64];
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_maxf(mx);
+    mx = __shfl(mx, 0, 64);
+    float sum = 0.f;
+    for (int i = 0; i < per; ++i) {
+        v[i] = expf(v[i] - mx);
+        sum += v[i];
+    }
+    sum = wave_sumf(sum);
+    sum = __shfl(sum, 0, 64);
+    float inv = 1.0f / sum;
+    for (int i = 0; i < per; ++i) p[lane + i * 64] = v[i] * inv;
+}
+void launch_softmax_rows(float* S, long rows, int T, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, rows, T);
+}
+
+__global__ __launch_bounds__(256) void softmax_jac_kernel(float* dS, const float* P, long rows, int T,
+                                                          long p_rows, float scale) {
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* d = dS + row * T;
+    const float* p = P + (row % p_rows) * T;
+    const int per = T / 64;
+    float dv[16], pv[16];
+    float dot = 0.f;
+    for (int i = 0; i < per; ++i) {
+        dv[i] = d[lane + i * 64];
+        pv[i] = p[lane + i * 64];
+        dot += dv[i] * pv[i];
+    }
+    dot = wave_sumf(dot);
+    dot = __shfl(dot, 0, 64);
+    for (int i = 0; i < per; ++i) d[lane + i * 64] = scale * pv[i] * (dv[i] - dot);
+}
+void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_jac_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, dS, P, rows, T,
+                       p_rows, scale);
+}
+
+// ---------------------------------------------------------------------------
+// time embedding: [sin, cos] sinusoid (divisor half-1) -> dense0 -> swish -> dense1 -> swish
+// (reference diffusion.py:783-804, 154-157, and the nonlinearity(temb) of :899)
+__global__ void temb_kernel(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
+                            const float* w1, const float* b1, float* out) {
+    extern __shared__ float sm[];
+    float* emb = sm;           // [ch]
+    float* h = sm + ch;        // [temb_ch]
+    const int half = ch / 2;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float a = t * freq[i];   // freq table built on the host exactly as torch does (engine.hip)
+        emb[i] = sinf(a);
+        emb[half + i] = cosf(a);
+    }
+    if ((ch & 1) && threadIdx.x == 0) emb[ch - 1] = 0.f;
+    __syncthreads();
+    for (int o = threadIdx.x; o < temb_ch; o += blockDim.x) {
+        float acc = b0[o];
+        for (int i = 0; i < ch; ++i) acc = fmaf(w0[(long)o * ch + i], emb[i], acc);
+        h[o] = acc * sigm(acc);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < temb_ch; o += blockDim.x) {
+        float acc = b1[o];
+        for (int i = 0; i < temb_ch; ++i) acc = fmaf(w1[(long)o * temb_ch + i], h[i], acc);
+        out[o] = acc * sigm(acc);
+    }
+}
+void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0, const float* w1,
+                 const float* b1, float* scratch, hipStream_t st) {
+    hipLaunchKernelGGL(temb_kernel, dim3(1), dim3(512), (ch + temb_ch) * sizeof(float), st, t, ch, temb_ch, freq,
+                       w0, b0, w1, b1, scratch);
+}
+// out[o] = b[o] + sum_i w[o][i]*tact[i]; one wave per output row
+__global__ __launch_bounds__(256) void temb_proj_kernel(const float* tact, int temb_ch, const float* w,
+                                                        const float* b, int cout, float* out) {
+    int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= cout) return;
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int i = lane; i < temb_ch; i += 64) acc = fmaf(w[(long)o * temb_ch + i], tact[i], acc);
+    acc = wave_sumf(acc);
+    if (lane == 0) out[o] = acc + b[o];
+}
+void launch_temb_proj(const float* tact, int temb_ch, const float* w, const float* b, int cout, float* out,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(temb_proj_kernel, dim3((cout + 3) / 4), dim3(256), 0, st, tact, temb_ch, w, b, cout, out);
+}
+
+// ---------------------------------------------------------------------------
+__global__ void pool2x2_kernel(const float* in, long in_bs, float* out, long out_bs, int accumulate, int C,
+                               int Ho, int Wo) {
+    const int b = blockIdx.y;
+    const long per = (long)C * Ho * Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+        int x = (int)(i % Wo);
+        long r = i / Wo;
+        int y = (int)(r % Ho);
+        long c = r / Ho;
+        const float* p = in + (long)b * in_bs + (c * 2 * Ho + 2 * y) * (2 * Wo) + 2 * x;
+        float2 a = *reinterpret_cast<const float2*>(p);
+        float2 d = *reinterpret_cast<const float2*>(p + 2 * Wo);
+        float v = (a.x + a.y) + (d.x + d.y);
+        float* o = out + (long)b * out_bs + i;
+        if (accumulate) v += *o;
+        *o = v;
+    }
+}
+void launch_pool2x2_sum(const float* in, long in_bs, float* out, long out_bs, int accumulate, int B, int C,
+                        int Hout, int Wout, hipStream_t st) {
+    long per = (long)C * Hout * Wout;
+    int blocks = (int)((per + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pool2x2_kernel, dim3(blocks, B), dim3(256), 0, st, in, in_bs, out, out_bs, accumulate, C,
+                       Hout, Wout);
+}
+
+__global__ void copy_kernel(const float* in, long in_bs, float* out, long out_bs, int accumulate, long per) {
+    const int b = blockIdx.y;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < per; i += (long)gridDim.x * blockDim.x * 4) {
+        float4 v = *reinterpret_cast<const float4*>(in + (long)b * in_bs + i);
+        float4* o = reinterpret_cast<float4*>(out + (long)b * out_bs + i);
+        if (accumulate) {
+            float4 w = *o;
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        *o = v;
+    }
+}
+void launch_copy(const float* in, long in_bs, float* out, long out_bs, int accumulate, int B, long per_sample,
+                 hipStream_t st) {
+    int blocks = (int)((per_sample / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(copy_kernel, dim3(blocks, B), dim3(256), 0, st, in, in_bs, out, out_bs, accumulate,
+                       per_sample);
+}
+
+// ---------------------------------------------------------------------------
+// DDIM update, op order of reference utils.py:362-374:
+//   P = (x - e*c_x0_e)/c_x0_x ; next = c_next_x0*P + c_next_e*e (+ c_noise*noise)
+__global__ void ddim_step_kernel(const float* x, const float* eps, const float* noise, float* out, long count,
+                                 float sq1mat, float sqat, float sqatn, float ce, float cn) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        float e = eps[i];
+        float p = (x[i] - e * sq1mat) / sqat;
+        float v = sqatn * p + ce * e;
+        if (noise) v += cn * noise[i];
+        out[i] = v;
+    }
+}
+void launch_ddim_step(const float* x, const float* eps, const float* noise, float* out, long count, float c_x0_x,
+                      float c_x0_e, float c_next_x0, float c_next_e, float c_noise, hipStream_t st) {
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(blocks), dim3(256), 0, st, x, eps, noise, out, count, c_x0_e, c_x0_x,
+                       c_next_x0, c_next_e, c_noise);
+}
+
+__global__ void masked_axpby_kernel(const float* V, const float* dE, const uint8_t* mask, float cv, float ce,
+                                    float* U, long n, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long j = i % n;
+        float m = (!mask || mask[j]) ? 1.f : 0.f;
+        U[i] = m * (cv * V[i] + ce * dE[i]);
+    }
+}
+void launch_masked_axpby(const float* V, const float* dE, const uint8_t* mask, float cv, float ce, float* U, int k,
+                         long n, hipStream_t st) {
+    long total = (long)k * n;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(masked_axpby_kernel, dim3(blocks), dim3(256), 0, st, V, dE, mask, cv, ce, U, n, total);
+}
+
+__global__ void cot_seed_kernel(const float* U, const uint8_t* mask, float cv, float ce, float* gE, float* gX0,
+                                long n, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long j = i % n;
+        float u = (!mask || mask[j]) ? U[i] : 0.f;
+        gE[i] = ce * u;
+        gX0[i] = cv * u;
+    }
+}
+void launch_cot_seed(const float* U, const uint8_t* mask, float cv, float ce, float* gE, float* gX0, int k, long n,
+                     hipStream_t st) {
+    long total = (long)k * n;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cot_seed_kernel, dim3(blocks), dim3(256), 0, st, U, mask, cv, ce, gE, gX0, n, total);
+}
+
+__global__ void add_kernel(const float* a, const float* b, float* out, long count) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+void launch_add(const float* a, const float* b, float* out, long count, hipStream_t st) {
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, st, a, b, out, count);
+}
+
+}  // namespace loco

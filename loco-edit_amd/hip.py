@@ -1,0 +1,275 @@
+"""ctypes binding of ``libloco_hip.so`` (C ABI: ``include/loco_hip.h``).
+
+PyTorch is used only as the owner of device memory and the current HIP stream;
+every numerical operation below is a call into the hand-written gfx950 kernels.
+There is NO fallback: a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .config import UNetConfig
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libloco_hip.so")
+_lib = None
+
+# every symbol include/loco_hip.h declares
+SYMBOLS = [
+    "loco_version", "loco_device_count", "loco_create", "loco_destroy", "loco_last_error",
+    "loco_load_param", "loco_params_missing", "loco_unet_forward", "loco_ddim_step",
+    "loco_pmp_primal", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
+    "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
+    "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop", "loco_debug_tensor",
+]
+
+
+class LocoCfg(C.Structure):
+    _fields_ = [
+        ("resolution", C.c_int32), ("in_channels", C.c_int32), ("out_ch", C.c_int32), ("ch", C.c_int32),
+        ("num_levels", C.c_int32), ("ch_mult", C.c_int32 * 8), ("num_res_blocks", C.c_int32),
+        ("num_attn_res", C.c_int32), ("attn_resolutions", C.c_int32 * 8), ("gn_groups", C.c_int32),
+        ("gn_eps", C.c_float), ("max_batch", C.c_int32),
+    ]
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the engine and declare prototypes.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.loco_version.restype = C.c_char_p
+    lib.loco_device_count.restype = C.c_int
+    lib.loco_create.argtypes = [C.POINTER(LocoCfg), C.POINTER(vp)]
+    lib.loco_destroy.argtypes = [vp]
+    lib.loco_destroy.restype = None
+    lib.loco_last_error.argtypes = [vp]
+    lib.loco_last_error.restype = C.c_char_p
+    lib.loco_load_param.argtypes = [vp, C.c_char_p, vp, C.POINTER(i64), i32, i32]
+    lib.loco_params_missing.argtypes = [vp]
+    lib.loco_unet_forward.argtypes = [vp, vp, f32, i32, vp, vp]
+    lib.loco_ddim_step.argtypes = [vp, vp, f32, f32, f32, f32, vp, i32, vp, vp]
+    lib.loco_pmp_primal.argtypes = [vp, vp, f32, f32, vp, i32, vp]
+    lib.loco_pmp_jvp.argtypes = [vp, vp, i32, vp, vp]
+    lib.loco_pmp_vjp.argtypes = [vp, vp, i32, vp, vp]
+    lib.loco_orthonormalize.argtypes = [vp, vp, i32, i64, vp, vp]
+    lib.loco_qr_rows.argtypes = [vp, vp, i32, i64, vp]
+    lib.loco_convergence.argtypes = [vp, vp, vp, i64, f32, vp, vp]
+    lib.loco_null_project.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp]
+    lib.loco_edit_axpy.argtypes = [vp, vp, vp, C.POINTER(f32), i32, i64, vp, vp]
+    lib.loco_mask_gather.argtypes = [vp, vp, i32, vp, vp]
+    lib.loco_mask_count.argtypes = [vp]
+    lib.loco_mask_count.restype = i64
+    lib.loco_unet_flops.argtypes = [vp]
+    lib.loco_unet_flops.restype = C.c_double
+    lib.loco_workspace_bytes.argtypes = [vp]
+    lib.loco_workspace_bytes.restype = i64
+    lib.loco_timer_start.argtypes = [vp, vp]
+    lib.loco_timer_stop.argtypes = [vp, vp, C.POINTER(f32)]
+    lib.loco_debug_tensor.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    lib.loco_debug_tensor.restype = i64
+    _lib = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_dev(t: torch.Tensor, dtype=torch.float32):
+    if not t.is_cuda:
+        raise ValueError("loco_hip operates on device tensors only")
+    if t.dtype != dtype:
+        raise ValueError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+
+
+class LocoEngine:
+    """One engine (= loco_ctx) per process and GPU."""
+
+    def __init__(self, cfg: UNetConfig, max_batch: int = 8, device: Optional[torch.device] = None):
+        self.lib = load_library()
+        if not torch.cuda.is_available() or self.lib.loco_device_count() < 1:
+            raise RuntimeError("loco_hip: no HIP device visible; the hot path has no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        torch.cuda.set_device(self.device)
+        self.cfg = cfg
+        self.max_batch = int(max_batch)
+        c = LocoCfg()
+        c.resolution, c.in_channels, c.out_ch, c.ch = cfg.resolution, cfg.in_channels, cfg.out_ch, cfg.ch
+        c.num_levels = len(cfg.ch_mult)
+        for i, m in enumerate(cfg.ch_mult):
+            c.ch_mult[i] = m
+        c.num_res_blocks = cfg.num_res_blocks
+        c.num_attn_res = len(cfg.attn_resolutions)
+        for i, r in enumerate(cfg.attn_resolutions):
+            c.attn_resolutions[i] = r
+        c.gn_groups, c.gn_eps, c.max_batch = cfg.gn_groups, cfg.gn_eps, self.max_batch
+        self._ctx = C.c_void_p()
+        rc = self.lib.loco_create(C.byref(c), C.byref(self._ctx))
+        if rc != 0:
+            msg = self.lib.loco_last_error(self._ctx).decode() if self._ctx else "?"
+            raise RuntimeError(f"loco_create failed ({rc}): {msg}")
+        self.n = cfg.n
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self.lib.loco_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.loco_last_error(self._ctx).decode()}")
+
+    # ---- parameters (model.load_state_dict, reference utils.py:102-105)
+    def load_state_dict(self, sd: Dict[str, "np.ndarray | torch.Tensor"]):
+        for name, v in sd.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            rc = self.lib.loco_load_param(self._ctx, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim, 0)
+            self._check(rc, f"loco_load_param({name})")
+        miss = self.lib.loco_params_missing(self._ctx)
+        if miss != 0:
+            raise RuntimeError(f"{miss} parameters missing: {self.lib.loco_last_error(self._ctx).decode()}")
+
+    # ---- denoiser
+    def unet_forward(self, x: torch.Tensor, t: float) -> torch.Tensor:
+        _chk_dev(x)
+        eps = torch.empty_like(x)
+        self._check(self.lib.loco_unet_forward(self._ctx, _ptr(x), float(t), x.shape[0], _ptr(eps), _stream()),
+                    "loco_unet_forward")
+        return eps
+
+    def ddim_step(self, x, t, at, at_next, eta=0.0, noise=None, out=None):
+        _chk_dev(x)
+        if noise is not None:
+            _chk_dev(noise)
+        out = torch.empty_like(x) if out is None else out
+        self._check(self.lib.loco_ddim_step(self._ctx, _ptr(x), float(t), float(at), float(at_next), float(eta),
+                                            _ptr(noise), x.shape[0], _ptr(out), _stream()), "loco_ddim_step")
+        return out
+
+    # ---- PMP-Jacobian operator
+    def pmp_primal(self, x, t, at, mask: Optional[torch.Tensor] = None, use_et: bool = False):
+        _chk_dev(x)
+        m8 = None
+        if mask is not None:
+            m8 = mask.to(device=x.device, dtype=torch.uint8).contiguous().view(-1)
+            if m8.numel() != self.n:
+                raise ValueError("mask must have C*H*W elements")
+        self._mask_keepalive = m8
+        self._check(self.lib.loco_pmp_primal(self._ctx, _ptr(x), float(t), float(at), _ptr(m8), int(use_et),
+                                             _stream()), "loco_pmp_primal")
+
+    def pmp_jvp(self, V: torch.Tensor) -> torch.Tensor:
+        _chk_dev(V)
+        k = V.shape[0]
+        U = torch.empty(k, self.n, device=V.device, dtype=torch.float32)
+        self._check(self.lib.loco_pmp_jvp(self._ctx, _ptr(V), k, _ptr(U), _stream()), "loco_pmp_jvp")
+        return U
+
+    def pmp_vjp(self, U: torch.Tensor) -> torch.Tensor:
+        _chk_dev(U)
+        k = U.shape[0]
+        A = torch.empty(k, self.n, device=U.device, dtype=torch.float32)
+        self._check(self.lib.loco_pmp_vjp(self._ctx, _ptr(U), k, _ptr(A), _stream()), "loco_pmp_vjp")
+        return A
+
+    # ---- solver algebra
+    def orthonormalize_(self, A: torch.Tensor) -> torch.Tensor:
+        _chk_dev(A)
+        k, n = A.shape
+        s = torch.empty(k, device=A.device, dtype=torch.float32)
+        self._check(self.lib.loco_orthonormalize(self._ctx, _ptr(A), k, n, _ptr(s), _stream()), "loco_orthonormalize")
+        return s
+
+    def qr_rows_(self, A: torch.Tensor):
+        _chk_dev(A)
+        k, n = A.shape
+        self._check(self.lib.loco_qr_rows(self._ctx, _ptr(A), k, n, _stream()), "loco_qr_rows")
+        return A
+
+    def convergence(self, Vprev, V, atol) -> torch.Tensor:
+        _chk_dev(Vprev)
+        _chk_dev(V)
+        out = torch.empty(2, device=V.device, dtype=torch.float32)
+        self._check(self.lib.loco_convergence(self._ctx, _ptr(Vprev), _ptr(V), V.numel(), float(atol), _ptr(out),
+                                              _stream()), "loco_convergence")
+        return out
+
+    def null_project(self, Vm, Vn=None) -> torch.Tensor:
+        _chk_dev(Vm)
+        k, n = Vm.shape
+        k0 = 0
+        if Vn is not None:
+            _chk_dev(Vn)
+            k0 = Vn.shape[0]
+        out = torch.empty_like(Vm)
+        self._check(self.lib.loco_null_project(self._ctx, _ptr(Vm), k, _ptr(Vn), k0, n, _ptr(out), _stream()),
+                    "loco_null_project")
+        return out
+
+    def edit_axpy(self, x, v, alphas) -> torch.Tensor:
+        _chk_dev(x)
+        _chk_dev(v)
+        B = len(alphas)
+        n = x.numel()
+        out = torch.empty((B,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+        arr = (C.c_float * B)(*[float(a) for a in alphas])
+        self._check(self.lib.loco_edit_axpy(self._ctx, _ptr(x), _ptr(v), arr, B, n, _ptr(out), _stream()),
+                    "loco_edit_axpy")
+        torch.cuda.current_stream().synchronize()   # `arr` is host memory read asynchronously
+        return out
+
+    def mask_gather(self, U) -> torch.Tensor:
+        _chk_dev(U)
+        k = U.shape[0]
+        L = int(self.lib.loco_mask_count(self._ctx))
+        out = torch.empty(k, L, device=U.device, dtype=torch.float32)
+        self._check(self.lib.loco_mask_gather(self._ctx, _ptr(U), k, _ptr(out), _stream()), "loco_mask_gather")
+        return out
+
+    # ---- introspection
+    def unet_flops(self) -> float:
+        return float(self.lib.loco_unet_flops(self._ctx))
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.loco_workspace_bytes(self._ctx))
+
+    def timer_start(self):
+        self._check(self.lib.loco_timer_start(self._ctx, _stream()), "loco_timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.loco_timer_stop(self._ctx, _stream(), C.byref(ms)), "loco_timer_stop")
+        return float(ms.value)
+
+    def debug_tensor(self, name: str, numel: int) -> torch.Tensor:
+        dst = torch.empty(numel, device=self.device, dtype=torch.float32)
+        got = self.lib.loco_debug_tensor(self._ctx, name.encode(), _ptr(dst), numel, _stream())
+        if got < 0:
+            raise RuntimeError(f"loco_debug_tensor({name}) failed: {self.lib.loco_last_error(self._ctx).decode()}")
+        return dst[:got]

@@ -1,0 +1,331 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A plain-PyTorch (CPU, fp32) restatement of the LOCO-Edit null-space-projection
+hot path of the reference (ChicyChen/LOCO-Edit @ 2024-10-22).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; the product package ``loco-edit_amd/`` never does.
+
+Parity status: PINNED for the unconditional DDPM path (BASELINE.json configs
+0-1) -- ``oracle/make_golden.py`` imports the reference itself in the build
+container (stub modules for the absent torchvision/diffusers/skimage), checks
+every function below against the reference's own output and commits the
+input/output vectors under ``tests/golden/`` (the reference has no tests or
+golden vectors of its own).
+
+Every function cites the reference file:line it restates.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# Denoiser A: Ho-DDPM U-Net (reference src/models/ddpm/diffusion.py)
+# --------------------------------------------------------------------------
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """[sin, cos] sinusoid with divisor (half-1) -- diffusion.py:783-804."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    arg = t.float()[:, None] * freq[None, :]
+    emb = torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
+    if dim % 2 == 1:
+        emb = F.pad(emb, (0, 1, 0, 0))
+    return emb
+
+
+def _swish(x):  # diffusion.py:806-808
+    return x * torch.sigmoid(x)
+
+
+def _gn(p, name, x, cfg):  # diffusion.py:810-811 (GroupNorm 32, eps 1e-6)
+    return F.group_norm(x, cfg.gn_groups, p[name + ".weight"], p[name + ".bias"], cfg.gn_eps)
+
+
+def _resblock(p, name, x, temb, cfg):
+    """diffusion.py:855-912."""
+    h = _gn(p, name + ".norm1", x, cfg)
+    h = _swish(h)
+    h = F.conv2d(h, p[name + ".conv1.weight"], p[name + ".conv1.bias"], padding=1)
+    h = h + F.linear(_swish(temb), p[name + ".temb_proj.weight"], p[name + ".temb_proj.bias"])[:, :, None, None]
+    h = _gn(p, name + ".norm2", h, cfg)
+    h = _swish(h)
+    h = F.conv2d(h, p[name + ".conv2.weight"], p[name + ".conv2.bias"], padding=1)
+    if (name + ".nin_shortcut.weight") in p:
+        x = F.conv2d(x, p[name + ".nin_shortcut.weight"], p[name + ".nin_shortcut.bias"])
+    return x + h
+
+
+def _attn(p, name, x, cfg):
+    """Single-head self-attention over H*W tokens -- diffusion.py:914-966."""
+    h = _gn(p, name + ".norm", x, cfg)
+    q = F.conv2d(h, p[name + ".q.weight"], p[name + ".q.bias"])
+    k = F.conv2d(h, p[name + ".k.weight"], p[name + ".k.bias"])
+    v = F.conv2d(h, p[name + ".v.weight"], p[name + ".v.bias"])
+    b, c, hh, ww = q.shape
+    q = q.reshape(b, c, hh * ww).permute(0, 2, 1)
+    k = k.reshape(b, c, hh * ww)
+    w_ = torch.bmm(q, k) * (int(c) ** (-0.5))
+    w_ = F.softmax(w_, dim=2)
+    v = v.reshape(b, c, hh * ww)
+    h = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    h = F.conv2d(h, p[name + ".proj_out.weight"], p[name + ".proj_out.bias"])
+    return x + h
+
+
+def unet_forward(p: Dict[str, torch.Tensor], cfg, x: torch.Tensor, t: torch.Tensor,
+                 trace: Optional[dict] = None) -> torch.Tensor:
+    """eps_theta(x, t) -- PullBackDDPM.forward, diffusion.py:145-200.
+    ``trace`` (tests only) collects each block's output under its module name."""
+    def rec(name, v):
+        if trace is not None:
+            trace[name] = v.detach().clone()
+        return v
+    t = t.reshape(1) if t.dim() == 0 else t
+    temb = timestep_embedding(t.to(torch.float32), cfg.ch)
+    temb = F.linear(temb, p["temb.dense.0.weight"], p["temb.dense.0.bias"])
+    temb = _swish(temb)
+    temb = F.linear(temb, p["temb.dense.1.weight"], p["temb.dense.1.bias"])
+    nres = len(cfg.ch_mult)
+    res = cfg.resolution
+    hs = [rec("conv_in", F.conv2d(x, p["conv_in.weight"], p["conv_in.bias"], padding=1))]
+    for lvl in range(nres):
+        for b in range(cfg.num_res_blocks):
+            h = rec(f"down.{lvl}.block.{b}", _resblock(p, f"down.{lvl}.block.{b}", hs[-1], temb, cfg))
+            if res in cfg.attn_resolutions:
+                h = rec(f"down.{lvl}.attn.{b}", _attn(p, f"down.{lvl}.attn.{b}", h, cfg))
+            hs.append(h)
+        if lvl != nres - 1:
+            # Downsample: pad (0,1,0,1) then 3x3 stride 2 -- diffusion.py:834-853
+            h = F.pad(hs[-1], (0, 1, 0, 1))
+            hs.append(rec(f"down.{lvl}.downsample.conv",
+                          F.conv2d(h, p[f"down.{lvl}.downsample.conv.weight"],
+                                   p[f"down.{lvl}.downsample.conv.bias"], stride=2)))
+            res //= 2
+    h = hs[-1]
+    h = rec("mid.block_1", _resblock(p, "mid.block_1", h, temb, cfg))
+    h = rec("mid.attn_1", _attn(p, "mid.attn_1", h, cfg))
+    h = rec("mid.block_2", _resblock(p, "mid.block_2", h, temb, cfg))
+    for lvl in reversed(range(nres)):
+        for b in range(cfg.num_res_blocks + 1):
+            h = rec(f"up.{lvl}.block.{b}",
+                    _resblock(p, f"up.{lvl}.block.{b}", torch.cat([h, hs.pop()], dim=1), temb, cfg))
+            if res in cfg.attn_resolutions:
+                h = rec(f"up.{lvl}.attn.{b}", _attn(p, f"up.{lvl}.attn.{b}", h, cfg))
+        if lvl != 0:
+            # Upsample: nearest x2 then 3x3 -- diffusion.py:816-832
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = rec(f"up.{lvl}.upsample.conv",
+                    F.conv2d(h, p[f"up.{lvl}.upsample.conv.weight"], p[f"up.{lvl}.upsample.conv.bias"], padding=1))
+            res *= 2
+    h = _swish(_gn(p, "norm_out", h, cfg))
+    return F.conv2d(h, p["conv_out.weight"], p["conv_out.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------
+# Scheduler (reference src/utils/utils.py:305-461)
+# --------------------------------------------------------------------------
+class Scheduler:
+    """YHCustomScheduler restated -- utils.py:305-423 (linear schedule only,
+    which is what ``preset`` forces for the unconditional models,
+    define_argparser.py:233)."""
+
+    t_max = 999
+
+    def __init__(self):
+        betas = torch.linspace(0.0001, 0.02, 1000, dtype=torch.float64)  # utils.py:385-391,408-409
+        self.betas = betas.to(torch.float32)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).to(torch.float32)  # :401-403
+        self.timesteps = None
+        self.timesteps_next = None
+
+    def set_timesteps(self, n: int, is_inversion: bool = False):  # utils.py:316-329
+        seq = torch.linspace(0, 1, n) * self.t_max
+        if is_inversion:
+            seq = seq + 1e-6
+            seq_prev = torch.cat([torch.tensor([-1.0]), seq[:-1]])
+            self.timesteps = seq_prev[1:]
+            self.timesteps_next = seq[1:]
+        else:
+            seq_prev = torch.cat([torch.tensor([-1.0]), seq[:-1]])
+            self.timesteps = torch.flip(seq[1:], dims=[0])
+            self.timesteps_next = torch.flip(seq_prev[1:], dims=[0])
+
+    def get_timesteps(self, t):  # utils.py:331-337
+        return self.timesteps_next[torch.where(self.timesteps == t)]
+
+    def alpha_at(self, t) -> torch.Tensor:
+        """``extract``: alpha-bar gathered at floor(t) -- utils.py:444-461."""
+        return self.alphas_cumprod[int(torch.as_tensor(t).long().item())]
+
+    def step(self, et, t, xt, eta: float = 0.0, noise: Optional[torch.Tensor] = None):
+        """utils.py:342-383 (learn_sigma False).  ``noise`` injects the randn_like draw."""
+        idx = self.timesteps.tolist().index(float(t))
+        t_next = self.timesteps_next[idx]
+        at = self.alpha_at(t)
+        at_next = self.alpha_at(t_next)
+        p_xt = (xt - et * (1 - at).sqrt()) / at.sqrt()
+        if eta == 0:
+            xt_next = at_next.sqrt() * p_xt + (1 - at_next).sqrt() * et
+        else:
+            sigma = ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
+            if noise is None:
+                noise = torch.randn_like(xt)
+            xt_next = at_next.sqrt() * p_xt + (1 - at_next - eta * sigma ** 2).sqrt() * et + eta * sigma * noise
+        return xt_next, p_xt
+
+
+# --------------------------------------------------------------------------
+# Edit pipeline (reference src/modules/edit.py:2034-2625)
+# --------------------------------------------------------------------------
+class OracleEdit:
+    def __init__(self, params: Dict[str, torch.Tensor], cfg, for_steps=100, inv_steps=100,
+                 edit_t=0.6, performance_boosting_t=0.2):
+        self.p = params
+        self.cfg = cfg
+        self.sched = Scheduler()
+        self.for_steps, self.inv_steps = for_steps, inv_steps
+        self.sched.set_timesteps(for_steps)
+        ts = self.sched.timesteps
+        self.edit_t_idx = int((ts - edit_t * 1000).abs().argmin())  # edit.py:2071-2072
+        self.performance_boosting_t_idx = (
+            int((ts - performance_boosting_t * 1000).abs().argmin())
+            if performance_boosting_t > 0 else 1000)  # edit.py:2073
+
+    def unet(self, x, t):
+        return unet_forward(self.p, self.cfg, x, t)
+
+    # -- edit.py:2369-2391
+    def get_x0(self, t, x, mask=None):
+        et = self.unet(x, t)
+        at = self.sched.alpha_at(t)
+        p_xt = (x - et * (1 - at).sqrt()) / at.sqrt()
+        if mask is not None:
+            p_xt = p_xt[:, mask]
+        return p_xt
+
+    # -- edit.py:2394-2403
+    def get_et(self, t, x, mask=None):
+        et = self.unet(x, t)
+        if mask is not None:
+            et = et[:, mask]
+        return et
+
+    # -- edit.py:2117-2167 (98 of 99 steps, eta = 0)
+    @torch.no_grad()
+    def ddim_inversion(self, x0):
+        self.sched.set_timesteps(self.inv_steps, is_inversion=True)
+        ts = self.sched.timesteps
+        xt = x0
+        for i, t in enumerate(ts):
+            if i == len(ts) - 1:
+                break
+            xt, _ = self.sched.step(self.unet(xt, t), t, xt, eta=0)
+        return xt
+
+    # -- edit.py:2508-2614 (CPU bounce buffer / chunking are no-ops numerically)
+    @torch.no_grad()
+    def ddim_forwardsteps(self, xt, t_start_idx, t_end_idx, performance_boosting=False,
+                          noises: Optional[Sequence[torch.Tensor]] = None):
+        self.sched.set_timesteps(self.for_steps)
+        ts = self.sched.timesteps
+        for i, t in enumerate(ts):
+            if t_end_idx == i:
+                return xt, t, i
+            elif i < t_start_idx:
+                continue
+            eta = 1 if (performance_boosting and self.performance_boosting_t_idx <= i
+                        and self.performance_boosting_t_idx != len(ts) - 1) else 0
+            nz = None if (noises is None or eta == 0) else noises[i]
+            xt, _ = self.sched.step(self.unet(xt, t), t, xt, eta=eta, noise=nz)
+        return xt
+
+    # -- edit.py:2406-2504 block power iteration on J^T J
+    def pullback(self, x, t, pca_rank, v0: torch.Tensor, min_iter=10, max_iter=100,
+                 convergence_threshold=1e-3, mask=None, noise=False, chunk_size=25,
+                 verbose=False):
+        """``v0`` is the [n, k] Gaussian matrix the reference draws at edit.py:2435
+        (injected so results are reproducible); it is QR-orthonormalised exactly as
+        at :2436.  Returns (u [L,k], s [k], vT [k,n], n_iter)."""
+        c, hh, ww = x.shape[1:]
+        n = c * hh * ww
+        num_chunk = pca_rank // chunk_size if pca_rank % chunk_size == 0 else pca_rank // chunk_size + 1
+        a = torch.tensor(0.0)
+        q, _ = torch.linalg.qr(v0.to(torch.float32))
+        v = q.T.reshape(-1, c, hh, ww)
+        fn = self.get_et if noise else self.get_x0
+        n_done = 0
+        for i in range(max_iter):
+            v_prev = v.detach().clone()
+            u = []
+            for vi in v.chunk(num_chunk):
+                g = lambda a_: fn(t, x + a_ * vi, mask=mask)
+                u.append(torch.func.jacfwd(g, argnums=0, randomness="error")(a).detach())  # u_i = J v_i
+            u = torch.cat(u, dim=0)
+            if mask is None:
+                g2 = lambda x_: torch.einsum("bcwh,icwh->b", u, fn(t, x_, mask=mask))
+            else:
+                g2 = lambda x_: torch.einsum("bl,il->b", u, fn(t, x_, mask=mask))
+            v_ = torch.autograd.functional.jacobian(g2, x).reshape(-1, n)  # rows u_i^T J
+            _, s, v = torch.linalg.svd(v_, full_matrices=False)
+            v = v.reshape(-1, c, hh, ww)
+            n_done = i + 1
+            if verbose:
+                print(f"power method : {i}-th step convergence : ", torch.dist(v_prev, v).item())
+            if torch.allclose(v_prev, v, atol=convergence_threshold) and (i > min_iter):
+                break
+        u = u.reshape(u.shape[0], -1).T.detach()
+        return u, s.sqrt().detach(), v.reshape(-1, n).detach(), n_done
+
+    # -- edit.py:2313-2323
+    @staticmethod
+    def project(vT_modify, vT_null=None, pca_rank_null=None):
+        if vT_null is None:
+            return vT_modify / vT_modify.norm(dim=1, keepdim=True)
+        vT_null = vT_null[:pca_rank_null, :]
+        vT = (vT_null.T @ (vT_null @ vT_modify.T)).T
+        vT = vT_modify - vT
+        return vT / vT.norm(dim=1, keepdim=True)
+
+    # -- edit.py:2339-2363 and :2618-2625
+    @staticmethod
+    def edit_batch(xt, vk_row, scale, num_step, vis_num, edit_step=1.0):
+        xts = {}
+        for direction in (1, -1):
+            vk = direction * vk_row.view(-1, *xt.shape[1:])
+            lst = [xt.clone()]
+            for _ in range(num_step):
+                lst.append(lst[-1] + scale * edit_step * vk)
+            b = torch.cat(lst, dim=0)
+            b = b[[0, -1], :] if vis_num == 1 else b[::(b.size(0) // vis_num)]
+            xts[direction] = b
+        return torch.cat([xts[-1].flip(dims=[0])[:-1], xts[1]], dim=0)
+
+
+# --------------------------------------------------------------------------
+# Explicit J / J^T products (used by tests as an independent check of the HIP
+# tangent / cotangent passes, and by bench.py's cpu_baseline leg)
+# --------------------------------------------------------------------------
+def jvp_x0(ed: OracleEdit, x, t, V, mask=None, noise=False):
+    """U = J V with J = d x0_hat[mask] / d x (forward mode, as edit.py:2451-2455)."""
+    fn = ed.get_et if noise else ed.get_x0
+    a = torch.tensor(0.0)
+    g = lambda a_: fn(t, x + a_ * V, mask=mask)
+    return torch.func.jacfwd(g)(a).detach()
+
+
+def vjp_x0(ed: OracleEdit, x, t, U, mask=None, noise=False):
+    """A = U^T J (reverse mode, as edit.py:2460-2480); U is [k, L] or [k,c,h,w]."""
+    fn = ed.get_et if noise else ed.get_x0
+    if mask is None:
+        g2 = lambda x_: torch.einsum("bcwh,icwh->b", U, fn(t, x_, mask=mask))
+    else:
+        g2 = lambda x_: torch.einsum("bl,il->b", U, fn(t, x_, mask=mask))
+    return torch.autograd.functional.jacobian(g2, x).reshape(U.shape[0], -1).detach()
+
+
+def to_torch(params_np) -> Dict[str, torch.Tensor]:
+    return {k: torch.from_numpy(v.copy()) for k, v in params_np.items()}
