@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the LOCO-Edit hot path on MI355X.
+
+Metric (BASELINE.json): edit-directions/sec for a top-5 PMP-Jacobian basis at
+256x256, t = 0.6T.  One *step* = one complete subspace solve on synthetic input
+(BASELINE.md section 4): denoiser = CelebA-HQ DDPM architecture with the
+deterministic synthetic checkpoint (seed 0), x_t = randn (seed 1),
+t = timesteps[40] = 595.36, mask = rows 110:130 x cols 70:110 on 3 channels
+(L = 2400), V0 = randn (seed 7), 12 power iterations (the reference's minimum,
+edit.py:2492 with min_iter=10), i.e. per step: thin QR of V0, 1 primal pass,
+12 x (k tangent passes + k cotangent passes + Gram/eig re-orthonormalisation).
+
+N GPUs: weak scaling -- every rank keeps 5 probes (k = 5 N probes of ONE image
+sharded over ranks, one RCCL all-gather of the A shards per iteration, the
+k x k algebra replicated); value = 5 N directions / step time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import loco_edit_amd  # noqa: E402
+from loco_edit_amd.config import CELEBA_DDPM, synth_params  # noqa: E402
+from loco_edit_amd.dist import ProbeSharder  # noqa: E402
+from loco_edit_amd.hip import LocoEngine  # noqa: E402
+from loco_edit_amd.scheduler import YHCustomScheduler  # noqa: E402
+from loco_edit_amd import solver  # noqa: E402
+
+K_PER_GPU = 5
+N_ITER = 12
+PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def synthetic_inputs(cfg, k, device):
+    x = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=torch.Generator().manual_seed(1)).to(device)
+    mask = torch.zeros(3, cfg.resolution, cfg.resolution, dtype=torch.bool)
+    r = cfg.resolution
+    mask[:, r * 110 // 256:r * 130 // 256, r * 70 // 256:r * 110 // 256] = True
+    v0 = torch.randn(cfg.n, k, generator=torch.Generator().manual_seed(7)).to(device)
+    return x, mask.to(device), v0
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(cfg, params, t, budget_s=30.0):
+    """Reference algorithm (oracle = pinned restatement: jacfwd + autograd.functional.jacobian
+    + svd) timed on the host cores on a BOUNDED sample of the same workload (<= ~30 s)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import loco_oracle as orc
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    p = orc.to_torch(params)
+    oed = orc.OracleEdit(p, cfg)
+    x = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=torch.Generator().manual_seed(1))
+    mask = torch.zeros(3, cfg.resolution, cfg.resolution, dtype=torch.bool)
+    mask[:, 110:130, 70:110] = True
+    tt = torch.tensor(float(t))
+    with torch.no_grad():
+        t0 = time.time()
+        oed.unet(x, tt)
+        t_first = time.time() - t0
+        t0 = time.time()
+        oed.unet(x, tt)
+        t_fwd = time.time() - t0
+    # one k=1 power iteration costs about 4-6 forward equivalents on the CPU
+    if t_first + t_fwd * 7 < budget_s:
+        v0 = torch.randn(cfg.n, 1, generator=torch.Generator().manual_seed(7))
+        t0 = time.time()
+        oed.pullback(x, tt, 1, v0, min_iter=1, max_iter=1, mask=mask)
+        t_iter1 = time.time() - t0
+        t_iter5 = t_iter1 * (3 * 5 + 1) / (3 * 1 + 1)   # reference cost model (3k+1)F, BASELINE.md section 2
+        sample = (f"1 power iteration (jacfwd JVP + autograd VJP + svd) at k=1, 256x256, fp32: {t_iter1:.1f} s; "
+                  f"U-Net forward {t_fwd:.2f} s; scaled to k=5 x {N_ITER} iterations by the (3k+1)F cost model")
+    else:
+        t_iter5 = t_fwd * (3 * 5 + 1)
+        sample = (f"U-Net forward 256x256 fp32: {t_fwd:.2f} s (a full power iteration would exceed the {budget_s:.0f} s "
+                  f"sample budget); scaled by the reference's (3k+1) forward-equivalents per iteration, k=5 x {N_ITER}")
+    val = K_PER_GPU / (N_ITER * t_iter5)
+    return {"value": val, "unit": "edit-directions/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    cfg = CELEBA_DDPM
+    params = synth_params(cfg, seed=0)
+    eng = LocoEngine(cfg, max_batch=8, device=device)
+    eng.load_state_dict(params)
+    sched = YHCustomScheduler()
+    sched.set_timesteps(100)
+    t = float(sched.timesteps[40])
+    at = sched.alpha_at(t)
+    k = K_PER_GPU * world
+    x, mask, v0 = synthetic_inputs(cfg, k, device)
+    sharder = ProbeSharder("world")
+
+    def step():
+        return solver.local_basis(eng, x, t, at, k, mask=mask, min_iter=N_ITER, max_iter=N_ITER,
+                                  convergence_threshold=1e-4, v0=v0, sharder=sharder, verbose=False)
+
+    for _ in range(a.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        u, s, vT, n_iter = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    value = k / (elapsed / a.steps)
+
+    # ---- roofline leg: per-kernel HIP-event profile of one more identical step
+    roofline = None
+    F = eng.unet_flops()
+    if rank == 0 and not a.no_profile:
+        eng.profile_enable(True)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        t_prof = time.perf_counter() - tp0
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        dom = max(rep.items(), key=lambda kv: kv[1]["ms"])
+        name, r = dom
+        achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        tot_ms = sum(v["ms"] for v in rep.values())
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(name)
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
+            "launches": r["launches"], "avg_launch_ms": round(r["ms"] / r["launches"], 4),
+            "flops_per_launch": r["flops"] / r["launches"],
+            "conv_share_of_step": round(tot_ms / (t_prof * 1e3), 3),
+            "whole_step_TFLOPs": round((1 + 2 * K_PER_GPU) * F * N_ITER / (ms_per_step * 1e-3) / 1e12, 2),
+            "all_conv_kernels": {n: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                     "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                 for n, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, params, t)
+
+    if rank == 0:
+        out = {
+            "metric": "edit-directions/sec (top-5 PMP-Jacobian SVD @256^2)",
+            "value": round(value, 4), "unit": "edit-directions/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CelebA-HQ DDPM 256x256 top-5 local basis (l_eye-sized mask, L=2400), "
+                                   "t=0.6T, 12 power iterations, probes sharded 5 per GPU",
+                       "probes_total": k, "n_iter": int(n_iter), "mask_L": int(mask.sum().item()),
+                       "weights": "synthetic seed 0"},
+            "singular_values": [round(float(v), 4) for v in s.tolist()[:5]],
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,13 @@ int  loco_unet_forward(loco_ctx* ctx, const float* x, float t, int32_t B,
 int  loco_ddim_step(loco_ctx* ctx, const float* x, float t, float at, float at_next,
                     float eta, const float* noise, int32_t B, float* x_next, void* stream);
 
+/* The scheduler update alone, for callers that hold eps already (seam 3 of
+ * scheduler.step(et, t, xt, eta).prev_sample / .x0, utils.py:342-383).
+ * x0_out (optional) receives P_xt = (xt - et*sqrt(1-at))/sqrt(at). */
+int  loco_sched_step(loco_ctx* ctx, const float* x, const float* et, float at, float at_next,
+                     float eta, const float* noise, int64_t count, float* x_next, float* x0_out,
+                     void* stream);
+
 /* --- PMP-Jacobian operator J = d x0_hat[mask] / d x_t  (edit.py:2369-2391) ---
  * loco_pmp_primal evaluates the denoiser once at (x,t), caching what the
  * tangent and cotangent passes need; `mask` is uint8 [C*H*W] (nullptr = all
@@ -123,6 +130,13 @@ int64_t loco_workspace_bytes(loco_ctx* ctx);
  * available from the API; instead these bracket a region. */
 int  loco_timer_start(loco_ctx* ctx, void* stream);
 int  loco_timer_stop(loco_ctx* ctx, void* stream, float* ms);
+
+/* Per-kernel HIP-event profile of the convolution launches (bench.py roofline
+ * leg).  While enabled every conv launch is bracketed by two events on the
+ * caller's stream; loco_profile_report synchronises, then writes one line per
+ * kernel variant: "name launches total_ms total_flops" (algorithmic 2*MAC). */
+int  loco_profile_enable(loco_ctx* ctx, int32_t on);
+int  loco_profile_report(loco_ctx* ctx, char* buf, int64_t cap);
 
 /* Debug / test hook: copy an internal primal activation ("down.0.block.0" ...)
  * of the last forward/primal call into dst (device), returns element count or <0. */

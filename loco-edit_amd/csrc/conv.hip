@@ -18,6 +18,7 @@
 // pixels / couts per half wave).  The next chunk's global loads are issued
 // before the MFMA block of the current one (register prefetch).
 #include "kernels.h"
+#include <cstdio>
 
 namespace loco {
 
@@ -343,6 +344,19 @@ static void launch_tile(const ConvArgs& a, hipStream_t st) {
         case 2: launch_one<TAPS, 1, 4, 1, 1, MODE>(a, st); break;
         default: launch_one<TAPS, 2, 2, 1, 1, MODE>(a, st); break;
     }
+}
+
+const char* conv_variant_name(const ConvArgs& a, int taps) {
+    static const char* tiles[4] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1"};
+    static char names[2][4][5][48];
+    int t = pick_tile(a.Cout, a.Hout * a.Wout);
+    int ti = taps == 9 ? 0 : 1;
+    int m = a.mode;
+    if (taps != 9 && m != CM_NONE) m = CM_GN;
+    if (m < 0 || m > 4) m = 2;
+    char* n = names[ti][t][m];
+    if (!n[0]) snprintf(n, 48, "conv_mfma_f32<%d,%s,%d>", taps, tiles[t], m);
+    return n;
 }
 
 void launch_conv(const ConvArgs& a, int taps, hipStream_t st) {

@@ -11,6 +11,7 @@
 // by the tangent and the cotangent pass of a probe batch.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -106,6 +107,18 @@ struct loco_ctx {
     int primal_B = 0;
     double flops = 0.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // per-launch conv profile
+    bool prof_on = false;
+    struct ProfRec { const char* name; double flops; hipEvent_t e0, e1; };
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t next_event() {
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e);
+        }
+        return ev_pool[ev_used++];
+    }
 };
 
 namespace {
@@ -496,6 +509,18 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
     if (a.nsplit < 1) a.nsplit = 1;
     a.partial = c->partial;
+    if (c->prof_on) {
+        loco_ctx::ProfRec r;
+        r.name = conv_variant_name(a, taps);
+        r.flops = 2.0 * a.Cin * a.Cout * taps * (double)a.Hout * a.Wout * a.B;
+        if (a.zins) r.flops *= 0.25;     // algorithmic work of the stride-2 data gradient
+        r.e0 = c->next_event(); r.e1 = c->next_event();
+        (void)hipEventRecord(r.e0, st);
+        launch_conv(a, taps, st);
+        (void)hipEventRecord(r.e1, st);
+        c->prof.push_back(r);
+        return;
+    }
     launch_conv(a, taps, st);
 }
 
@@ -956,6 +981,7 @@ void loco_destroy(loco_ctx* c) {
     for (float* p : c->owned) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -1003,25 +1029,38 @@ int loco_unet_forward(loco_ctx* c, const float* x, float t, int32_t B, float* ep
     return 0;
 }
 
+static void sched_coeffs(float at, float at_next, float eta, float* s1, float* s2, float* s3, float* ce, float* cn) {
+    // fp32 arithmetic in the op order of reference utils.py:362-374
+    *s1 = std::sqrt(1.0f - at); *s2 = std::sqrt(at); *s3 = std::sqrt(at_next);
+    *cn = 0.f;
+    if (eta == 0.f) {
+        *ce = std::sqrt(1.0f - at_next);
+    } else {
+        float sigma = std::sqrt((1.0f - at / at_next) * (1.0f - at_next) / (1.0f - at));
+        *ce = std::sqrt(1.0f - at_next - eta * (sigma * sigma));
+        *cn = eta * sigma;
+    }
+}
+
+int loco_sched_step(loco_ctx* c, const float* x, const float* et, float at, float at_next, float eta,
+                    const float* noise, int64_t count, float* x_next, float* x0_out, void* stream) {
+    if (!c) return -2;
+    if (eta != 0.f && !noise) { c->err = "eta != 0 needs a noise tensor"; return -2; }
+    float s1, s2, s3, ce, cn;
+    sched_coeffs(at, at_next, eta, &s1, &s2, &s3, &ce, &cn);
+    launch_ddim_step(x, et, eta == 0.f ? nullptr : noise, x_next, x0_out, (long)count, s2, s1, s3, ce, cn,
+                     (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 int loco_ddim_step(loco_ctx* c, const float* x, float t, float at, float at_next, float eta, const float* noise,
                    int32_t B, float* x_next, void* stream) {
     if (!c) return -2;
     if (eta != 0.f && !noise) { c->err = "eta != 0 needs a noise tensor"; return -2; }
     int rc = loco_unet_forward(c, x, t, B, c->eps_buf, stream);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    float s1 = std::sqrt(1.0f - at), s2 = std::sqrt(at), s3 = std::sqrt(at_next);
-    float ce, cn = 0.f;
-    if (eta == 0.f) {
-        ce = std::sqrt(1.0f - at_next);
-    } else {
-        float sigma = std::sqrt((1.0f - at / at_next) * (1.0f - at_next) / (1.0f - at));
-        ce = std::sqrt(1.0f - at_next - eta * sigma * sigma);
-        cn = eta * sigma;
-    }
-    launch_ddim_step(x, c->eps_buf, eta == 0.f ? nullptr : noise, x_next, (long)B * c->n_in, s2, s1, s3, ce, cn, st);
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    return loco_sched_step(c, x, c->eps_buf, at, at_next, eta, noise, (int64_t)B * c->n_in, x_next, nullptr, stream);
 }
 
 int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_t* mask, int32_t use_et,
@@ -1182,6 +1221,34 @@ int loco_timer_stop(loco_ctx* c, void* stream, float* ms) {
     HIPCHK(c, hipEventRecord(c->ev1, (hipStream_t)stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+int loco_profile_enable(loco_ctx* c, int32_t on) {
+    if (!c) return -2;
+    c->prof_on = on != 0;
+    if (on) { c->prof.clear(); c->ev_used = 0; }
+    return 0;
+}
+
+int loco_profile_report(loco_ctx* c, char* buf, int64_t cap) {
+    if (!c || !buf || cap < 1) return -2;
+    HIPCHK(c, hipDeviceSynchronize());
+    std::map<std::string, std::array<double, 3>> agg;   // launches, ms, flops
+    for (auto& r : c->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        auto& a = agg[r.name];
+        a[0] += 1.0; a[1] += ms; a[2] += r.flops;
+    }
+    std::string out;
+    char line[256];
+    for (auto& kv : agg) {
+        snprintf(line, sizeof(line), "%s %.0f %.6f %.6e\n", kv.first.c_str(), kv.second[0], kv.second[1], kv.second[2]);
+        out += line;
+    }
+    if ((int64_t)out.size() + 1 > cap) { c->err = "profile buffer too small"; return -4; }
+    std::memcpy(buf, out.c_str(), out.size() + 1);
     return 0;
 }
 

@@ -45,6 +45,8 @@ struct ConvArgs {
 };
 
 void launch_conv(const ConvArgs& a, int taps, hipStream_t st);
+// name of the kernel variant launch_conv would pick (for the per-kernel profile)
+const char* conv_variant_name(const ConvArgs& a, int taps);
 // workspace (floats) a conv launch with these args needs for split-K partials
 size_t conv_partial_floats(const ConvArgs& a);
 int conv_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int taps);
@@ -105,7 +107,7 @@ void launch_copy(const float* in, long in_bs, float* out, long out_bs, int accum
                  int B, long per_sample, hipStream_t st);
 
 // ---- DDIM / x0 algebra --------------------------------------------------------
-void launch_ddim_step(const float* x, const float* eps, const float* noise, float* out, long count,
+void launch_ddim_step(const float* x, const float* eps, const float* noise, float* out, float* x0_out, long count,
                       float c_x0_x, float c_x0_e, float c_next_x0, float c_next_e, float c_noise,
                       hipStream_t st);
 // U = mask * (cv*V + ce*dEps)

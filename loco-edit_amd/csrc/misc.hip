@@ -434,21 +434,22 @@ void launch_copy(const float* in, long in_bs, float* out, long out_bs, int accum
 // ---------------------------------------------------------------------------
 // DDIM update, op order of reference utils.py:362-374:
 //   P = (x - e*c_x0_e)/c_x0_x ; next = c_next_x0*P + c_next_e*e (+ c_noise*noise)
-__global__ void ddim_step_kernel(const float* x, const float* eps, const float* noise, float* out, long count,
-                                 float sq1mat, float sqat, float sqatn, float ce, float cn) {
+__global__ void ddim_step_kernel(const float* x, const float* eps, const float* noise, float* out, float* x0_out,
+                                 long count, float sq1mat, float sqat, float sqatn, float ce, float cn) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         float e = eps[i];
         float p = (x[i] - e * sq1mat) / sqat;
         float v = sqatn * p + ce * e;
         if (noise) v += cn * noise[i];
+        if (x0_out) x0_out[i] = p;
         out[i] = v;
     }
 }
-void launch_ddim_step(const float* x, const float* eps, const float* noise, float* out, long count, float c_x0_x,
-                      float c_x0_e, float c_next_x0, float c_next_e, float c_noise, hipStream_t st) {
+void launch_ddim_step(const float* x, const float* eps, const float* noise, float* out, float* x0_out, long count,
+                      float c_x0_x, float c_x0_e, float c_next_x0, float c_next_e, float c_noise, hipStream_t st) {
     int blocks = (int)((count + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(ddim_step_kernel, dim3(blocks), dim3(256), 0, st, x, eps, noise, out, count, c_x0_e, c_x0_x,
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(blocks), dim3(256), 0, st, x, eps, noise, out, x0_out, count, c_x0_e, c_x0_x,
                        c_next_x0, c_next_e, c_noise);
 }
 

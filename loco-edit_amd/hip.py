@@ -21,10 +21,11 @@ _lib = None
 # every symbol include/loco_hip.h declares
 SYMBOLS = [
     "loco_version", "loco_device_count", "loco_create", "loco_destroy", "loco_last_error",
-    "loco_load_param", "loco_params_missing", "loco_unet_forward", "loco_ddim_step",
+    "loco_load_param", "loco_params_missing", "loco_unet_forward", "loco_ddim_step", "loco_sched_step",
     "loco_pmp_primal", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop", "loco_debug_tensor",
+    "loco_profile_enable", "loco_profile_report",
 ]
 
 
@@ -63,6 +64,7 @@ def load_library():
     lib.loco_params_missing.argtypes = [vp]
     lib.loco_unet_forward.argtypes = [vp, vp, f32, i32, vp, vp]
     lib.loco_ddim_step.argtypes = [vp, vp, f32, f32, f32, f32, vp, i32, vp, vp]
+    lib.loco_sched_step.argtypes = [vp, vp, vp, f32, f32, f32, vp, i64, vp, vp, vp]
     lib.loco_pmp_primal.argtypes = [vp, vp, f32, f32, vp, i32, vp]
     lib.loco_pmp_jvp.argtypes = [vp, vp, i32, vp, vp]
     lib.loco_pmp_vjp.argtypes = [vp, vp, i32, vp, vp]
@@ -80,6 +82,8 @@ def load_library():
     lib.loco_workspace_bytes.restype = i64
     lib.loco_timer_start.argtypes = [vp, vp]
     lib.loco_timer_stop.argtypes = [vp, vp, C.POINTER(f32)]
+    lib.loco_profile_enable.argtypes = [vp, i32]
+    lib.loco_profile_report.argtypes = [vp, C.c_char_p, i64]
     lib.loco_debug_tensor.argtypes = [vp, C.c_char_p, vp, i64, vp]
     lib.loco_debug_tensor.restype = i64
     _lib = lib
@@ -171,6 +175,16 @@ class LocoEngine:
         self._check(self.lib.loco_ddim_step(self._ctx, _ptr(x), float(t), float(at), float(at_next), float(eta),
                                             _ptr(noise), x.shape[0], _ptr(out), _stream()), "loco_ddim_step")
         return out
+
+    def sched_step(self, x, et, at, at_next, eta=0.0, noise=None, want_x0=False):
+        _chk_dev(x)
+        _chk_dev(et)
+        out = torch.empty_like(x)
+        x0 = torch.empty_like(x) if want_x0 else None
+        self._check(self.lib.loco_sched_step(self._ctx, _ptr(x), _ptr(et), float(at), float(at_next), float(eta),
+                                             _ptr(noise), x.numel(), _ptr(out), _ptr(x0), _stream()),
+                    "loco_sched_step")
+        return out, x0
 
     # ---- PMP-Jacobian operator
     def pmp_primal(self, x, t, at, mask: Optional[torch.Tensor] = None, use_et: bool = False):
@@ -266,6 +280,19 @@ class LocoEngine:
         ms = C.c_float()
         self._check(self.lib.loco_timer_stop(self._ctx, _stream(), C.byref(ms)), "loco_timer_stop")
         return float(ms.value)
+
+    def profile_enable(self, on: bool):
+        self._check(self.lib.loco_profile_enable(self._ctx, int(on)), "loco_profile_enable")
+
+    def profile_report(self):
+        """-> {kernel variant: dict(launches, ms, flops)} for the conv launches since profile_enable(True)."""
+        buf = C.create_string_buffer(1 << 16)
+        self._check(self.lib.loco_profile_report(self._ctx, buf, len(buf)), "loco_profile_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms, fl = line.rsplit(" ", 3)
+            out[name] = dict(launches=int(float(n)), ms=float(ms), flops=float(fl))
+        return out
 
     def debug_tensor(self, name: str, numel: int) -> torch.Tensor:
         dst = torch.empty(numel, device=self.device, dtype=torch.float32)

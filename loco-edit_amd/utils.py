@@ -1,0 +1,157 @@
+"""Factories around the hot path: denoiser, scheduler, datasets, image writer.
+
+Mirrors the call surface of reference ``src/utils/utils.py:52-134,472-672`` for
+the unconditional models.  There is no network in this deployment, so weights
+come from ``--ckpt_path`` (a state_dict with the vendored Ho-DDPM key layout,
+``diffusion.py`` module tree) or from the deterministic synthesiser
+(``--synthetic_weights SEED``); the hub / cluster loaders of the reference are
+out of scope.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .config import CELEBA_DDPM, UNetConfig, synth_params
+from .hip import LocoEngine
+from .scheduler import YHCustomScheduler
+
+# architecture per --model_name (reference utils.py:83-100 maps names to checkpoints of these shapes)
+MODEL_CONFIGS = {
+    "CelebA_HQ_HF": CELEBA_DDPM,     # google/ddpm-ema-celebahq-256
+    "CelebA_HQ": CELEBA_DDPM,        # SDEdit celeba_hq.ckpt (same module tree)
+    "LSUN_church_HF": CELEBA_DDPM,   # google/ddpm-ema-church-256 (same architecture)
+    "LSUN_bedroom_HF": CELEBA_DDPM,
+}
+
+
+class HipUNet:
+    """``unet(x, t) -> eps`` duck type (seam 3 of SURVEY.md 8b) on the HIP engine."""
+
+    def __init__(self, engine: LocoEngine):
+        self.engine = engine
+        self.learn_sigma = False
+
+    def __call__(self, x: torch.Tensor, t) -> torch.Tensor:
+        return self.engine.unet_forward(x.contiguous(), float(t))
+
+    def to(self, *a, **k):
+        return self
+
+
+def get_custom_diffusion_model(args) -> HipUNet:
+    """reference utils.py:77-133."""
+    cfg: Optional[UNetConfig] = getattr(args, "unet_config", None) or MODEL_CONFIGS.get(args.model_name)
+    if cfg is None:
+        raise ValueError('model_name choice: ' + ", ".join(MODEL_CONFIGS))
+    engine = LocoEngine(cfg, max_batch=getattr(args, "max_batch", 8), device=args.device)
+    ckpt = getattr(args, "ckpt_path", "")
+    if ckpt:
+        sd = torch.load(ckpt, map_location="cpu")
+        if "state_dict" in sd:
+            sd = sd["state_dict"]
+        engine.load_state_dict(sd)
+    else:
+        seed = getattr(args, "synthetic_weights", None)
+        if seed is None:
+            raise ValueError("no checkpoint: pass --ckpt_path (vendored-DDPM state_dict) or --synthetic_weights SEED")
+        engine.load_state_dict(synth_params(cfg, seed=int(seed)))
+    return HipUNet(engine)
+
+
+def get_custom_diffusion_scheduler(args, engine=None):
+    """reference utils.py:52-75 (custom scheduler is mandatory for uncond models,
+    define_argparser.py:245)."""
+    if not args.use_yh_custom_scheduler:
+        raise ValueError('please set use_yh_custom_scheduler = True')
+    return YHCustomScheduler(args, engine=engine)
+
+
+# ---------------------------------------------------------------------------
+# image writer (replaces torchvision.utils.save_image at edit.py:2139,2163,2596)
+def save_image(img: torch.Tensor, path: str, nrow: int = 8, padding: int = 2):
+    from PIL import Image
+    img = img.detach().float().cpu().clamp(0, 1)
+    if img.dim() == 3:
+        img = img[None]
+    b, c, h, w = img.shape
+    ncol = min(nrow, b)
+    nr = (b + ncol - 1) // ncol
+    grid = torch.zeros(c, nr * (h + padding) + padding, ncol * (w + padding) + padding)
+    for i in range(b):
+        r, cc = divmod(i, ncol)
+        y0, x0 = padding + r * (h + padding), padding + cc * (w + padding)
+        grid[:, y0:y0 + h, x0:x0 + w] = img[i]
+    arr = (grid * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
+    if arr.shape[2] == 1:
+        arr = arr[:, :, 0]
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    Image.fromarray(arr).save(path)
+
+
+# ---------------------------------------------------------------------------
+# datasets
+class SyntheticDataset:
+    """Seeded stand-in for CelebAMask-HQ when no dataset is mounted: image =
+    clamp(randn) in [-1,1], mask = an 'l_eye'-sized rectangle."""
+
+    def __init__(self, image_size=256, c_in=3):
+        self.res, self.c = image_size, c_in
+
+    def __getitem__(self, idx):
+        g = torch.Generator().manual_seed(int(idx))
+        return torch.randn(1, self.c, self.res, self.res, generator=g).clamp(-1, 1)
+
+    def getmask(self, idx, choose_sem, list_sem=True):
+        m = torch.zeros(self.c, self.res, self.res, dtype=torch.bool)
+        r = self.res
+        m[:, int(r * 110 / 256):int(r * 130 / 256), int(r * 70 / 256):int(r * 110 / 256)] = True
+        return m
+
+
+class CelebAMaskDataset:
+    """CelebAMask-HQ image + ground-truth part masks (reference
+    ``src/dataset/celeba_hq_dataloader.py:9-123``): images ``CelebA-HQ-img/{idx}.jpg``,
+    masks ``CelebAMask-HQ-mask-anno/{k}/{idx:05d}_{sem}.png``; both resized to
+    ``res`` with PIL's default resampling; mask = ``astype(bool)`` -> [3,res,res]."""
+
+    def __init__(self, root, res=256):
+        self.root, self.res = root, res
+        self.img_dir = os.path.join(root, "CelebA-HQ-img")
+        self.mask_dir = os.path.join(root, "CelebAMask-HQ-mask-anno")
+        if not os.path.isdir(self.img_dir):
+            raise FileNotFoundError(f"CelebAMask-HQ not found under {root}")
+
+    def _img(self, idx):
+        from PIL import Image
+        return Image.open(os.path.join(self.img_dir, f"{idx}.jpg")).resize((self.res, self.res))
+
+    def __getitem__(self, idx):
+        a = np.asarray(self._img(idx).convert("RGB"), dtype=np.float32) / 255.0
+        t = torch.from_numpy(a).permute(2, 0, 1)
+        return ((t - 0.5) / 0.5).unsqueeze(0)
+
+    def getmask(self, idx, choose_sem, list_sem=True):
+        from PIL import Image
+        sub = os.path.join(self.mask_dir, str(idx // 2000))
+        path = os.path.join(sub, f"{idx:05d}_{choose_sem}.png")
+        if not os.path.exists(path):
+            raise AssertionError(f"For the {idx}th image, semantic {choose_sem} has no annotation")
+        m = np.array(Image.open(path).resize((self.res, self.res)))
+        if m.ndim == 2:
+            m = np.repeat(m[:, :, None], 3, axis=2)
+        return torch.tensor(m.astype(bool)).permute(2, 0, 1)
+
+
+def get_dataset(args):
+    """reference utils.py:472-560 (the datasets the unconditional path uses)."""
+    if args.dataset_name == "CelebA_HQ_mask":
+        return CelebAMaskDataset(args.dataset_root, res=args.image_size)
+    if args.dataset_name == "Synthetic":
+        return SyntheticDataset(args.image_size, args.c_in)
+    if args.dataset_name == "Random":
+        return None
+    raise ValueError('Invalid dataset name (supported here: CelebA_HQ_mask, Synthetic, Random)')

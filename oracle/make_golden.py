@@ -68,6 +68,7 @@ def ref_model(PullBackDDPM, cfg, params):
     sd = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
     missing = m.load_state_dict(sd, strict=True)
     m.eval()
+    m.requires_grad_(False)
     return m
 
 
@@ -186,6 +187,8 @@ def gen_for_config(tag, cfg, redit, YHS, PullBackDDPM, k, k_null, n_iter, mrect,
 
         torch.randn = fake_randn
         try:
+          # the reference calls the solver under @torch.no_grad() (edit.py:2215)
+          with torch.no_grad():
             u_m, s_m, vT_m = ed.local_encoder_decoder_pullback_xt(
                 x=x, t=t, pca_rank=k, min_iter=n_iter, max_iter=n_iter,
                 convergence_threshold=1e-4, mask=mask)
