@@ -131,6 +131,18 @@ int64_t loco_workspace_bytes(loco_ctx* ctx);
 int  loco_timer_start(loco_ctx* ctx, void* stream);
 int  loco_timer_stop(loco_ctx* ctx, void* stream, float* ms);
 
+/* Arithmetic of the convolutions: 0 = exact fp32 (v_mfma_f32_32x32x2_f32, the parity
+ * anchor), 1 = split-bf16 "bf16x3" (3 x v_mfma_f32_32x32x16_bf16 per product, fp32
+ * accumulate, fp32-faithful to ~2^-16; the default).  Env LOCO_PRECISION=f32|bf16x3 overrides.
+ * Invalidates the cached primal. */
+int  loco_set_precision(loco_ctx* ctx, int32_t mode);
+int  loco_get_precision(loco_ctx* ctx);
+
+/* Tuning hook: average ms of one convolution shape (random scratch data) over `iters` launches.
+ * mode: 0 raw, 1 GN+SiLU, 2 GN, 3 tangent, 4 cotangent; tile: -1 auto or a variant id. */
+int  loco_bench_conv(loco_ctx* ctx, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t B, int32_t mode,
+                     int32_t taps, int32_t tile, int32_t iters, float* ms_avg, void* stream);
+
 /* Per-kernel HIP-event profile of the convolution launches (bench.py roofline
  * leg).  While enabled every conv launch is bracketed by two events on the
  * caller's stream; loco_profile_report synchronises, then writes one line per

@@ -304,6 +304,7 @@ static inline int pick_tile(int Cout, int HW) {
     if (Cout > 64) return 1;
     return 3;
 }
+int conv_pick_tile(int Cout, int HW) { return pick_tile(Cout, HW); }
 static const TileCfg kTiles[4] = {{128, 128}, {128, 64}, {32, 128}, {64, 64}};
 
 int conv_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int taps) {
@@ -346,16 +347,19 @@ static void launch_tile(const ConvArgs& a, hipStream_t st) {
     }
 }
 
-const char* conv_variant_name(const ConvArgs& a, int taps) {
-    static const char* tiles[4] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1"};
-    static char names[2][4][5][48];
-    int t = pick_tile(a.Cout, a.Hout * a.Wout);
+int conv_bf16_pick_tile(int Cout, int HW, int Bsplit);   // conv_bf16.hip
+
+const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
+    static const char* tiles[6] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1", "2,2,2,4", "2,4,2,2"};
+    static char names[2][2][6][5][56];
+    int t = prec ? conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B * a.nsplit) : pick_tile(a.Cout, a.Hout * a.Wout);
+    if (t < 0 || t > 5) t = 0;
     int ti = taps == 9 ? 0 : 1;
     int m = a.mode;
     if (taps != 9 && m != CM_NONE) m = CM_GN;
     if (m < 0 || m > 4) m = 2;
-    char* n = names[ti][t][m];
-    if (!n[0]) snprintf(n, 48, "conv_mfma_f32<%d,%s,%d>", taps, tiles[t], m);
+    char* n = names[prec ? 1 : 0][ti][t][m];
+    if (!n[0]) snprintf(n, 56, "%s<%d,%s,%d>", prec ? "conv_mfma_bf16x3" : "conv_mfma_f32", taps, tiles[t], m);
     return n;
 }
 
@@ -374,6 +378,10 @@ void launch_conv(const ConvArgs& a, int taps, hipStream_t st) {
             default: launch_tile<1, CM_GN>(a, st); break;
         }
     }
+    launch_conv_splitk_reduce(a, st);
+}
+
+void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st) {
     if (a.nsplit > 1) {
         long total = (long)a.B * a.Cout * a.Hout * a.Wout;
         int blocks = (int)((total + 255) / 256);

@@ -1,0 +1,433 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on v_mfma_f32_32x32x16_bf16 with SPLIT-bf16
+// operands ("bf16x3"): every fp32 operand is carried as hi + lo bf16 halves and each
+// product is three MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate).  The dropped
+// lo*lo term and the rounding of lo are <= 2^-16 relative per product, i.e. the
+// result is fp32-faithful to ~1.5e-5 while running on the 2.5 PF/s matrix pipe
+// (effective peak 2500/3 = 833 TF/s vs 157 TF/s for the f32-input MFMA).
+//
+// Structure (same GEMM view as conv.hip: D[cout][pixel]): a workgroup owns MT couts
+// x NT pixels; Cin is walked in chunks of 16 channels (one MFMA k-step).  The halo
+// patch of a chunk is staged ONCE as 64-byte pixel records [hi k0-7|hi k8-15|lo k0-7|
+// lo k8-15] with the GroupNorm/SiLU forward, tangent or cotangent map applied in
+// fp32 BEFORE the split; weights are staged one kernel row (3 taps) at a time from
+// a pre-split, pre-swizzled global layout (straight 16-byte copies).  Records are
+// XOR-swizzled (chunk ^= (index>>2)&3) so every ds_read_b128 of 32 consecutive
+// pixels / couts is bank-conflict free.  Next stage's global loads are issued
+// before the MFMA block of the current one.
+#include "kernels.h"
+
+namespace loco {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BKC = 16;
+
+__device__ __forceinline__ float sigmoidf2_(float y) { return 1.0f / (1.0f + __expf(-y)); }
+
+// byte offset of logical 16-byte chunk q (0..3) inside the 64-byte record of index p
+__device__ __forceinline__ int rec_off(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 hb = (__bf16)v[j];
+        float r = v[j] - (float)hb;
+        __bf16 lb = (__bf16)r;
+        h[j] = __builtin_bit_cast(unsigned short, hb);
+        l[j] = __builtin_bit_cast(unsigned short, lb);
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+constexpr int max_halo(int NT, int taps, bool s2) {
+    if (taps == 1) return NT;
+    // TW = 32 (or the image width when smaller); worst case over the supported widths
+    if (NT >= 128) {
+        int th = NT / 32;
+        return s2 ? (2 * th + 1) * 65 : (th + 2) * 34;
+    }
+    return s2 ? 17 * 17 : 10 * 10;   // NT = 64 : 8x8 output tile
+}
+
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE, bool S2>
+__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int MT = WM * TM * 32;
+    constexpr int NT = WN * TN * 32;
+    constexpr int KS = (TAPS == 9) ? 3 : 1;
+    constexpr int NTS = KS;                          // taps per weight stage (one kernel row)
+    constexpr int NROW = (TAPS == 9) ? 3 : 1;        // weight stages per channel chunk
+    constexpr bool NEEDP = (MODE == CM_TAN_SILU || MODE == CM_COT_SILU);
+    constexpr int NITEM = (2 * max_halo(NT, TAPS, S2) + NTHR - 1) / NTHR;
+    constexpr int WTOT = NTS * MT * 4;               // 16-byte pieces of one weight stage
+    constexpr int NWV = (WTOT + NTHR - 1) / NTHR;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* Ws = smem_b;                      // [NTS][MT] records
+    unsigned char* Hs = smem_b + NTS * MT * 64;      // [halo_sz] records
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int khalf = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int S = a.stride;
+    const int TW = a.Wout < 32 ? a.Wout : 32;
+    const int TH = NT / TW;
+    const int tiles_x = a.Wout / TW;
+    const int oy0 = (blockIdx.x / tiles_x) * TH;
+    const int ox0 = (blockIdx.x % tiles_x) * TW;
+    const int co0 = blockIdx.y * MT;
+    const int b = blockIdx.z / a.nsplit;
+    const int split = blockIdx.z % a.nsplit;
+
+    const int halo_w = (TW - 1) * S + KS;
+    const int halo_h = (TH - 1) * S + KS;
+    const int halo_sz = halo_h * halo_w;
+
+    const int LH = (a.upsample || a.zins) ? a.Hin * 2 : a.Hin;
+    const int LW = (a.upsample || a.zins) ? a.Win * 2 : a.Win;
+    const long in_plane = (long)a.Hin * a.Win;
+
+    // staging items of this thread: (octet of 8 channels, halo position).  Loads are issued
+    // UNCONDITIONALLY from clamped addresses (uniform base + 32-bit per-lane offset) and masked
+    // afterwards: per-element branches around loads serialise them (one vmcnt(0) per element).
+    int ipos[NITEM], ioct[NITEM];
+    unsigned ivoff[NITEM];
+    bool ival[NITEM];
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+        int it = tid + i * NTHR;
+        int oct = it / halo_sz, pos = it - oct * halo_sz;
+        int off = -1;
+        if (it < 2 * halo_sz) {
+            int hy = pos / halo_w, hx = pos - hy * halo_w;
+            int Y = oy0 * S - a.pad + hy, X = ox0 * S - a.pad + hx;
+            if (Y >= 0 && Y < LH && X >= 0 && X < LW) {
+                if (a.upsample) off = (Y >> 1) * a.Win + (X >> 1);
+                else if (a.zins) off = ((Y | X) & 1) ? -1 : (Y >> 1) * a.Win + (X >> 1);
+                else off = Y * a.Win + X;
+            }
+        } else {
+            pos = -1; oct = 0;
+        }
+        ipos[i] = pos; ioct[i] = oct;
+        ival[i] = off >= 0;
+        ivoff[i] = (unsigned)(oct * 8 * (int)in_plane + (off >= 0 ? off : 0));
+    }
+
+    int hoff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int p = (wn * TN + j) * 32 + l31;
+        int ty = p / TW, tx = p - ty * TW;
+        hoff[j] = ty * S * halo_w + tx * S;
+    }
+    // A-operand (weight) record offsets inside one tap block: cout-local index fixed per lane
+    int aoff_hi[TM], aoff_lo[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int p = (wm * TM + i) * 32 + l31;
+        aoff_hi[i] = rec_off(p, khalf);
+        aoff_lo[i] = rec_off(p, 2 + khalf);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nchunks = (a.Cin + BKC - 1) / BKC;
+    const int cps = (nchunks + a.nsplit - 1) / a.nsplit;
+    const int cbeg = split * cps;
+    const int cend = (cbeg + cps < nchunks) ? cbeg + cps : nchunks;
+
+    const float* inb = a.in + (long)b * a.in_bs;
+    const float2* sxb = NEEDP ? a.sx : nullptr;                     // primal (S, xhat) cache, B = 1
+    const float* scb = (MODE == CM_GN_SILU || MODE == CM_GN) ? a.sc + (long)b * a.scsh_bs : nullptr;
+    const float* shb = (MODE == CM_GN_SILU || MODE == CM_GN) ? a.sh + (long)b * a.scsh_bs : nullptr;
+    const int wpitch = (a.Cout + 31) & ~31;                         // records per tap in the global layout
+    const uint4* wg = reinterpret_cast<const uint4*>(a.wb);
+
+    float hv[NITEM][8];
+    float2 pv[NEEDP ? NITEM : 1][8];
+    uint4 wv[NWV];
+    // per-channel constants of the chunk in flight: wave-uniform (scalar loads), selected per lane by octet
+    float cA[(MODE == CM_NONE) ? 1 : 16], cB[(MODE == CM_NONE) ? 1 : 16];
+    const float* tcb = NEEDP ? a.tc + (long)b * a.tc_bs : nullptr;   // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent)
+
+    auto prefetch_h = [&](int chunk) {
+        const int c0 = chunk * BKC;
+        if constexpr (MODE != CM_NONE) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                int c = c0 + kk < a.Cin ? c0 + kk : a.Cin - 1;
+                if constexpr (NEEDP) { cA[kk] = tcb[2 * c]; cB[kk] = tcb[2 * c + 1]; }
+                else { cA[kk] = scb[c]; cB[kk] = shb[c]; }
+            }
+        }
+        if (c0 + BKC <= a.Cin) {
+            // fast path: all 16 channels exist -> wave-uniform plane base + per-lane 32-bit offset
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* pk = inb + (long)(c0 + k) * in_plane;
+                const float2* sk = NEEDP ? sxb + (long)(c0 + k) * in_plane : nullptr;
+#pragma unroll
+                for (int i = 0; i < NITEM; ++i) {
+                    hv[i][k] = pk[ivoff[i]];
+                    if constexpr (NEEDP) pv[i][k] = sk[ivoff[i]];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NITEM; ++i) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int c = c0 + ioct[i] * 8 + k;
+                    int cc = c < a.Cin ? c : a.Cin - 1;
+                    unsigned vo = ivoff[i] - (unsigned)(ioct[i] * 8 * (int)in_plane);
+                    float v = inb[(long)cc * in_plane + vo];
+                    hv[i][k] = c < a.Cin ? v : 0.0f;
+                    if constexpr (NEEDP) {
+                        float2 pp = sxb[(long)cc * in_plane + vo];
+                        pv[i][k] = c < a.Cin ? pp : make_float2(0.f, 0.f);
+                    }
+                }
+            }
+        }
+    };
+    unsigned wrel[NWV];
+    bool wval[NWV];
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+        int e = tid + i * NTHR;
+        int tap = e / (MT * 4), rem = e - tap * (MT * 4);
+        int rec = co0 + (rem >> 2);
+        wval[i] = (e < WTOT) && (rec < wpitch);
+        wrel[i] = wval[i] ? (unsigned)((tap * wpitch + rec) * 4 + (rem & 3)) : 0u;
+    }
+    auto prefetch_w = [&](int chunk, int row) {
+        const uint4* wbase = wg + ((long)chunk * TAPS + row * NTS) * wpitch * 4;
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            uint4 v = wbase[wrel[i]];
+            wv[i] = wval[i] ? v : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stage_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            int e = tid + i * NTHR;
+            if (e < WTOT) *reinterpret_cast<uint4*>(Ws + (long)e * 16) = wv[i];
+        }
+    };
+    auto stage_h = [&](int chunk) {
+        const int c0 = chunk * BKC;
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            if (ipos[i] < 0) continue;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int c = c0 + ioct[i] * 8 + k;
+                float r = 0.0f;
+                if (ival[i] && c < a.Cin) {
+                    float d = hv[i][k];
+                    if constexpr (MODE == CM_NONE) {
+                        r = d;
+                    } else {
+                        const float ca = ioct[i] ? cA[8 + k] : cA[k];
+                        const float cb = ioct[i] ? cB[8 + k] : cB[k];
+                        if constexpr (MODE == CM_GN_SILU) {
+                            float y = fmaf(ca, d, cb);
+                            r = y * sigmoidf2_(y);
+                        } else if constexpr (MODE == CM_GN) {
+                            r = fmaf(ca, d, cb);
+                        } else {
+                            float Sv = pv[i][k].x, xh = pv[i][k].y;
+                            if constexpr (MODE == CM_TAN_SILU) r = Sv * (d - ca - xh * cb);
+                            else r = Sv * d - ca - xh * cb;
+                        }
+                    }
+                }
+                v[k] = r;
+            }
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            *reinterpret_cast<uint4*>(Hs + rec_off(ipos[i], ioct[i])) = hi;
+            *reinterpret_cast<uint4*>(Hs + rec_off(ipos[i], 2 + ioct[i])) = lo;
+        }
+    };
+
+    auto mfma_stage = [&](int row) {
+#pragma unroll
+        for (int tp = 0; tp < NTS; ++tp) {
+            const int tapoff = (TAPS == 9) ? row * halo_w + tp : 0;
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_hi[i]);
+                al[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_lo[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int p = hoff[j] + tapoff;
+                bh[j] = *reinterpret_cast<const bf16x8*>(Hs + rec_off(p, khalf));
+                bl[j] = *reinterpret_cast<const bf16x8*>(Hs + rec_off(p, 2 + khalf));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // Stage loop, unrolled over the kernel rows of a chunk so that the load queue is static:
+    // the halo loads of the NEXT chunk are issued (row 0) behind the weight loads of the next
+    // stage, and the waits in rows 1..2 are counted (vmcnt(#halo loads)), never vmcnt(0).
+    if (cbeg < cend) {
+        prefetch_h(cbeg);
+        prefetch_w(cbeg, 0);
+    }
+    for (int chunk = cbeg; chunk < cend; ++chunk) {
+#pragma unroll
+        for (int row = 0; row < NROW; ++row) {
+            __syncthreads();
+            stage_w();
+            if (row == 0) stage_h(chunk);
+            __syncthreads();
+            if (row + 1 < NROW) prefetch_w(chunk, row + 1);
+            else if (chunk + 1 < cend) prefetch_w(chunk + 1, 0);
+            if (row == 0 && chunk + 1 < cend) prefetch_h(chunk + 1);
+            mfma_stage(row);
+        }
+    }
+
+    // epilogue.  D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const long out_plane = (long)a.Hout * a.Wout;
+    const bool full_co = (co0 + MT <= a.Cout);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int p = (wn * TN + j) * 32 + l31;
+        int ty = p / TW, tx = p - ty * TW;
+        int oy = oy0 + ty, ox = ox0 + tx;
+        const unsigned pix = (unsigned)(oy * a.Wout + ox);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int cob = co0 + (wm * TM + i) * 32 + 4 * khalf;
+            if (a.nsplit > 1) {
+                float* pb = a.partial + (((long)split * a.B + b) * a.Cout) * out_plane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co = cob + (r & 3) + 8 * (r >> 2);
+                    if (full_co || co < a.Cout) pb[(long)co * out_plane + pix] = acc[i][j][r];
+                }
+            } else {
+                float* ob = a.out + (long)b * a.out_bs;
+                const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+                const float* b2 = a.bias2 ? a.bias2 + (long)b * a.bias2_bs : nullptr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co = cob + (r & 3) + 8 * (r >> 2);
+                    if (!(full_co || co < a.Cout)) continue;
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[co];
+                    if (b2) v += b2[co];
+                    const long off = (long)co * out_plane + pix;
+                    if (rb) v += rb[off];
+                    if (a.accumulate) v += ob[off];
+                    ob[off] = v;
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+int conv_pick_tile(int Cout, int HW);   // conv.hip
+
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE, bool S2>
+static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
+    constexpr int MT = WM * TM * 32, NT = WN * TN * 32;
+    constexpr int KS = (TAPS == 9) ? 3 : 1;
+    int TW = a.Wout < 32 ? a.Wout : 32;
+    int TH = NT / TW;
+    int halo_w = (TW - 1) * a.stride + KS, halo_h = (TH - 1) * a.stride + KS;
+    size_t lds = (size_t)KS * MT * 64 + (size_t)halo_w * halo_h * 64;
+    dim3 grid((a.Hout * a.Wout) / NT, (a.Cout + MT - 1) / MT, a.B * a.nsplit);
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, S2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, S2>), grid, dim3(WM * WN * 64), lds, st, a);
+}
+
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE>
+static void launch_one_b(const ConvArgs& a, hipStream_t st) {
+    if constexpr (MODE == CM_NONE && TAPS == 9) {
+        if (a.stride == 2) { launch_one_b2<TAPS, WM, WN, TM, TN, MODE, true>(a, st); return; }
+    }
+    launch_one_b2<TAPS, WM, WN, TM, TN, MODE, false>(a, st);
+}
+
+int g_bf16_tile_override = -1;   // debug / tuning: force a tile variant for the big-image case
+
+int conv_bf16_pick_tile(int Cout, int HW, int Bsplit) {
+    int t = conv_pick_tile(Cout, HW);
+    if (t == 0 && HW >= 256) {
+        if (g_bf16_tile_override >= 0) return g_bf16_tile_override;
+        // 128 x 256 tile with 8 waves once it still fills the chip (>= 2 workgroups per CU)
+        long blocks = (long)(HW / 256) * ((Cout + 127) / 128) * Bsplit;
+        if (blocks >= 512) return 5;
+    }
+    return t;
+}
+
+template <int TAPS, int MODE>
+static void launch_tile_b(const ConvArgs& a, hipStream_t st) {
+    switch (conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B * a.nsplit)) {
+        case 4: launch_one_b<TAPS, 2, 2, 2, 4, MODE>(a, st); break;   // 128 x 256, 4 waves (64 x 128 each)
+        case 5: launch_one_b<TAPS, 2, 4, 2, 2, MODE>(a, st); break;   // 128 x 256, 8 waves (64 x 64 each)
+        case 0: launch_one_b<TAPS, 2, 2, 2, 2, MODE>(a, st); break;
+        case 1: launch_one_b<TAPS, 4, 1, 1, 2, MODE>(a, st); break;
+        case 2: launch_one_b<TAPS, 1, 4, 1, 1, MODE>(a, st); break;
+        default: launch_one_b<TAPS, 2, 2, 1, 1, MODE>(a, st); break;
+    }
+}
+
+void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st) {
+    if (taps == 9) {
+        switch (a.mode) {
+            case CM_NONE: launch_tile_b<9, CM_NONE>(a, st); break;
+            case CM_GN_SILU: launch_tile_b<9, CM_GN_SILU>(a, st); break;
+            case CM_TAN_SILU: launch_tile_b<9, CM_TAN_SILU>(a, st); break;
+            case CM_COT_SILU: launch_tile_b<9, CM_COT_SILU>(a, st); break;
+            default: launch_tile_b<9, CM_GN>(a, st); break;
+        }
+    } else {
+        switch (a.mode) {
+            case CM_NONE: launch_tile_b<1, CM_NONE>(a, st); break;
+            default: launch_tile_b<1, CM_GN>(a, st); break;
+        }
+    }
+    launch_conv_splitk_reduce(a, st);
+}
+
+}  // namespace loco

@@ -14,6 +14,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -40,10 +41,16 @@ struct Tens { long off; int C, H, W; };
 struct ConvP {       // one convolution's parameters in kernel layouts
     float* wf = nullptr;    // forward  [Cin][taps][CoutP]
     float* wd = nullptr;    // dgrad    [Cout][taps][CinP]  (flipped taps)
+    float* wbf = nullptr;   // split-bf16 forward records [Cin/16][taps][CoutP][32 x u16]
+    float* wbd = nullptr;   // split-bf16 dgrad records   [Cout/16][taps][CinP][32 x u16]
     float* bias = nullptr;
     int cin = 0, cout = 0, taps = 0;
 };
-struct NormP { float* gamma = nullptr; float* beta = nullptr; int C = 0; long soff = 0; };   // soff: stats offset
+struct NormP {
+    float* gamma = nullptr; float* beta = nullptr; int C = 0;
+    long soff = 0;      // offset into a stats arena
+    long sx_off = -1;   // offset (in float2) into the primal {S, xhat} cache, -1: none
+};
 
 enum OpKind { OP_CONV_IN, OP_RES, OP_ATTN, OP_DOWN, OP_UP, OP_OUT };
 
@@ -94,6 +101,9 @@ struct loco_ctx {
     float* tmpA = nullptr;         // [64][n] temp for solver rotations
     double *G = nullptr, *Q = nullptr, *W = nullptr, *gscratch = nullptr;
     float* alphas = nullptr;
+    float2* sxcache = nullptr;     // primal {S, xhat} per GroupNorm+SiLU input (bf16x3 path)
+    long sx_total = 0;
+    int prec = 0;                  // 0: exact fp32 MFMA, 1: split-bf16 (bf16x3) MFMA
     std::vector<float*> owned;     // everything to hipFree
     size_t bytes = 0;
 
@@ -151,9 +161,13 @@ NormP new_norm(loco_ctx* c, int C) {
     NormP n;
     n.C = C;
     n.soff = c->stats_per_sample;
-    // layout per norm: sc[C], sh[C], mr[2G], tst[2G]
-    c->stats_per_sample += align4(2L * C + 4L * c->cfg.gn_groups);
+    // layout per norm: sc[C], sh[C], mr[2G], tst[2G], tc[2C]
+    c->stats_per_sample += align4(4L * C + 4L * c->cfg.gn_groups);
     return n;
+}
+void norm_cache(loco_ctx* c, NormP& n, int HW) {
+    n.sx_off = c->sx_total;
+    c->sx_total += (long)n.C * HW;
 }
 bool attn_at(const loco_unet_cfg& cfg, int res) {
     for (int i = 0; i < cfg.num_attn_res; ++i)
@@ -308,6 +322,16 @@ int build_program(loco_ctx* c) {
         c->ops.push_back(o);
         c->eps_t = o.out;
     }
+    for (auto& op : c->ops) {
+        if (op.kind == OP_RES) {
+            const Tens& ti = c->tens[op.in];
+            norm_cache(c, op.n1, ti.H * ti.W);
+            norm_cache(c, op.n2, ti.H * ti.W);
+        } else if (op.kind == OP_OUT) {
+            const Tens& ti = c->tens[op.in];
+            norm_cache(c, op.n1, ti.H * ti.W);
+        }
+    }
     return 0;
 }
 
@@ -372,6 +396,40 @@ int upload(loco_ctx* c, float** dst, const std::vector<float>& h) {
     return 0;
 }
 
+static inline uint16_t f2bf(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f;
+}
+// split-bf16 records: W(o, i, t) for o < nout, i < nin -> [ceil(nin/16)][taps][noutP][32 x u16], 64-byte record
+// per (chunk, tap, o): logical 16-byte pieces {hi k0-7, hi k8-15, lo k0-7, lo k8-15} stored at piece ^ ((o>>2)&3)
+template <typename F>
+static std::vector<float> build_records(int nin, int nout, int taps, F get) {
+    int nch = (nin + 15) / 16, noutP = (nout + 31) & ~31;
+    std::vector<uint16_t> rec((size_t)nch * taps * noutP * 32, 0);
+    for (int ck = 0; ck < nch; ++ck)
+        for (int t = 0; t < taps; ++t)
+            for (int o = 0; o < nout; ++o) {
+                uint16_t* r = rec.data() + (((size_t)ck * taps + t) * noutP + o) * 32;
+                int sw = (o >> 2) & 3;
+                for (int k = 0; k < 16; ++k) {
+                    int i = ck * 16 + k;
+                    float v = (i < nin) ? get(o, i, t) : 0.f;
+                    uint16_t h = f2bf(v);
+                    uint16_t l = f2bf(v - bf2f(h));
+                    int qh = (k >> 3) ^ sw, ql = (2 + (k >> 3)) ^ sw;
+                    r[qh * 8 + (k & 7)] = h;
+                    r[ql * 8 + (k & 7)] = l;
+                }
+            }
+    std::vector<float> out(rec.size() / 2);
+    std::memcpy(out.data(), rec.data(), rec.size() * 2);
+    return out;
+}
+
 // weights [cout][cin][k][k] -> forward [cin][taps][coutP], dgrad [cout][taps][cinP] with flipped taps
 int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::vector<const HostParam*>& bs,
               ConvP* out) {
@@ -396,6 +454,12 @@ int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::v
     }
     out->cin = cin; out->cout = cout; out->taps = taps;
     if (upload(c, &out->wf, wf) || upload(c, &out->wd, wd) || upload(c, &out->bias, bias)) return -1;
+    // the same two operators as split-bf16 records (read back from the fp32 layouts built above)
+    auto fwd = [&](int o, int i, int t) { return wf[((size_t)i * taps + t) * coutP + o]; };
+    auto dgr = [&](int o, int i, int t) { return wd[((size_t)i * taps + t) * cinP + o]; };   // o: cin index, i: cout index
+    std::vector<float> rf = build_records(cin, cout, taps, fwd);
+    std::vector<float> rd = build_records(cout, cin, taps, dgr);
+    if (upload(c, &out->wbf, rf) || upload(c, &out->wbd, rd)) return -1;
     return 0;
 }
 int make_conv1(loco_ctx* c, const std::string& name, ConvP* out) {
@@ -511,24 +575,30 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
     a.partial = c->partial;
     if (c->prof_on) {
         loco_ctx::ProfRec r;
-        r.name = conv_variant_name(a, taps);
+        r.name = conv_variant_name(a, taps, c->prec);
         r.flops = 2.0 * a.Cin * a.Cout * taps * (double)a.Hout * a.Wout * a.B;
         if (a.zins) r.flops *= 0.25;     // algorithmic work of the stride-2 data gradient
         r.e0 = c->next_event(); r.e1 = c->next_event();
         (void)hipEventRecord(r.e0, st);
-        launch_conv(a, taps, st);
+        if (c->prec == 1) launch_conv_bf16x3(a, taps, st); else launch_conv(a, taps, st);
         (void)hipEventRecord(r.e1, st);
         c->prof.push_back(r);
         return;
     }
-    launch_conv(a, taps, st);
+    if (c->prec == 1) launch_conv_bf16x3(a, taps, st); else launch_conv(a, taps, st);
+}
+
+inline void setw(ConvArgs& a, const ConvP& p, bool dgrad) {
+    a.w = dgrad ? p.wd : p.wf;
+    a.wb = dgrad ? (const void*)p.wbd : (const void*)p.wbf;
 }
 
 // sc / sh / mr / tst pointers of a norm inside a stats arena
-struct NS { float *sc, *sh, *mr, *tst; };
+struct NS { float *sc, *sh, *mr, *tst, *tc; };
 NS nstats(const loco_ctx* c, float* base, const NormP& n) {
     NS s;
     s.sc = base + n.soff; s.sh = s.sc + n.C; s.mr = s.sh + n.C; s.tst = s.mr + 2 * c->cfg.gn_groups;
+    s.tc = s.tst + 2 * c->cfg.gn_groups;
     return s;
 }
 
@@ -552,7 +622,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
             case OP_CONV_IN: {
                 ConvArgs a; conv_defaults(a);
                 a.in = x; a.in_bs = c->n_in; a.Cin = cfg.in_channels; a.Hin = cfg.resolution; a.Win = cfg.resolution;
-                a.w = op.conv.wf; a.bias = op.conv.bias;
+                setw(a, op.conv, false); a.bias = op.conv.bias;
                 a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
                 break;
@@ -563,7 +633,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 NS s1 = nstats(c, stats, op.n1);
                 ConvArgs a; conv_defaults(a);
                 a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
-                a.w = op.c1.wf; a.bias = op.c1.bias; a.bias2 = c->tproj + op.tproj_off; a.bias2_bs = 0;
+                setw(a, op.c1, false); a.bias = op.c1.bias; a.bias2 = c->tproj + op.tproj_off; a.bias2_bs = 0;
                 a.mode = CM_GN_SILU; a.sc = s1.sc; a.sh = s1.sh; a.scsh_bs = SB;
                 a.out = p.T(op.h1); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
@@ -573,14 +643,14 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 if (op.has_nin) {
                     ConvArgs n; conv_defaults(n);
                     n.in = p.T(op.in); n.in_bs = p.bs(); n.Cin = ti.C; n.Hin = ti.H; n.Win = ti.W;
-                    n.w = op.nin.wf; n.bias = op.nin.bias; n.pad = 0;
+                    setw(n, op.nin, false); n.bias = op.nin.bias; n.pad = 0;
                     n.out = p.T(op.out); n.out_bs = p.bs(); n.Cout = to.C; n.Hout = to.H; n.Wout = to.W; n.B = B;
                     run_conv(c, n, 1, st);
                     res = p.T(op.out);
                 }
                 ConvArgs b; conv_defaults(b);
                 b.in = p.T(op.h1); b.in_bs = p.bs(); b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
-                b.w = op.c2.wf; b.bias = op.c2.bias; b.res = res; b.res_bs = p.bs();
+                setw(b, op.c2, false); b.bias = op.c2.bias; b.res = res; b.res_bs = p.bs();
                 b.mode = CM_GN_SILU; b.sc = s2.sc; b.sh = s2.sh; b.scsh_bs = SB;
                 b.out = p.T(op.out); b.out_bs = p.bs(); b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
                 run_conv(c, b, 9, st);
@@ -592,7 +662,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 NS s = nstats(c, stats, op.n1);
                 ConvArgs a; conv_defaults(a);
                 a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = C; a.Hin = to.H; a.Win = to.W;
-                a.w = op.qkvc.wf; a.bias = op.qkvc.bias; a.pad = 0;
+                setw(a, op.qkvc, false); a.bias = op.qkvc.bias; a.pad = 0;
                 a.mode = CM_GN; a.sc = s.sc; a.sh = s.sh; a.scsh_bs = SB;
                 a.out = p.T(op.qkv); a.out_bs = p.bs(); a.Cout = 3 * C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 1, st);
@@ -613,7 +683,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 launch_gemm(h, st);
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = p.T(op.o); pr.in_bs = p.bs(); pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
-                pr.w = op.proj.wf; pr.bias = op.proj.bias; pr.pad = 0;
+                setw(pr, op.proj, false); pr.bias = op.proj.bias; pr.pad = 0;
                 pr.res = p.T(op.in); pr.res_bs = p.bs();
                 pr.out = p.T(op.out); pr.out_bs = p.bs(); pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
                 run_conv(c, pr, 1, st);
@@ -623,7 +693,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
                 a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
-                a.w = op.conv.wf; a.bias = op.conv.bias;
+                setw(a, op.conv, false); a.bias = op.conv.bias;
                 if (op.kind == OP_DOWN) { a.stride = 2; a.pad = 0; } else { a.upsample = 1; }
                 a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
@@ -635,7 +705,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 NS s = nstats(c, stats, op.n1);
                 ConvArgs a; conv_defaults(a);
                 a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
-                a.w = op.conv.wf; a.bias = op.conv.bias;
+                setw(a, op.conv, false); a.bias = op.conv.bias;
                 a.mode = CM_GN_SILU; a.sc = s.sc; a.sh = s.sh; a.scsh_bs = SB;
                 a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
@@ -653,7 +723,7 @@ void tangent_stats(loco_ctx* c, const NormP& n, const float* d, long dbs, const 
     NS sp = nstats(c, c->statsP, n);
     NS stt = nstats(c, c->statsT, n);
     launch_gn_tstats(d, dbs, x, 0, B, n.C, HW, c->cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, 0, stt.tst,
-                     c->stats_per_sample, c->red, st);
+                     stt.tc, c->stats_per_sample, c->red, st);
 }
 void set_tan(loco_ctx* c, ConvArgs& a, const NormP& n, const float* prim) {
     NS sp = nstats(c, c->statsP, n);
@@ -661,6 +731,8 @@ void set_tan(loco_ctx* c, ConvArgs& a, const NormP& n, const float* prim) {
     a.mode = CM_TAN_SILU; a.prim = prim; a.prim_bs = 0;
     a.sc = sp.sc; a.sh = sp.sh; a.scsh_bs = 0; a.mr = sp.mr; a.mr_bs = 0; a.gamma_ = n.gamma;
     a.tst = stt.tst; a.tst_bs = c->stats_per_sample; a.cpg = n.C / c->cfg.gn_groups;
+    a.tc = stt.tc; a.tc_bs = c->stats_per_sample;
+    a.sx = (n.sx_off >= 0 && c->sxcache) ? c->sxcache + n.sx_off : nullptr;
 }
 
 int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
@@ -675,7 +747,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
             case OP_CONV_IN: {
                 ConvArgs a; conv_defaults(a);
                 a.in = V; a.in_bs = c->n_in; a.Cin = cfg.in_channels; a.Hin = cfg.resolution; a.Win = cfg.resolution;
-                a.w = op.conv.wf;
+                setw(a, op.conv, false);
                 a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
                 break;
@@ -685,7 +757,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
                 ConvArgs a; conv_defaults(a);
                 a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
-                a.w = op.c1.wf;
+                setw(a, op.c1, false);
                 set_tan(c, a, op.n1, TP(op.in));
                 a.out = TT(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
@@ -694,14 +766,14 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 if (op.has_nin) {
                     ConvArgs n; conv_defaults(n);
                     n.in = TT(op.in); n.in_bs = PS; n.Cin = ti.C; n.Hin = ti.H; n.Win = ti.W;
-                    n.w = op.nin.wf; n.pad = 0;
+                    setw(n, op.nin, false); n.pad = 0;
                     n.out = TT(op.out); n.out_bs = PS; n.Cout = to.C; n.Hout = to.H; n.Wout = to.W; n.B = B;
                     run_conv(c, n, 1, st);
                     res = TT(op.out);
                 }
                 ConvArgs b; conv_defaults(b);
                 b.in = TT(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
-                b.w = op.c2.wf; b.res = res; b.res_bs = PS;
+                setw(b, op.c2, false); b.res = res; b.res_bs = PS;
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.out = TT(op.out); b.out_bs = PS; b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
                 run_conv(c, b, 9, st);
@@ -716,7 +788,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                                 cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
                 ConvArgs a; conv_defaults(a);
                 a.in = TT(op.hn); a.in_bs = PS; a.Cin = C; a.Hin = to.H; a.Win = to.W;
-                a.w = op.qkvc.wf; a.pad = 0;
+                setw(a, op.qkvc, false); a.pad = 0;
                 a.out = TT(op.qkv); a.out_bs = PS; a.Cout = 3 * C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 1, st);
                 float* q = TP(op.qkv); float* k = q + (long)C * T; float* v = k + (long)C * T;
@@ -741,7 +813,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 launch_gemm(h, st);
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = TT(op.o); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
-                pr.w = op.proj.wf; pr.pad = 0; pr.res = TT(op.in); pr.res_bs = PS;
+                setw(pr, op.proj, false); pr.pad = 0; pr.res = TT(op.in); pr.res_bs = PS;
                 pr.out = TT(op.out); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
                 run_conv(c, pr, 1, st);
                 break;
@@ -750,7 +822,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
                 a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
-                a.w = op.conv.wf;
+                setw(a, op.conv, false);
                 if (op.kind == OP_DOWN) { a.stride = 2; a.pad = 0; } else { a.upsample = 1; }
                 a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
@@ -761,7 +833,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), ti.H * ti.W, B, st);
                 ConvArgs a; conv_defaults(a);
                 a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
-                a.w = op.conv.wf;
+                setw(a, op.conv, false);
                 set_tan(c, a, op.n1, TP(op.in));
                 a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
@@ -778,7 +850,7 @@ void cot_stats(loco_ctx* c, const NormP& n, const float* d, long dbs, const floa
     NS sp = nstats(c, c->statsP, n);
     NS stt = nstats(c, c->statsT, n);
     launch_gn_tstats(d, dbs, x, 0, B, n.C, HW, c->cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, kind, stt.tst,
-                     c->stats_per_sample, c->red, st);
+                     stt.tc, c->stats_per_sample, c->red, st);
 }
 
 // ge: cotangent of eps [B][n]; result A[B][n] = conv_in^T(...) + gx0
@@ -797,7 +869,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
                 a.in = ge; a.in_bs = c->n_in; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
-                a.w = op.conv.wd;
+                setw(a, op.conv, true);
                 a.out = TG(op.a1); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
                 run_conv(c, a, 9, st);
                 cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), ti.H * ti.W, B, 1, st);
@@ -811,7 +883,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
-                a.w = op.conv.wd;
+                setw(a, op.conv, true);
                 a.out = TG(op.up); a.out_bs = PS; a.Cout = ti.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
                 launch_pool2x2_sum(TG(op.up), PS, TG(op.in), PS, 0, B, ti.C, ti.H, ti.W, st);
@@ -821,7 +893,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
-                a.w = op.conv.wd; a.zins = 1; a.pad = 2; a.accumulate = op.in_is_skip ? 1 : 0;
+                setw(a, op.conv, true); a.zins = 1; a.pad = 2; a.accumulate = op.in_is_skip ? 1 : 0;
                 a.out = TG(op.in); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
                 run_conv(c, a, 9, st);
                 break;
@@ -831,14 +903,14 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 // g_a2 = dgrad conv2 (g_out)  -> slot h1
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
-                a.w = op.c2.wd;
+                setw(a, op.c2, true);
                 a.out = TG(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
                 cot_stats(c, op.n2, TG(op.h1), PS, TP(op.h1), HW, B, 1, st);
                 // g_a1 = dgrad conv1 ( norm2/silu cotangent of g_a2 )  -> slot a1
                 ConvArgs b; conv_defaults(b);
                 b.in = TG(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
-                b.w = op.c1.wd;
+                setw(b, op.c1, true);
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.mode = CM_COT_SILU;
                 b.out = TG(op.a1); b.out_bs = PS; b.Cout = ti.C; b.Hout = ti.H; b.Wout = ti.W; b.B = B;
@@ -850,7 +922,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 if (op.has_nin) {
                     ConvArgs n; conv_defaults(n);
                     n.in = TG(op.out); n.in_bs = PS; n.Cin = to.C; n.Hin = to.H; n.Win = to.W;
-                    n.w = op.nin.wd; n.pad = 0; n.accumulate = acc;
+                    setw(n, op.nin, true); n.pad = 0; n.accumulate = acc;
                     n.out = TG(op.in); n.out_bs = PS; n.Cout = ti.C; n.Hout = ti.H; n.Wout = ti.W; n.B = B;
                     run_conv(c, n, 1, st);
                     launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 1, B, ti.C, HW, G,
@@ -868,7 +940,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 // g_o = proj^T g_out
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = TG(op.out); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
-                pr.w = op.proj.wd; pr.pad = 0;
+                setw(pr, op.proj, true); pr.pad = 0;
                 pr.out = TG(op.o); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
                 run_conv(c, pr, 1, st);
                 // g_v[c][j] = sum_i g_o[c][i] P[i][j]
@@ -901,7 +973,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 // g_hn = Wqkv^T g_qkv
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.qkv); a.in_bs = PS; a.Cin = 3 * C; a.Hin = to.H; a.Win = to.W;
-                a.w = op.qkvc.wd; a.pad = 0;
+                setw(a, op.qkvc, true); a.pad = 0;
                 a.out = TG(op.hn); a.out_bs = PS; a.Cout = C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 1, st);
                 cot_stats(c, op.n1, TG(op.hn), PS, TP(op.in), HW, B, 2, st);
@@ -914,7 +986,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
             case OP_CONV_IN: {
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
-                a.w = op.conv.wd; a.res = gx0; a.res_bs = c->n_in;
+                setw(a, op.conv, true); a.res = gx0; a.res_bs = c->n_in;
                 a.out = Aout; a.out_bs = c->n_in; a.Cout = cfg.in_channels; a.Hout = cfg.resolution;
                 a.Wout = cfg.resolution; a.B = B;
                 run_conv(c, a, 9, st);
@@ -970,6 +1042,13 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         if (dalloc(c, &c->gscratch, nblk * 64 * 64 + 4096)) return -1;
     }
     if (dalloc(c, &c->alphas, 256)) return -1;
+    if (dalloc(c, &c->sxcache, (size_t)c->sx_total)) return -1;
+    {
+        const char* e = getenv("LOCO_PRECISION");
+        c->prec = (e && std::string(e) == "f32") ? 0 : 1;   // default: split-bf16 (fp32-faithful to ~2^-16)
+        const char* t = getenv("LOCO_BF16_TILE");
+        if (t) g_bf16_tile_override = atoi(t);
+    }
     if (dalloc(c, &c->mask, (size_t)c->n_in) || dalloc(c, &c->mask_idx, (size_t)c->n_in)) return -1;
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
@@ -1070,6 +1149,22 @@ int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_
     hipStream_t st = (hipStream_t)stream;
     if (forward_pass(c, x, t, 1, c->arenaP, c->statsP, st)) return -1;
     c->primal_B = 1;
+    if (c->prec == 1) {
+        // {S, xhat} cache for the tangent / cotangent staging of the split-bf16 convs
+        for (auto& op : c->ops) {
+            if (op.kind != OP_RES && op.kind != OP_OUT) continue;
+            const Tens& ti = c->tens[op.in];
+            const int HW = ti.H * ti.W, G = c->cfg.gn_groups;
+            NS s1 = nstats(c, c->statsP, op.n1);
+            launch_gn_cache(c->arenaP + ti.off, op.n1.C, HW, op.n1.C / G, s1.sc, s1.sh, s1.mr,
+                            c->sxcache + op.n1.sx_off, st);
+            if (op.kind == OP_RES) {
+                NS s2 = nstats(c, c->statsP, op.n2);
+                launch_gn_cache(c->arenaP + c->tens[op.h1].off, op.n2.C, HW, op.n2.C / G, s2.sc, s2.sh, s2.mr,
+                                c->sxcache + op.n2.sx_off, st);
+            }
+        }
+    }
     if (use_et) { c->p_cv = 0.f; c->p_ce = 1.f; }
     else { c->p_cv = 1.0f / std::sqrt(at); c->p_ce = -std::sqrt(1.0f - at) / std::sqrt(at); }
     c->has_mask = (mask != nullptr);
@@ -1221,6 +1316,64 @@ int loco_timer_stop(loco_ctx* c, void* stream, float* ms) {
     HIPCHK(c, hipEventRecord(c->ev1, (hipStream_t)stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+int loco_set_precision(loco_ctx* c, int32_t mode) {
+    if (!c) return -2;
+    if (mode != 0 && mode != 1) { c->err = "precision mode must be 0 (f32) or 1 (bf16x3)"; return -2; }
+    c->prec = mode;
+    c->primal_ok = false;   // the {S, xhat} cache belongs to the mode it was built in
+    return 0;
+}
+int loco_get_precision(loco_ctx* c) { return c ? c->prec : -2; }
+
+// Tuning hook: time one convolution shape on scratch data (random inputs), avg ms over `iters` launches.
+int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t B, int32_t mode,
+                    int32_t taps, int32_t tile, int32_t iters, float* ms_avg, void* stream) {
+    if (!c) return -2;
+    if (finalize_params(c)) return -3;
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const long in_e = (long)cin * HW, out_e = (long)cout * HW;
+    if ((in_e + out_e) * B > (long)c->cfg.max_batch * c->per_sample || 2 * in_e > (long)c->per_sample ||
+        in_e > c->sx_total) { c->err = "bench_conv: shape exceeds the arenas"; return -2; }
+    float* in = c->arenaT;
+    float* out = c->arenaT + in_e * B;
+    launch_fill_random(in, in_e * B, 1u, 1.0f, st);
+    launch_fill_random(c->arenaP, in_e, 2u, 1.0f, st);
+    launch_fill_random(reinterpret_cast<float*>(c->sxcache), 2 * in_e, 3u, 1.0f, st);
+    launch_fill_random(c->statsP, c->stats_per_sample, 4u, 1.0f, st);
+    launch_fill_random(c->statsT, c->stats_per_sample * B, 5u, 0.01f, st);
+    // weights: any conv of matching size is fine for timing; synthesise records in the split-K workspace
+    size_t wfl = (size_t)((cin + 15) / 16) * 16 * taps * ((cout + 31) & ~31);
+    if (wfl * 2 > c->partial_floats) { c->err = "bench_conv: weights exceed workspace"; return -2; }
+    float* wf = c->partial + c->partial_floats - wfl * 2;
+    launch_fill_random(wf, (long)wfl * 2, 6u, 0.05f, st);
+    ConvArgs a; conv_defaults(a);
+    a.in = in; a.in_bs = in_e; a.Cin = cin; a.Hin = H; a.Win = W;
+    a.prim = c->arenaP; a.prim_bs = 0; a.sx = c->sxcache;
+    a.w = wf; a.wb = wf;
+    a.out = out; a.out_bs = out_e; a.Cout = cout; a.Hout = H; a.Wout = W; a.B = B;
+    a.mode = mode; a.pad = taps == 9 ? 1 : 0;
+    a.sc = c->statsP; a.sh = c->statsP + cin; a.scsh_bs = 0; a.mr = c->statsP + 2 * cin; a.mr_bs = 0;
+    a.gamma_ = c->statsP; a.tst = c->statsT; a.tst_bs = c->stats_per_sample; a.cpg = cin / c->cfg.gn_groups;
+    a.tc = c->statsT + 64; a.tc_bs = c->stats_per_sample;
+    if (a.cpg < 1) a.cpg = 1;
+    a.nsplit = 1; a.partial = c->partial;
+    int saved = g_bf16_tile_override;
+    g_bf16_tile_override = tile;
+    auto run = [&]() { if (c->prec == 1) launch_conv_bf16x3(a, taps, st); else launch_conv(a, taps, st); };
+    run();
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    for (int i = 0; i < iters; ++i) run();
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    g_bf16_tile_override = saved;
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_avg = ms / iters;
+    HIPCHK(c, hipGetLastError());
     return 0;
 }
 

@@ -23,6 +23,10 @@ struct ConvArgs {
     const float* prim; long prim_bs;
     // weights, layout [Cin][TAPS][Cout]
     const float* w;
+    // split-bf16 weights, layout [Cin/16][TAPS][Cout^32][hi0-7|hi8-15|lo0-7|lo8-15] (swizzled 64-byte records)
+    const void* wb;
+    // primal cache {S = sc*silu'(y), xhat} per element of `in`'s primal (bf16x3 path, modes TAN/COT)
+    const float2* sx;
     float* out; long out_bs; int Cout, Hout, Wout;
     const float* bias;                   // [Cout] or nullptr
     const float* bias2; long bias2_bs;   // [B][Cout] or nullptr (temb projection)
@@ -32,6 +36,7 @@ struct ConvArgs {
     const float* mr; long mr_bs;                      // per (b_prim, group): {mean, rstd}
     const float* gamma_;                              // per channel GroupNorm gain (mode COT)
     const float* tst; long tst_bs;                    // per (b, group): {m1, m2}
+    const float* tc; long tc_bs;                      // per (b, channel): {m1, m2} or {rstd*m1, rstd*m2} (bf16x3 path)
     int cpg;                                          // channels per group
     int mode;
     int stride;      // 1 or 2
@@ -45,8 +50,16 @@ struct ConvArgs {
 };
 
 void launch_conv(const ConvArgs& a, int taps, hipStream_t st);
+void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st);
+void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st);
+int conv_pick_tile(int Cout, int HW);
+extern int g_bf16_tile_override;
+void launch_fill_random(float* p, long count, unsigned seed, float scale, hipStream_t st);
+// sx[c][hw] = { sc_c * silu'(sc_c*x + sh_c), (x - mean_g) * rstd_g }   (B = 1 primal cache)
+void launch_gn_cache(const float* x, int C, int HW, int cpg, const float* sc, const float* sh, const float* mr,
+                     float2* sx, hipStream_t st);
 // name of the kernel variant launch_conv would pick (for the per-kernel profile)
-const char* conv_variant_name(const ConvArgs& a, int taps);
+const char* conv_variant_name(const ConvArgs& a, int taps, int prec);
 // workspace (floats) a conv launch with these args needs for split-K partials
 size_t conv_partial_floats(const ConvArgs& a);
 int conv_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int taps);
@@ -76,7 +89,7 @@ void launch_gn_stats(const float* x, long bs, int B, int C, int HW, int G, float
 //   tst[b][g] = { mean_g(z), mean_g(xh * z) },  xh = (x - mean)*rstd of the primal (prim_bs may be 0)
 void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int B, int C, int HW, int G,
                       const float* sc, const float* sh, const float* mr, long pbs_c, long pbs_g,
-                      int kind, float* tst, long tst_bs, double* scratch, hipStream_t st);
+                      int kind, float* tst, float* tc, long tst_bs, double* scratch, hipStream_t st);
 // elementwise GroupNorm applications (no conv behind them):
 //   kind 0: out = sc*x + sh                                    (attention norm forward)
 //   kind 1: out = sc*(d - m1 - xh*m2)                          (attention norm tangent)

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void gn_tstats_partial(const float* d, long d_
 }
 
 __global__ void gn_tstats_finalize(const double* scratch, int nsplit, long BG, int G, double inv_n, float* tst,
-                                   long tbs) {
+                                   float* tc, long tbs, int cpg, const float* mr, long pbs_g, int kind) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= BG) return;
     float* o = tst + (i / G) * tbs + 2 * (i % G);
@@ -187,13 +187,21 @@ __global__ void gn_tstats_finalize(const double* scratch, int nsplit, long BG, i
         a += scratch[(i * nsplit + s) * 2];
         c += scratch[(i * nsplit + s) * 2 + 1];
     }
-    o[0] = (float)(a * inv_n);
-    o[1] = (float)(c * inv_n);
+    float m1 = (float)(a * inv_n), m2 = (float)(c * inv_n);
+    o[0] = m1;
+    o[1] = m2;
+    if (tc) {
+        // per-channel expansion for the split-bf16 conv staging; the cotangent form carries rstd
+        int g = (int)(i % G);
+        float f = kind == 0 ? 1.0f : mr[(i / G) * pbs_g + 2 * g + 1];
+        float* t = tc + (i / G) * tbs + 2 * (long)g * cpg;
+        for (int k = 0; k < cpg; ++k) { t[2 * k] = f * m1; t[2 * k + 1] = f * m2; }
+    }
 }
 
 void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int B, int C, int HW, int G,
                       const float* sc, const float* sh, const float* mr, long pbs_c, long pbs_g, int kind,
-                      float* tst, long tst_bs, double* scratch, hipStream_t st) {
+                      float* tst, float* tc, long tst_bs, double* scratch, hipStream_t st) {
     int cpg = C / G;
     long len = (long)cpg * HW;
     int ns = gn_nsplit(len, B * G);
@@ -209,7 +217,7 @@ void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int 
                            pbs_c, pbs_g, scratch);
     long BG = (long)B * G;
     hipLaunchKernelGGL(gn_tstats_finalize, dim3((unsigned)((BG + 255) / 256)), dim3(256), 0, st, scratch, ns, BG,
-                       G, 1.0 / (double)len, tst, tst_bs);
+                       G, 1.0 / (double)len, tst, tc, tst_bs, cpg, mr, pbs_g, kind);
 }
 
 // ---------------------------------------------------------------------------
@@ -277,6 +285,38 @@ void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x
         default: GA(3); break;
     }
 #undef GA
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_cache_kernel(const float* x, int C, int HW, int cpg, const float* sc,
+                                                       const float* sh, const float* mr, float2* sx) {
+    const long per = (long)C * HW;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per; i += (long)gridDim.x * 1024) {
+        int c = (int)(i / HW);
+        int g = c / cpg;
+        float scc = sc[c], shc = sh[c], mean = mr[2 * g], rstd = mr[2 * g + 1];
+        float4 xv = *reinterpret_cast<const float4*>(x + i);
+        float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+        float4 o0, o1;
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[2 * j] = scc * dsilu(fmaf(scc, xx[j], shc));
+            r[2 * j + 1] = (xx[j] - mean) * rstd;
+        }
+        o0 = make_float4(r[0], r[1], r[2], r[3]);
+        o1 = make_float4(r[4], r[5], r[6], r[7]);
+        float4* o = reinterpret_cast<float4*>(sx + i);
+        o[0] = o0;
+        o[1] = o1;
+    }
+}
+void launch_gn_cache(const float* x, int C, int HW, int cpg, const float* sc, const float* sh, const float* mr,
+                     float2* sx, hipStream_t st) {
+    long per = (long)C * HW;
+    int blocks = (int)((per / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gn_cache_kernel, dim3(blocks), dim3(256), 0, st, x, C, HW, cpg, sc, sh, mr, sx);
 }
 
 // ---------------------------------------------------------------------------
@@ -484,6 +524,17 @@ void launch_cot_seed(const float* U, const uint8_t* mask, float cv, float ce, fl
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(cot_seed_kernel, dim3(blocks), dim3(256), 0, st, U, mask, cv, ce, gE, gX0, n, total);
+}
+
+__global__ void fill_random_kernel(float* p, long count, unsigned seed, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed;
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        p[i] = scale * ((float)(h & 0xFFFFFF) / 8388608.0f - 1.0f);
+    }
+}
+void launch_fill_random(float* p, long count, unsigned seed, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(fill_random_kernel, dim3(2048), dim3(256), 0, st, p, count, seed, scale);
 }
 
 __global__ void add_kernel(const float* a, const float* b, float* out, long count) {

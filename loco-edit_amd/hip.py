@@ -25,7 +25,8 @@ SYMBOLS = [
     "loco_pmp_primal", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop", "loco_debug_tensor",
-    "loco_profile_enable", "loco_profile_report",
+    "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision",
+    "loco_bench_conv",
 ]
 
 
@@ -82,6 +83,9 @@ def load_library():
     lib.loco_workspace_bytes.restype = i64
     lib.loco_timer_start.argtypes = [vp, vp]
     lib.loco_timer_stop.argtypes = [vp, vp, C.POINTER(f32)]
+    lib.loco_set_precision.argtypes = [vp, i32]
+    lib.loco_get_precision.argtypes = [vp]
+    lib.loco_bench_conv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32), vp]
     lib.loco_profile_enable.argtypes = [vp, i32]
     lib.loco_profile_report.argtypes = [vp, C.c_char_p, i64]
     lib.loco_debug_tensor.argtypes = [vp, C.c_char_p, vp, i64, vp]
@@ -279,6 +283,22 @@ class LocoEngine:
     def timer_stop(self) -> float:
         ms = C.c_float()
         self._check(self.lib.loco_timer_stop(self._ctx, _stream(), C.byref(ms)), "loco_timer_stop")
+        return float(ms.value)
+
+    PRECISIONS = {"f32": 0, "bf16x3": 1}
+
+    def set_precision(self, mode: str):
+        """'f32' = exact fp32 MFMA (parity anchor); 'bf16x3' = split-bf16 MFMA (fp32-faithful to ~2^-16)."""
+        self._check(self.lib.loco_set_precision(self._ctx, self.PRECISIONS[mode]), "loco_set_precision")
+
+    def get_precision(self) -> str:
+        m = self.lib.loco_get_precision(self._ctx)
+        return {v: k for k, v in self.PRECISIONS.items()}[m]
+
+    def bench_conv(self, cin, cout, H, W, B, mode, taps=9, tile=-1, iters=20) -> float:
+        ms = C.c_float()
+        self._check(self.lib.loco_bench_conv(self._ctx, cin, cout, H, W, B, mode, taps, tile, iters, C.byref(ms),
+                                             _stream()), "loco_bench_conv")
         return float(ms.value)
 
     def profile_enable(self, on: bool):
