@@ -40,6 +40,12 @@ typedef struct loco_unet_cfg {
     int32_t gn_groups;         /* 32  (diffusion.py:810) */
     float   gn_eps;            /* 1e-6 */
     int32_t max_batch;         /* largest image / probe batch one call may carry */
+    /* 0: Ho-DDPM U-Net (models/ddpm/diffusion.py); 1: guided-diffusion / P2 U-Net
+     * (models/guided_diffusion/unet.py:398-684 with P2_DICT, script_util.py:166-190:
+     * scale-shift norm, ResBlock up/down, legacy multi-head attention, [cos,sin] embedding) */
+    int32_t arch;
+    int32_t num_head_channels; /* arch 1: channels per attention head (P2: 64) */
+    int32_t learn_sigma;       /* arch 1: the head emits 2*out_ch channels, eps = first out_ch (unet.py:680-684) */
 } loco_unet_cfg;
 
 /* Library / device probes (no ctx). */

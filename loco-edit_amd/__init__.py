@@ -6,4 +6,4 @@ unconditional DDPM denoiser.  All numerics run in hand-written HIP kernels for
 gfx950 behind the C ABI declared in ``include/loco_hip.h``; this package is the
 Python host side mirroring the reference's ``src/modules/edit.py`` interface.
 """
-from .config import UNetConfig, CELEBA_DDPM, TINY_DDPM, MID_DDPM  # noqa: F401
+from .config import UNetConfig, CELEBA_DDPM, TINY_DDPM, MID_DDPM, FFHQ_P2, TINY_ADM  # noqa: F401

@@ -30,6 +30,11 @@ class UNetConfig:
     attn_resolutions: Tuple[int, ...] = (16,)
     gn_groups: int = 32
     gn_eps: float = 1e-6
+    # "ddpm": Ho et al. U-Net (models/ddpm/diffusion.py); "adm": guided-diffusion / P2 U-Net
+    # (models/guided_diffusion/unet.py with P2_DICT: scale-shift norm, resblock up/down, legacy multi-head attention)
+    arch: str = "ddpm"
+    num_head_channels: int = -1     # adm: channels per attention head (P2: 64)
+    learn_sigma: bool = False       # adm: network emits 2*out_ch channels, eps = the first out_ch (unet.py:680-684)
 
     @property
     def temb_ch(self) -> int:
@@ -47,11 +52,78 @@ TINY_DDPM = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=2
                        attn_resolutions=(16,))
 MID_DDPM = UNetConfig(resolution=64, ch=32, ch_mult=(1, 1, 2), num_res_blocks=1,
                       attn_resolutions=(16,))
+# config 2 of BASELINE.json: FFHQ-P2 (script_util.py:166-190 P2_DICT + create_model :379-435)
+FFHQ_P2 = UNetConfig(resolution=256, ch=128, ch_mult=(1, 1, 2, 2, 4, 4), num_res_blocks=1, attn_resolutions=(16,),
+                     gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=True)
+TINY_ADM = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,),
+                      gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True)
+
+
+def adm_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict layout of guided_diffusion ``UNetModel`` (unet.py:398-617) for the P2 flavour:
+    ``time_embed.{0,2}``, ``input_blocks.N.{0,1}``, ``middle_block.{0,1,2}``, ``output_blocks.N.{0,1,2}``, ``out.{0,2}``;
+    ResBlock = ``in_layers.{0,2}``, ``emb_layers.1``, ``out_layers.{0,3}``, ``skip_connection``;
+    AttentionBlock = ``norm``, ``qkv`` (Conv1d), ``proj_out`` (Conv1d)."""
+    shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    mc, ted = cfg.ch, cfg.ch * 4
+    out_channels = cfg.out_ch * (2 if cfg.learn_sigma else 1)
+
+    def res(name, cin, cout):
+        shapes[name + ".in_layers.0.weight"] = (cin,); shapes[name + ".in_layers.0.bias"] = (cin,)
+        shapes[name + ".in_layers.2.weight"] = (cout, cin, 3, 3); shapes[name + ".in_layers.2.bias"] = (cout,)
+        shapes[name + ".emb_layers.1.weight"] = (2 * cout, ted); shapes[name + ".emb_layers.1.bias"] = (2 * cout,)
+        shapes[name + ".out_layers.0.weight"] = (cout,); shapes[name + ".out_layers.0.bias"] = (cout,)
+        shapes[name + ".out_layers.3.weight"] = (cout, cout, 3, 3); shapes[name + ".out_layers.3.bias"] = (cout,)
+        if cin != cout:
+            shapes[name + ".skip_connection.weight"] = (cout, cin, 1, 1); shapes[name + ".skip_connection.bias"] = (cout,)
+
+    def attn(name, c):
+        shapes[name + ".norm.weight"] = (c,); shapes[name + ".norm.bias"] = (c,)
+        shapes[name + ".qkv.weight"] = (3 * c, c, 1); shapes[name + ".qkv.bias"] = (3 * c,)
+        shapes[name + ".proj_out.weight"] = (c, c, 1); shapes[name + ".proj_out.bias"] = (c,)
+
+    shapes["time_embed.0.weight"] = (ted, mc); shapes["time_embed.0.bias"] = (ted,)
+    shapes["time_embed.2.weight"] = (ted, ted); shapes["time_embed.2.bias"] = (ted,)
+    ch = mc * cfg.ch_mult[0]
+    shapes["input_blocks.0.0.weight"] = (ch, cfg.in_channels, 3, 3); shapes["input_blocks.0.0.bias"] = (ch,)
+    chans = [ch]
+    res_px = cfg.resolution
+    ib = 1
+    for lvl, mult in enumerate(cfg.ch_mult):
+        for _ in range(cfg.num_res_blocks):
+            res(f"input_blocks.{ib}.0", ch, mc * mult)
+            ch = mc * mult
+            if res_px in cfg.attn_resolutions:
+                attn(f"input_blocks.{ib}.1", ch)
+            chans.append(ch); ib += 1
+        if lvl != len(cfg.ch_mult) - 1:
+            res(f"input_blocks.{ib}.0", ch, ch)      # ResBlock(down=True)
+            chans.append(ch); ib += 1
+            res_px //= 2
+    res("middle_block.0", ch, ch); attn("middle_block.1", ch); res("middle_block.2", ch, ch)
+    ob = 0
+    for lvl, mult in list(enumerate(cfg.ch_mult))[::-1]:
+        for i in range(cfg.num_res_blocks + 1):
+            ich = chans.pop()
+            res(f"output_blocks.{ob}.0", ch + ich, mc * mult)
+            ch = mc * mult
+            j = 1
+            if res_px in cfg.attn_resolutions:
+                attn(f"output_blocks.{ob}.{j}", ch); j += 1
+            if lvl and i == cfg.num_res_blocks:
+                res(f"output_blocks.{ob}.{j}", ch, ch)   # ResBlock(up=True)
+                res_px *= 2
+            ob += 1
+    shapes["out.0.weight"] = (ch,); shapes["out.0.bias"] = (ch,)
+    shapes["out.2.weight"] = (out_channels, mc * cfg.ch_mult[0], 3, 3); shapes["out.2.bias"] = (out_channels,)
+    return shapes
 
 
 def param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     """Ordered name -> shape map following the constructor order of the
     reference module tree (``diffusion.py:41-126``)."""
+    if cfg.arch == "adm":
+        return adm_param_shapes(cfg)
     shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
 
     def lin(name, cin, cout):
@@ -134,7 +206,8 @@ def synth_params(cfg: UNetConfig, seed: int = 0) -> Dict[str, np.ndarray]:
         rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
         z = rng.standard_normal(shape).astype(np.float32)
         if name.endswith(".bias"):
-            if ".norm" in name or name.startswith("norm_out"):
+            if (".norm" in name or name.startswith("norm_out") or name.endswith("in_layers.0.bias")
+                    or name.endswith("out_layers.0.bias") or name == "out.0.bias"):
                 val = 0.1 * z
             else:
                 val = 0.05 * z

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(ConvArgs a) {
                 rstd = mrb[2 * g + 1];
                 m1 = tsb[2 * g];
                 m2 = tsb[2 * g + 1];
-                gm = a.gamma_ ? a.gamma_[c] : 0.f;
+                gm = sc / rstd;   // effective gain (includes the scale-shift factor of the ADM blocks)
             }
 #pragma unroll
             for (int i = 0; i < NPOS; ++i) {

@@ -80,11 +80,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     const int TW = a.Wout < 32 ? a.Wout : 32;
     const int TH = NT / TW;
     const int tiles_x = a.Wout / TW;
-    const int oy0 = (blockIdx.x / tiles_x) * TH;
-    const int ox0 = (blockIdx.x % tiles_x) * TW;
-    const int co0 = blockIdx.y * MT;
-    const int b = blockIdx.z / a.nsplit;
-    const int split = blockIdx.z % a.nsplit;
+    // Block order: the probes (and K-splits) of one (pixel tile, cout tile) are adjacent in dispatch order
+    // and land on the same XCD, so the shared primal {S, xhat} cache and the weights of the tile are
+    // served from that XCD's L2 instead of HBM once per probe (blocks L and L+8 share an XCD).
+    int tile_id, cot_id, zid;
+    {
+        const int ntile = (a.Hout * a.Wout) / NT, ncot = (a.Cout + MT - 1) / MT, Z = a.B * a.nsplit;
+        const int NTC = ntile * ncot, L = blockIdx.x;
+        int T;
+        if ((NTC & 7) == 0) { int q = L >> 3; zid = q % Z; T = (q / Z) * 8 + (L & 7); }
+        else { zid = L % Z; T = L / Z; }
+        tile_id = T % ntile; cot_id = T / ntile;
+    }
+    const int oy0 = (tile_id / tiles_x) * TH;
+    const int ox0 = (tile_id % tiles_x) * TW;
+    const int co0 = cot_id * MT;
+    const int b = zid / a.nsplit;
+    const int split = zid % a.nsplit;
 
     const int halo_w = (TW - 1) * S + KS;
     const int halo_h = (TH - 1) * S + KS;
@@ -367,7 +379,7 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     int TH = NT / TW;
     int halo_w = (TW - 1) * a.stride + KS, halo_h = (TH - 1) * a.stride + KS;
     size_t lds = (size_t)KS * MT * 64 + (size_t)halo_w * halo_h * 64;
-    dim3 grid((a.Hout * a.Wout) / NT, (a.Cout + MT - 1) / MT, a.B * a.nsplit);
+    dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -395,7 +407,7 @@ int conv_bf16_pick_tile(int Cout, int HW, int Bsplit) {
         if (g_bf16_tile_override >= 0) return g_bf16_tile_override;
         // 128 x 256 tile with 8 waves once it still fills the chip (>= 2 workgroups per CU)
         long blocks = (long)(HW / 256) * ((Cout + 127) / 128) * Bsplit;
-        if (blocks >= 512) return 5;
+        if (blocks >= 256) return 5;
     }
     return t;
 }

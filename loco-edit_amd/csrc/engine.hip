@@ -61,8 +61,14 @@ struct Op {
     int h1 = -1, a1 = -1;         // RES: conv1 output; cotangent scratch with the input's shape
     int hn = -1, qkv = -1, S = -1, o = -1;   // ATTN
     int up = -1;                  // UP: cotangent scratch at the upsampled size
+    int ap = -1, xu = -1;         // ADM up/down ResBlock: pooled activation (down), resampled shortcut input
+    int updown = 0;               // RES: 0 none, 1 down (avg-pool 2x2 on both branches), 2 up (nearest x2)
+    bool scale_shift = false;     // RES: GN(h)*(1+scale)+shift from the embedding (ADM); else conv1 += Linear(temb) (DDPM)
+    int heads = 1;                // ATTN
     bool in_is_skip = false;
     bool has_nin = false;
+    // parameter name stems in the reference state_dict
+    std::string pn_n1, pn_c1, pn_emb, pn_n2, pn_c2, pn_skip, pn_qkv, pn_proj, pn_conv;
     ConvP c1, c2, nin, qkvc, proj, conv;     // conv: CONV_IN / DOWN / UP / OUT
     NormP n1, n2;                 // RES norm1/norm2, ATTN norm (n1), OUT norm_out (n1)
     long tproj_off = 0;           // RES: offset into the concatenated temb projections
@@ -175,8 +181,11 @@ bool attn_at(const loco_unet_cfg& cfg, int res) {
     return false;
 }
 
+int build_program_adm(loco_ctx* c);
+
 // Build the op list + memory plan (mirrors DDPM.__init__/forward, reference diffusion.py:22-200)
 int build_program(loco_ctx* c) {
+    if (c->cfg.arch == 1) return build_program_adm(c);
     const loco_unet_cfg& cfg = c->cfg;
     const int ch = cfg.ch, nres = cfg.num_levels, R = cfg.resolution;
     c->n_in = cfg.in_channels * R * R;
@@ -327,6 +336,164 @@ int build_program(loco_ctx* c) {
             const Tens& ti = c->tens[op.in];
             norm_cache(c, op.n1, ti.H * ti.W);
             norm_cache(c, op.n2, ti.H * ti.W);
+            op.pn_n1 = op.name + ".norm1"; op.pn_c1 = op.name + ".conv1"; op.pn_emb = op.name + ".temb_proj";
+            op.pn_n2 = op.name + ".norm2"; op.pn_c2 = op.name + ".conv2"; op.pn_skip = op.name + ".nin_shortcut";
+        } else if (op.kind == OP_ATTN) {
+            op.pn_n1 = op.name + ".norm"; op.pn_proj = op.name + ".proj_out";
+        } else if (op.kind == OP_OUT) {
+            const Tens& ti = c->tens[op.in];
+            norm_cache(c, op.n1, ti.H * ti.W);
+            op.pn_n1 = "norm_out"; op.pn_conv = "conv_out";
+        } else {
+            op.pn_conv = op.name;
+        }
+    }
+    return 0;
+}
+
+
+// guided-diffusion / P2 U-Net (reference guided_diffusion/unet.py:398-684 with P2_DICT script_util.py:166-190):
+// input_blocks = conv, then per level {ResBlock [+Attention]} x num_res_blocks and a ResBlock(down) between levels;
+// middle = Res, Attn, Res; output_blocks = {ResBlock(cat) [+Attention] [+ResBlock(up)]}; out = GN, SiLU, conv.
+int build_program_adm(loco_ctx* c) {
+    const loco_unet_cfg& cfg = c->cfg;
+    const int mc = cfg.ch, nlev = cfg.num_levels, R = cfg.resolution;
+    c->n_in = cfg.in_channels * R * R;
+    auto heads_of = [&](int C) { return cfg.num_head_channels > 0 ? C / cfg.num_head_channels : 1; };
+    auto add_res = [&](const std::string& name, int in_t, int out_t, int updown, bool in_is_skip) {
+        Op r; r.kind = OP_RES; r.name = name; r.in = in_t; r.out = out_t; r.updown = updown;
+        r.scale_shift = true; r.in_is_skip = in_is_skip;
+        const Tens ti = c->tens[in_t];
+        const Tens to = c->tens[out_t];
+        r.has_nin = (ti.C != to.C);
+        r.h1 = new_tensor(c, to.C, to.H, to.W);
+        r.a1 = new_tensor(c, ti.C, ti.H, ti.W);
+        if (updown) { r.xu = new_tensor(c, ti.C, to.H, to.W); }
+        if (updown == 1) { r.ap = new_tensor(c, ti.C, to.H, to.W); }
+        r.n1 = new_norm(c, ti.C); r.n2 = new_norm(c, to.C);
+        r.pn_n1 = name + ".in_layers.0"; r.pn_c1 = name + ".in_layers.2"; r.pn_emb = name + ".emb_layers.1";
+        r.pn_n2 = name + ".out_layers.0"; r.pn_c2 = name + ".out_layers.3"; r.pn_skip = name + ".skip_connection";
+        c->ops.push_back(r);
+    };
+    auto add_attn = [&](const std::string& name, int in_t, int out_t) {
+        Op a; a.kind = OP_ATTN; a.name = name; a.in = in_t; a.out = out_t;
+        const Tens t = c->tens[in_t];
+        int T = t.H * t.W;
+        a.heads = heads_of(t.C);
+        a.hn = new_tensor(c, t.C, t.H, t.W);
+        a.qkv = new_tensor(c, 3 * t.C, t.H, t.W);
+        a.S = new_tensor(c, a.heads, T, T);
+        a.o = new_tensor(c, t.C, t.H, t.W);
+        a.n1 = new_norm(c, t.C);
+        a.pn_n1 = name + ".norm"; a.pn_qkv = name + ".qkv"; a.pn_proj = name + ".proj_out";
+        c->ops.push_back(a);
+    };
+    // pass 1: skip stack (channels, resolution) in push order
+    struct Skip { int C, H; };
+    std::vector<Skip> hs;
+    {
+        int ch = mc * cfg.ch_mult[0], res = R;
+        hs.push_back({ch, res});
+        for (int l = 0; l < nlev; ++l) {
+            for (int b = 0; b < cfg.num_res_blocks; ++b) { ch = mc * cfg.ch_mult[l]; hs.push_back({ch, res}); }
+            if (l != nlev - 1) { res /= 2; hs.push_back({ch, res}); }
+        }
+    }
+    const int nskip = (int)hs.size();
+    std::vector<int> cat_t(nskip), skip_t(nskip), hprev_t(nskip);
+    {
+        int res = hs.back().H, ch = hs.back().C, j = 0;
+        for (int l = nlev - 1; l >= 0; --l) {
+            for (int i = 0; i < cfg.num_res_blocks + 1; ++i) {
+                const Skip& sk = hs[nskip - 1 - j];
+                if (sk.H != res) { c->err = "internal: skip resolution mismatch (adm)"; return -1; }
+                int cat = new_tensor(c, ch + sk.C, res, res);
+                long base = c->tens[cat].off;
+                cat_t[j] = cat;
+                hprev_t[j] = new_tensor(c, ch, res, res, base);
+                skip_t[nskip - 1 - j] = new_tensor(c, sk.C, res, res, base + (long)ch * res * res);
+                ch = mc * cfg.ch_mult[l];
+                if (l && i == cfg.num_res_blocks) res *= 2;
+                ++j;
+            }
+        }
+    }
+    // pass 2: ops
+    int si = 0, res = R, ib = 1;
+    {
+        Op o; o.kind = OP_CONV_IN; o.name = "input_blocks.0.0"; o.out = skip_t[si++]; o.pn_conv = "input_blocks.0.0";
+        c->ops.push_back(o);
+    }
+    int cur = skip_t[0];
+    int ch = mc * cfg.ch_mult[0];
+    for (int l = 0; l < nlev; ++l) {
+        for (int b = 0; b < cfg.num_res_blocks; ++b) {
+            int cout = mc * cfg.ch_mult[l];
+            bool at = attn_at(cfg, res);
+            std::string nm = "input_blocks." + std::to_string(ib);
+            int out_t = at ? new_tensor(c, cout, res, res) : skip_t[si];
+            add_res(nm + ".0", cur, out_t, 0, true);
+            if (at) add_attn(nm + ".1", out_t, skip_t[si]);
+            cur = skip_t[si++]; ch = cout; ++ib;
+        }
+        if (l != nlev - 1) {
+            std::string nm = "input_blocks." + std::to_string(ib);
+            add_res(nm + ".0", cur, skip_t[si], 1, true);
+            cur = skip_t[si++]; ++ib; res /= 2;
+        }
+    }
+    {
+        int t0 = new_tensor(c, ch, res, res);
+        add_res("middle_block.0", cur, t0, 0, true);
+        int t1 = new_tensor(c, ch, res, res);
+        add_attn("middle_block.1", t0, t1);
+        add_res("middle_block.2", t1, hprev_t[0], 0, false);
+    }
+    {
+        int j = 0, ob = 0;
+        for (int l = nlev - 1; l >= 0; --l) {
+            for (int i = 0; i < cfg.num_res_blocks + 1; ++i) {
+                int cout = mc * cfg.ch_mult[l];
+                bool at = attn_at(cfg, res);
+                bool has_up = (l != 0 && i == cfg.num_res_blocks);
+                bool final_block = (l == 0 && i == cfg.num_res_blocks);
+                std::string nm = "output_blocks." + std::to_string(ob);
+                // destination of the block's last op
+                int dest = final_block ? new_tensor(c, cout, res, res) : -1;
+                int sub = 1;
+                int res_out = (at || has_up) ? new_tensor(c, cout, res, res) : (final_block ? dest : hprev_t[j + 1]);
+                add_res(nm + ".0", cat_t[j], res_out, 0, false);
+                int last = res_out;
+                if (at) {
+                    int a_out = has_up ? new_tensor(c, cout, res, res) : (final_block ? dest : hprev_t[j + 1]);
+                    add_attn(nm + "." + std::to_string(sub++), last, a_out);
+                    last = a_out;
+                }
+                if (has_up) {
+                    add_res(nm + "." + std::to_string(sub++), last, hprev_t[j + 1], 2, false);
+                    last = hprev_t[j + 1];
+                    res *= 2;
+                }
+                cur = last; ch = cout;
+                ++j; ++ob;
+            }
+        }
+    }
+    {
+        Op o; o.kind = OP_OUT; o.name = "out"; o.in = cur;
+        o.out = new_tensor(c, cfg.out_ch, R, R);
+        o.a1 = new_tensor(c, c->tens[cur].C, R, R);
+        o.n1 = new_norm(c, c->tens[cur].C);
+        o.pn_n1 = "out.0"; o.pn_conv = "out.2";
+        c->ops.push_back(o);
+        c->eps_t = o.out;
+    }
+    for (auto& op : c->ops) {
+        if (op.kind == OP_RES) {
+            const Tens& ti = c->tens[op.in];
+            const Tens& to = c->tens[op.out];
+            norm_cache(c, op.n1, ti.H * ti.W);
+            norm_cache(c, op.n2, to.H * to.W);
         } else if (op.kind == OP_OUT) {
             const Tens& ti = c->tens[op.in];
             norm_cache(c, op.n1, ti.H * ti.W);
@@ -355,36 +522,45 @@ void declare_lin(loco_ctx* c, const std::string& n, int cin, int cout) {
 
 void declare_all(loco_ctx* c) {
     const loco_unet_cfg& cfg = c->cfg;
+    const bool adm = cfg.arch == 1;
     int temb_ch = cfg.ch * 4;
-    declare_lin(c, "temb.dense.0", cfg.ch, temb_ch);
-    declare_lin(c, "temb.dense.1", temb_ch, temb_ch);
+    declare_lin(c, adm ? "time_embed.0" : "temb.dense.0", cfg.ch, temb_ch);
+    declare_lin(c, adm ? "time_embed.2" : "temb.dense.1", temb_ch, temb_ch);
     for (auto& op : c->ops) {
         switch (op.kind) {
-            case OP_CONV_IN: declare_conv(c, "conv_in", cfg.in_channels, cfg.ch, 3); break;
+            case OP_CONV_IN: declare_conv(c, op.pn_conv, cfg.in_channels, c->tens[op.out].C, 3); break;
             case OP_RES: {
                 int cin = c->tens[op.in].C, cout = c->tens[op.out].C;
-                declare_norm(c, op.name + ".norm1", cin);
-                declare_conv(c, op.name + ".conv1", cin, cout, 3);
-                declare_lin(c, op.name + ".temb_proj", temb_ch, cout);
-                declare_norm(c, op.name + ".norm2", cout);
-                declare_conv(c, op.name + ".conv2", cout, cout, 3);
-                if (op.has_nin) declare_conv(c, op.name + ".nin_shortcut", cin, cout, 1);
+                declare_norm(c, op.pn_n1, cin);
+                declare_conv(c, op.pn_c1, cin, cout, 3);
+                declare_lin(c, op.pn_emb, temb_ch, op.scale_shift ? 2 * cout : cout);
+                declare_norm(c, op.pn_n2, cout);
+                declare_conv(c, op.pn_c2, cout, cout, 3);
+                if (op.has_nin) declare_conv(c, op.pn_skip, cin, cout, 1);
                 break;
             }
             case OP_ATTN: {
                 int C = c->tens[op.in].C;
-                declare_norm(c, op.name + ".norm", C);
-                for (const char* p : {"q", "k", "v", "proj_out"}) declare_conv(c, op.name + "." + p, C, C, 1);
+                declare_norm(c, op.pn_n1, C);
+                if (adm) {   // Conv1d weights [3C, C, 1] / [C, C, 1] (unet.py:286,296)
+                    declare_param(c, op.pn_qkv + ".weight", {3 * C, C, 1});
+                    declare_param(c, op.pn_qkv + ".bias", {3 * C});
+                    declare_param(c, op.pn_proj + ".weight", {C, C, 1});
+                    declare_param(c, op.pn_proj + ".bias", {C});
+                } else {
+                    for (const char* p : {"q", "k", "v"}) declare_conv(c, op.name + "." + p, C, C, 1);
+                    declare_conv(c, op.pn_proj, C, C, 1);
+                }
                 break;
             }
             case OP_DOWN: case OP_UP: {
                 int C = c->tens[op.in].C;
-                declare_conv(c, op.name, C, C, 3);
+                declare_conv(c, op.pn_conv, C, C, 3);
                 break;
             }
             case OP_OUT:
-                declare_norm(c, "norm_out", c->tens[op.in].C);
-                declare_conv(c, "conv_out", c->tens[op.in].C, cfg.out_ch, 3);
+                declare_norm(c, op.pn_n1, c->tens[op.in].C);
+                declare_conv(c, op.pn_conv, c->tens[op.in].C, cfg.out_ch * (cfg.learn_sigma ? 2 : 1), 3);
                 break;
         }
     }
@@ -432,16 +608,19 @@ static std::vector<float> build_records(int nin, int nout, int taps, F get) {
 
 // weights [cout][cin][k][k] -> forward [cin][taps][coutP], dgrad [cout][taps][cinP] with flipped taps
 int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::vector<const HostParam*>& bs,
-              ConvP* out) {
-    int cin = (int)ws[0]->shape[1], k = (int)ws[0]->shape[2], taps = k * k;
+              ConvP* out, int row_limit = -1) {
+    int cin = (int)ws[0]->shape[1], k = (int)ws[0]->shape[2];
+    int taps = ws[0]->shape.size() == 3 ? k : k * k;      // Conv1d (k=1) or Conv2d
     int cout = 0;
     for (auto* w : ws) cout += (int)w->shape[0];
+    if (row_limit > 0 && ws.size() == 1 && row_limit < cout) cout = row_limit;   // eps half of a learn_sigma head
     int coutP = (cout + 31) & ~31, cinP = (cin + 31) & ~31;
     std::vector<float> wf((size_t)cin * taps * coutP, 0.f), wd((size_t)cout * taps * cinP, 0.f), bias(cout);
     int co0 = 0;
     for (size_t wi = 0; wi < ws.size(); ++wi) {
         const HostParam* w = ws[wi];
         int co_n = (int)w->shape[0];
+        if (co_n > cout - co0) co_n = cout - co0;
         for (int co = 0; co < co_n; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < taps; ++t) {
@@ -462,8 +641,8 @@ int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::v
     if (upload(c, &out->wbf, rf) || upload(c, &out->wbd, rd)) return -1;
     return 0;
 }
-int make_conv1(loco_ctx* c, const std::string& name, ConvP* out) {
-    return make_conv(c, {&c->params[name + ".weight"]}, {&c->params[name + ".bias"]}, out);
+int make_conv1(loco_ctx* c, const std::string& name, ConvP* out, int row_limit = -1) {
+    return make_conv(c, {&c->params[name + ".weight"]}, {&c->params[name + ".bias"]}, out, row_limit);
 }
 int make_norm(loco_ctx* c, const std::string& name, NormP* n) {
     if (upload(c, &n->gamma, c->params[name + ".weight"].data)) return -1;
@@ -477,17 +656,22 @@ int finalize_params(loco_ctx* c) {
         if (!c->params[n].loaded) { c->err = "parameter not loaded: " + n; return -1; }
     const loco_unet_cfg& cfg = c->cfg;
     int temb_ch = cfg.ch * 4;
-    if (upload(c, &c->td0w, c->params["temb.dense.0.weight"].data)) return -1;
-    if (upload(c, &c->td0b, c->params["temb.dense.0.bias"].data)) return -1;
-    if (upload(c, &c->td1w, c->params["temb.dense.1.weight"].data)) return -1;
-    if (upload(c, &c->td1b, c->params["temb.dense.1.bias"].data)) return -1;
-    // sinusoid frequencies exactly as torch: exp(float32(i) * float32(-ln(1e4)/(half-1)))  (diffusion.py:797-798)
+    const bool adm = cfg.arch == 1;
+    const std::string te0 = adm ? "time_embed.0" : "temb.dense.0", te1 = adm ? "time_embed.2" : "temb.dense.1";
+    if (upload(c, &c->td0w, c->params[te0 + ".weight"].data)) return -1;
+    if (upload(c, &c->td0b, c->params[te0 + ".bias"].data)) return -1;
+    if (upload(c, &c->td1w, c->params[te1 + ".weight"].data)) return -1;
+    if (upload(c, &c->td1b, c->params[te1 + ".bias"].data)) return -1;
+    // sinusoid frequencies exactly as torch computes them in fp32:
+    //   DDPM: exp(float32(i) * float32(-ln(1e4)/(half-1)))            (diffusion.py:797-798)
+    //   ADM : exp(float32(-ln(1e4)) * float32(i) / float32(half))     (guided_diffusion/nn.py:113-115)
     {
         int half = cfg.ch / 2;
         std::vector<float> f(half);
-        float e = (float)(-(std::log(10000.0) / (double)(half - 1)));
         for (int i = 0; i < half; ++i) {
-            float x = (float)i * e;
+            float x;
+            if (adm) x = ((float)(-std::log(10000.0)) * (float)i) / (float)half;
+            else x = (float)i * (float)(-(std::log(10000.0) / (double)(half - 1)));
             f[i] = (float)std::exp((double)x);
         }
         if (upload(c, &c->freq, f)) return -1;
@@ -495,30 +679,32 @@ int finalize_params(loco_ctx* c) {
     std::vector<float> tpw, tpb;
     for (auto& op : c->ops) {
         switch (op.kind) {
-            case OP_CONV_IN: if (make_conv1(c, "conv_in", &op.conv)) return -1; break;
+            case OP_CONV_IN: if (make_conv1(c, op.pn_conv, &op.conv)) return -1; break;
             case OP_RES: {
-                if (make_norm(c, op.name + ".norm1", &op.n1) || make_norm(c, op.name + ".norm2", &op.n2)) return -1;
-                if (make_conv1(c, op.name + ".conv1", &op.c1) || make_conv1(c, op.name + ".conv2", &op.c2)) return -1;
-                if (op.has_nin && make_conv1(c, op.name + ".nin_shortcut", &op.nin)) return -1;
+                if (make_norm(c, op.pn_n1, &op.n1) || make_norm(c, op.pn_n2, &op.n2)) return -1;
+                if (make_conv1(c, op.pn_c1, &op.c1) || make_conv1(c, op.pn_c2, &op.c2)) return -1;
+                if (op.has_nin && make_conv1(c, op.pn_skip, &op.nin)) return -1;
                 op.tproj_off = (long)tpb.size();
-                auto& w = c->params[op.name + ".temb_proj.weight"].data;
-                auto& b = c->params[op.name + ".temb_proj.bias"].data;
+                auto& w = c->params[op.pn_emb + ".weight"].data;
+                auto& b = c->params[op.pn_emb + ".bias"].data;
                 tpw.insert(tpw.end(), w.begin(), w.end());
                 tpb.insert(tpb.end(), b.begin(), b.end());
                 break;
             }
             case OP_ATTN: {
-                if (make_norm(c, op.name + ".norm", &op.n1)) return -1;
-                if (make_conv(c, {&c->params[op.name + ".q.weight"], &c->params[op.name + ".k.weight"],
-                                  &c->params[op.name + ".v.weight"]},
-                              {&c->params[op.name + ".q.bias"], &c->params[op.name + ".k.bias"],
-                               &c->params[op.name + ".v.bias"]}, &op.qkvc)) return -1;
-                if (make_conv1(c, op.name + ".proj_out", &op.proj)) return -1;
+                if (make_norm(c, op.pn_n1, &op.n1)) return -1;
+                if (adm) {
+                    if (make_conv1(c, op.pn_qkv, &op.qkvc)) return -1;
+                } else if (make_conv(c, {&c->params[op.name + ".q.weight"], &c->params[op.name + ".k.weight"],
+                                         &c->params[op.name + ".v.weight"]},
+                                     {&c->params[op.name + ".q.bias"], &c->params[op.name + ".k.bias"],
+                                      &c->params[op.name + ".v.bias"]}, &op.qkvc)) return -1;
+                if (make_conv1(c, op.pn_proj, &op.proj)) return -1;
                 break;
             }
-            case OP_DOWN: case OP_UP: if (make_conv1(c, op.name, &op.conv)) return -1; break;
+            case OP_DOWN: case OP_UP: if (make_conv1(c, op.pn_conv, &op.conv)) return -1; break;
             case OP_OUT:
-                if (make_norm(c, "norm_out", &op.n1) || make_conv1(c, "conv_out", &op.conv)) return -1;
+                if (make_norm(c, op.pn_n1, &op.n1) || make_conv1(c, op.pn_conv, &op.conv, cfg.out_ch)) return -1;
                 break;
         }
     }
@@ -613,7 +799,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
     const loco_unet_cfg& cfg = c->cfg;
     Pass p{c, st, B, arena, stats};
     const long SB = c->stats_per_sample;
-    launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st);
+    launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st, cfg.arch == 1);
     launch_temb_proj(c->tact, cfg.ch * 4, c->tp_w, c->tp_b, (int)c->tproj_total, c->tproj, st);
     for (auto& op : c->ops) {
         const Tens& to = c->tens[op.out];
@@ -629,20 +815,42 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
             }
             case OP_RES: {
                 const Tens& ti = c->tens[op.in];
-                gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HW);
+                const int HWi = ti.H * ti.W;
+                gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HWi);
                 NS s1 = nstats(c, stats, op.n1);
                 ConvArgs a; conv_defaults(a);
-                a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
-                setw(a, op.c1, false); a.bias = op.c1.bias; a.bias2 = c->tproj + op.tproj_off; a.bias2_bs = 0;
-                a.mode = CM_GN_SILU; a.sc = s1.sc; a.sh = s1.sh; a.scsh_bs = SB;
+                a.Cin = ti.C;
+                setw(a, op.c1, false); a.bias = op.c1.bias;
+                if (!op.scale_shift) { a.bias2 = c->tproj + op.tproj_off; a.bias2_bs = 0; }
+                if (op.updown == 1) {
+                    // h = conv(avg_pool(silu(gn(x)))), x' = avg_pool(x)      (unet.py:198-200, 239-244)
+                    launch_gn_apply(4, nullptr, 0, p.T(op.in), p.bs(), nullptr, 0, p.T(op.a1), p.bs(), 0, B, ti.C, HWi,
+                                    cfg.gn_groups, s1.sc, s1.sh, s1.mr, SB, SB, nullptr, 0, st);
+                    launch_pool2x2_sum(p.T(op.a1), p.bs(), p.T(op.ap), p.bs(), 0, B, ti.C, to.H, to.W, st, 0.25f);
+                    launch_pool2x2_sum(p.T(op.in), p.bs(), p.T(op.xu), p.bs(), 0, B, ti.C, to.H, to.W, st, 0.25f);
+                    a.in = p.T(op.ap); a.in_bs = p.bs(); a.Hin = to.H; a.Win = to.W;
+                } else {
+                    a.in = p.T(op.in); a.in_bs = p.bs(); a.Hin = ti.H; a.Win = ti.W;
+                    a.mode = CM_GN_SILU; a.sc = s1.sc; a.sh = s1.sh; a.scsh_bs = SB;
+                    if (op.updown == 2) {
+                        a.upsample = 1;
+                        launch_upsample2x(p.T(op.in), p.bs(), p.T(op.xu), p.bs(), 0, 1.0f, B, ti.C, ti.H, ti.W, st);
+                    }
+                }
                 a.out = p.T(op.h1); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
-                gn_forward_stats(p, op.n2, p.T(op.h1), p.bs(), HW);
+                {
+                    NS s2 = nstats(c, stats, op.n2);
+                    const float* ssc = op.scale_shift ? c->tproj + op.tproj_off : nullptr;
+                    launch_gn_stats(p.T(op.h1), p.bs(), B, op.n2.C, HW, cfg.gn_groups, cfg.gn_eps, op.n2.gamma,
+                                    op.n2.beta, s2.mr, s2.sc, s2.sh, SB, c->red, st, ssc, ssc ? ssc + to.C : nullptr);
+                }
                 NS s2 = nstats(c, stats, op.n2);
-                const float* res = p.T(op.in);
+                const float* xin = op.updown ? p.T(op.xu) : p.T(op.in);   // shortcut input after x_upd
+                const float* res = xin;
                 if (op.has_nin) {
                     ConvArgs n; conv_defaults(n);
-                    n.in = p.T(op.in); n.in_bs = p.bs(); n.Cin = ti.C; n.Hin = ti.H; n.Win = ti.W;
+                    n.in = xin; n.in_bs = p.bs(); n.Cin = ti.C; n.Hin = to.H; n.Win = to.W;
                     setw(n, op.nin, false); n.bias = op.nin.bias; n.pad = 0;
                     n.out = p.T(op.out); n.out_bs = p.bs(); n.Cout = to.C; n.Hout = to.H; n.Wout = to.W; n.B = B;
                     run_conv(c, n, 1, st);
@@ -657,7 +865,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 break;
             }
             case OP_ATTN: {
-                const int C = to.C, T = HW;
+                const int C = to.C, T = HW, NH = op.heads, CH = C / NH;
                 gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HW);
                 NS s = nstats(c, stats, op.n1);
                 ConvArgs a; conv_defaults(a);
@@ -666,20 +874,21 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 a.mode = CM_GN; a.sc = s.sc; a.sh = s.sh; a.scsh_bs = SB;
                 a.out = p.T(op.qkv); a.out_bs = p.bs(); a.Cout = 3 * C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 1, st);
-                float* q = p.T(op.qkv); float* k = q + (long)C * T; float* v = k + (long)C * T;
+                // per head h: q = qkv[h*3*CH ...], k = +CH, v = +2CH channels (QKVAttentionLegacy, unet.py:346;
+                // with one head this is the [q|k|v] stacking of the fused DDPM projection)
+                float* q = p.T(op.qkv); float* k = q + (long)CH * T; float* v = k + (long)CH * T;
                 GemmArgs g; std::memset(&g, 0, sizeof(g));
-                g.A = q; g.sam = 1; g.sak = T; g.sab = p.bs();
-                g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = p.bs();
-                g.C = p.T(op.S); g.scm = T; g.scn = 1; g.scb = p.bs();
-                g.M = T; g.N = T; g.K = C; g.batch = B; g.alpha = 1.0f / std::sqrt((float)C); g.beta = 0.f;
+                g.A = q; g.sam = 1; g.sak = T; g.sab = p.bs(); g.sah = 3L * CH * T;
+                g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = p.bs(); g.sbh = 3L * CH * T;
+                g.C = p.T(op.S); g.scm = T; g.scn = 1; g.scb = p.bs(); g.sch = (long)T * T;
+                g.M = T; g.N = T; g.K = CH; g.batch = B; g.batch2 = NH; g.alpha = 1.0f / std::sqrt((float)CH); g.beta = 0.f;
                 launch_gemm(g, st);
-                // softmax rows: per-sample S blocks are not contiguous across the batch
-                for (int b = 0; b < B; ++b) launch_softmax_rows(p.T(op.S) + (long)b * p.bs(), T, T, st);
+                for (int b = 0; b < B; ++b) launch_softmax_rows(p.T(op.S) + (long)b * p.bs(), (long)NH * T, T, st);
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
-                h.A = v; h.sam = T; h.sak = 1; h.sab = p.bs();
-                h.Bm = p.T(op.S); h.sbk = 1; h.sbn = T; h.sbb = p.bs();
-                h.C = p.T(op.o); h.scm = T; h.scn = 1; h.scb = p.bs();
-                h.M = C; h.N = T; h.K = T; h.batch = B; h.alpha = 1.f; h.beta = 0.f;
+                h.A = v; h.sam = T; h.sak = 1; h.sab = p.bs(); h.sah = 3L * CH * T;
+                h.Bm = p.T(op.S); h.sbk = 1; h.sbn = T; h.sbb = p.bs(); h.sbh = (long)T * T;
+                h.C = p.T(op.o); h.scm = T; h.scn = 1; h.scb = p.bs(); h.sch = (long)CH * T;
+                h.M = CH; h.N = T; h.K = T; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
                 launch_gemm(h, st);
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = p.T(op.o); pr.in_bs = p.bs(); pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
@@ -754,18 +963,35 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
             }
             case OP_RES: {
                 const Tens& ti = c->tens[op.in];
-                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
+                const int HWi = ti.H * ti.W;
+                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HWi, B, st);
                 ConvArgs a; conv_defaults(a);
-                a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
+                a.Cin = ti.C;
                 setw(a, op.c1, false);
-                set_tan(c, a, op.n1, TP(op.in));
+                if (op.updown == 1) {
+                    NS sp = nstats(c, c->statsP, op.n1);
+                    NS stt = nstats(c, c->statsT, op.n1);
+                    launch_gn_apply(5, TT(op.in), PS, TP(op.in), 0, nullptr, 0, TT(op.a1), PS, 0, B, ti.C, HWi,
+                                    cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                    launch_pool2x2_sum(TT(op.a1), PS, TT(op.ap), PS, 0, B, ti.C, to.H, to.W, st, 0.25f);
+                    launch_pool2x2_sum(TT(op.in), PS, TT(op.xu), PS, 0, B, ti.C, to.H, to.W, st, 0.25f);
+                    a.in = TT(op.ap); a.in_bs = PS; a.Hin = to.H; a.Win = to.W;
+                } else {
+                    a.in = TT(op.in); a.in_bs = PS; a.Hin = ti.H; a.Win = ti.W;
+                    set_tan(c, a, op.n1, TP(op.in));
+                    if (op.updown == 2) {
+                        a.upsample = 1;
+                        launch_upsample2x(TT(op.in), PS, TT(op.xu), PS, 0, 1.0f, B, ti.C, ti.H, ti.W, st);
+                    }
+                }
                 a.out = TT(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
                 tangent_stats(c, op.n2, TT(op.h1), PS, TP(op.h1), HW, B, st);
-                const float* res = TT(op.in);
+                const float* xin = op.updown ? TT(op.xu) : TT(op.in);
+                const float* res = xin;
                 if (op.has_nin) {
                     ConvArgs n; conv_defaults(n);
-                    n.in = TT(op.in); n.in_bs = PS; n.Cin = ti.C; n.Hin = ti.H; n.Win = ti.W;
+                    n.in = xin; n.in_bs = PS; n.Cin = ti.C; n.Hin = to.H; n.Win = to.W;
                     setw(n, op.nin, false); n.pad = 0;
                     n.out = TT(op.out); n.out_bs = PS; n.Cout = to.C; n.Hout = to.H; n.Wout = to.W; n.B = B;
                     run_conv(c, n, 1, st);
@@ -780,7 +1006,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 break;
             }
             case OP_ATTN: {
-                const int C = to.C, T = HW;
+                const int C = to.C, T = HW, NH = op.heads, CH = C / NH;
                 tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
@@ -791,23 +1017,25 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 setw(a, op.qkvc, false); a.pad = 0;
                 a.out = TT(op.qkv); a.out_bs = PS; a.Cout = 3 * C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 1, st);
-                float* q = TP(op.qkv); float* k = q + (long)C * T; float* v = k + (long)C * T;
-                float* dq = TT(op.qkv); float* dk = dq + (long)C * T; float* dv = dk + (long)C * T;
+                const long HS = 3L * CH * T, SS = (long)T * T;
+                float* q = TP(op.qkv); float* k = q + (long)CH * T; float* v = k + (long)CH * T;
+                float* dq = TT(op.qkv); float* dk = dq + (long)CH * T; float* dv = dk + (long)CH * T;
                 GemmArgs g; std::memset(&g, 0, sizeof(g));
-                g.A = dq; g.sam = 1; g.sak = T; g.sab = PS;
-                g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = 0;
-                g.C = TT(op.S); g.scm = T; g.scn = 1; g.scb = PS;
-                g.M = T; g.N = T; g.K = C; g.batch = B; g.alpha = 1.f; g.beta = 0.f;
+                g.A = dq; g.sam = 1; g.sak = T; g.sab = PS; g.sah = HS;
+                g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = HS;
+                g.C = TT(op.S); g.scm = T; g.scn = 1; g.scb = PS; g.sch = SS;
+                g.M = T; g.N = T; g.K = CH; g.batch = B; g.batch2 = NH; g.alpha = 1.f; g.beta = 0.f;
                 launch_gemm(g, st);
                 g.A = q; g.sab = 0; g.Bm = dk; g.sbb = PS; g.beta = 1.f;
                 launch_gemm(g, st);
                 for (int b = 0; b < B; ++b)
-                    launch_softmax_jac(TT(op.S) + (long)b * PS, TP(op.S), T, T, T, 1.0f / std::sqrt((float)C), st);
+                    launch_softmax_jac(TT(op.S) + (long)b * PS, TP(op.S), (long)NH * T, T, (long)NH * T,
+                                       1.0f / std::sqrt((float)CH), st);
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
-                h.A = dv; h.sam = T; h.sak = 1; h.sab = PS;
-                h.Bm = TP(op.S); h.sbk = 1; h.sbn = T; h.sbb = 0;
-                h.C = TT(op.o); h.scm = T; h.scn = 1; h.scb = PS;
-                h.M = C; h.N = T; h.K = T; h.batch = B; h.alpha = 1.f; h.beta = 0.f;
+                h.A = dv; h.sam = T; h.sak = 1; h.sab = PS; h.sah = HS;
+                h.Bm = TP(op.S); h.sbk = 1; h.sbn = T; h.sbb = 0; h.sbh = SS;
+                h.C = TT(op.o); h.scm = T; h.scn = 1; h.scb = PS; h.sch = (long)CH * T;
+                h.M = CH; h.N = T; h.K = T; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
                 launch_gemm(h, st);
                 h.A = v; h.sab = 0; h.Bm = TT(op.S); h.sbb = PS; h.beta = 1.f;
                 launch_gemm(h, st);
@@ -900,6 +1128,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
             }
             case OP_RES: {
                 const Tens& ti = c->tens[op.in];
+                const int HWi = ti.H * ti.W;
                 // g_a2 = dgrad conv2 (g_out)  -> slot h1
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
@@ -907,36 +1136,60 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 a.out = TG(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
                 cot_stats(c, op.n2, TG(op.h1), PS, TP(op.h1), HW, B, 1, st);
-                // g_a1 = dgrad conv1 ( norm2/silu cotangent of g_a2 )  -> slot a1
+                // dgrad conv1 of the norm2/silu cotangent of g_a2 (fused in the staging), at conv1's resolution
                 ConvArgs b; conv_defaults(b);
                 b.in = TG(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
                 setw(b, op.c1, true);
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.mode = CM_COT_SILU;
-                b.out = TG(op.a1); b.out_bs = PS; b.Cout = ti.C; b.Hout = ti.H; b.Wout = ti.W; b.B = B;
-                run_conv(c, b, 9, st);
-                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), HW, B, 1, st);
+                b.out_bs = PS; b.Cout = ti.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
+                if (op.updown == 0) {
+                    b.out = TG(op.a1);
+                    run_conv(c, b, 9, st);
+                } else if (op.updown == 1) {
+                    b.out = TG(op.ap);                                     // cotangent of the pooled activation
+                    run_conv(c, b, 9, st);
+                    launch_upsample2x(TG(op.ap), PS, TG(op.a1), PS, 0, 0.25f, B, ti.C, to.H, to.W, st);   // avg-pool^T
+                } else {
+                    b.out = TG(op.xu);                                     // cotangent of the nearest-upsampled activation
+                    run_conv(c, b, 9, st);
+                    launch_pool2x2_sum(TG(op.xu), PS, TG(op.a1), PS, 0, B, ti.C, ti.H, ti.W, st);           // nearest^T
+                }
+                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), HWi, B, 1, st);
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 int acc = op.in_is_skip ? 1 : 0;
+                // shortcut cotangent at the block's output resolution: identity or nin^T
+                const float* gsk = TG(op.out);
                 if (op.has_nin) {
                     ConvArgs n; conv_defaults(n);
                     n.in = TG(op.out); n.in_bs = PS; n.Cin = to.C; n.Hin = to.H; n.Win = to.W;
-                    setw(n, op.nin, true); n.pad = 0; n.accumulate = acc;
-                    n.out = TG(op.in); n.out_bs = PS; n.Cout = ti.C; n.Hout = ti.H; n.Wout = ti.W; n.B = B;
+                    setw(n, op.nin, true); n.pad = 0;
+                    n.Cout = ti.C; n.Hout = to.H; n.Wout = to.W; n.B = B; n.out_bs = PS;
+                    n.out = TG(op.in); n.accumulate = acc;      // (resampling blocks never change channels: no nin there)
                     run_conv(c, n, 1, st);
-                    launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 1, B, ti.C, HW, G,
-                                    sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                    gsk = nullptr;
+                }
+                if (op.updown == 0) {
+                    if (op.has_nin)
+                        launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 1, B, ti.C, HWi, G,
+                                        sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                    else
+                        launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, gsk, PS, TG(op.in), PS, acc, B, ti.C, HWi, G,
+                                        sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
                 } else {
-                    launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, TG(op.out), PS, TG(op.in), PS, acc, B, ti.C, HW,
-                                    G, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                    launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, acc, B, ti.C, HWi, G,
+                                    sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                    if (op.updown == 1) launch_upsample2x(gsk, PS, TG(op.in), PS, 1, 0.25f, B, ti.C, to.H, to.W, st);
+                    else launch_pool2x2_sum(gsk, PS, TG(op.in), PS, 1, B, ti.C, ti.H, ti.W, st);
                 }
                 break;
             }
             case OP_ATTN: {
-                const int C = to.C, T = HW;
-                float* q = TP(op.qkv); float* k = q + (long)C * T; float* v = k + (long)C * T;
-                float* gq = TG(op.qkv); float* gk = gq + (long)C * T; float* gv = gk + (long)C * T;
+                const int C = to.C, T = HW, NH = op.heads, CH = C / NH;
+                const long HS = 3L * CH * T, SS = (long)T * T, OS = (long)CH * T;
+                float* q = TP(op.qkv); float* k = q + (long)CH * T; float* v = k + (long)CH * T;
+                float* gq = TG(op.qkv); float* gk = gq + (long)CH * T; float* gv = gk + (long)CH * T;
                 // g_o = proj^T g_out
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = TG(op.out); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
@@ -945,26 +1198,27 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 run_conv(c, pr, 1, st);
                 // g_v[c][j] = sum_i g_o[c][i] P[i][j]
                 GemmArgs g; std::memset(&g, 0, sizeof(g));
-                g.A = TG(op.o); g.sam = T; g.sak = 1; g.sab = PS;
-                g.Bm = TP(op.S); g.sbk = T; g.sbn = 1; g.sbb = 0;
-                g.C = gv; g.scm = T; g.scn = 1; g.scb = PS;
-                g.M = C; g.N = T; g.K = T; g.batch = B; g.alpha = 1.f; g.beta = 0.f;
+                g.A = TG(op.o); g.sam = T; g.sak = 1; g.sab = PS; g.sah = OS;
+                g.Bm = TP(op.S); g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = SS;
+                g.C = gv; g.scm = T; g.scn = 1; g.scb = PS; g.sch = HS;
+                g.M = CH; g.N = T; g.K = T; g.batch = B; g.batch2 = NH; g.alpha = 1.f; g.beta = 0.f;
                 launch_gemm(g, st);
                 // g_P[i][j] = sum_c g_o[c][i] v[c][j]
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
-                h.A = TG(op.o); h.sam = 1; h.sak = T; h.sab = PS;
-                h.Bm = v; h.sbk = T; h.sbn = 1; h.sbb = 0;
-                h.C = TG(op.S); h.scm = T; h.scn = 1; h.scb = PS;
-                h.M = T; h.N = T; h.K = C; h.batch = B; h.alpha = 1.f; h.beta = 0.f;
+                h.A = TG(op.o); h.sam = 1; h.sak = T; h.sab = PS; h.sah = OS;
+                h.Bm = v; h.sbk = T; h.sbn = 1; h.sbb = 0; h.sbh = HS;
+                h.C = TG(op.S); h.scm = T; h.scn = 1; h.scb = PS; h.sch = SS;
+                h.M = T; h.N = T; h.K = CH; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
                 launch_gemm(h, st);
                 for (int b = 0; b < B; ++b)
-                    launch_softmax_jac(TG(op.S) + (long)b * PS, TP(op.S), T, T, T, 1.0f / std::sqrt((float)C), st);
+                    launch_softmax_jac(TG(op.S) + (long)b * PS, TP(op.S), (long)NH * T, T, (long)NH * T,
+                                       1.0f / std::sqrt((float)CH), st);
                 // g_q[c][i] = sum_j k[c][j] g_S[i][j]
                 GemmArgs gq_; std::memset(&gq_, 0, sizeof(gq_));
-                gq_.A = k; gq_.sam = T; gq_.sak = 1; gq_.sab = 0;
-                gq_.Bm = TG(op.S); gq_.sbk = 1; gq_.sbn = T; gq_.sbb = PS;
-                gq_.C = gq; gq_.scm = T; gq_.scn = 1; gq_.scb = PS;
-                gq_.M = C; gq_.N = T; gq_.K = T; gq_.batch = B; gq_.alpha = 1.f; gq_.beta = 0.f;
+                gq_.A = k; gq_.sam = T; gq_.sak = 1; gq_.sab = 0; gq_.sah = HS;
+                gq_.Bm = TG(op.S); gq_.sbk = 1; gq_.sbn = T; gq_.sbb = PS; gq_.sbh = SS;
+                gq_.C = gq; gq_.scm = T; gq_.scn = 1; gq_.scb = PS; gq_.sch = HS;
+                gq_.M = CH; gq_.N = T; gq_.K = T; gq_.batch = B; gq_.batch2 = NH; gq_.alpha = 1.f; gq_.beta = 0.f;
                 launch_gemm(gq_, st);
                 // g_k[c][j] = sum_i q[c][i] g_S[i][j]
                 GemmArgs gk_ = gq_;
@@ -1026,6 +1280,8 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         if (cfg->ch % 32) { c->err = "ch must be a multiple of 32"; return -2; }
     }
     if (build_program(c)) return -2;
+    for (auto& op : c->ops)
+        if (op.kind == OP_RES && op.updown && op.has_nin) { c->err = "resampling ResBlock with a channel change is not supported"; return -2; }
     declare_all(c);
     const size_t MB = (size_t)cfg->max_batch;
     if (dalloc(c, &c->arenaP, MB * c->per_sample) || dalloc(c, &c->arenaT, MB * c->per_sample)) return -1;
@@ -1159,8 +1415,9 @@ int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_
             launch_gn_cache(c->arenaP + ti.off, op.n1.C, HW, op.n1.C / G, s1.sc, s1.sh, s1.mr,
                             c->sxcache + op.n1.sx_off, st);
             if (op.kind == OP_RES) {
+                const Tens& th = c->tens[op.h1];
                 NS s2 = nstats(c, c->statsP, op.n2);
-                launch_gn_cache(c->arenaP + c->tens[op.h1].off, op.n2.C, HW, op.n2.C / G, s2.sc, s2.sh, s2.mr,
+                launch_gn_cache(c->arenaP + th.off, op.n2.C, th.H * th.W, op.n2.C / G, s2.sc, s2.sh, s2.mr,
                                 c->sxcache + op.n2.sx_off, st);
             }
         }

@@ -18,9 +18,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, khalf = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN, bz = blockIdx.z;
-    const float* A = g.A + (long)bz * g.sab;
-    const float* B = g.Bm + (long)bz * g.sbb;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int nb2 = g.batch2 > 0 ? g.batch2 : 1;
+    const int bz = blockIdx.z / nb2, hz = blockIdx.z % nb2;
+    const float* A = g.A + (long)bz * g.sab + (long)hz * g.sah;
+    const float* B = g.Bm + (long)bz * g.sbb + (long)hz * g.sbh;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -58,17 +60,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             if (m >= g.M) continue;
             long off = (long)m * g.scm + (long)n * g.scn;
             float v = g.alpha * acc[r];
-            float* c = g.C + (long)bz * g.scb + off;
+            float* c = g.C + (long)bz * g.scb + (long)hz * g.sch + off;
             if (g.beta != 0.f) v += g.beta * (*c);
             if (g.bias) v += g.bias[m];
-            if (g.R) v += g.R[(long)bz * g.srb + off];
+            if (g.R) v += g.R[(long)bz * g.srb + (long)hz * g.sch + off];
             *c = v;
         }
     }
 }
 
 void launch_gemm(const GemmArgs& g, hipStream_t st) {
-    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, g.batch);
+    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, g.batch * (g.batch2 > 0 ? g.batch2 : 1));
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
 }
 

@@ -73,6 +73,8 @@ struct GemmArgs {
     const float* R; long srb;    // residual with C's (m,n) strides, batch stride srb; or nullptr
     int M, N, K, batch;
     float alpha, beta;
+    // second-level batch (attention heads): blockIdx.z = b * batch2 + h, strides added per h
+    int batch2; long sah, sbh, sch;
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);
 
@@ -81,7 +83,8 @@ void launch_gemm(const GemmArgs& g, hipStream_t st);
 // writes mr[b][g] = {mean, rstd}, sc[b][c] = gamma*rstd, sh[b][c] = beta - mean*rstd*gamma
 void launch_gn_stats(const float* x, long bs, int B, int C, int HW, int G, float eps,
                      const float* gamma, const float* beta,
-                     float* mr, float* sc, float* sh, long stats_bs, double* scratch, hipStream_t st);
+                     float* mr, float* sc, float* sh, long stats_bs, double* scratch, hipStream_t st,
+                     const float* ss_scale = nullptr, const float* ss_shift = nullptr);
 // tangent / cotangent group statistics:
 //   kind 0 (tangent):            z = d
 //   kind 1 (cotangent, silu):    z = gamma * silu'(y) * d
@@ -95,6 +98,8 @@ void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int 
 //   kind 1: out = sc*(d - m1 - xh*m2)                          (attention norm tangent)
 //   kind 2: out (+)= base + rstd*(gamma*silu'(y)*d - m1 - xh*m2)  (resblock norm1 cotangent)
 //   kind 3: out (+)= base + rstd*(gamma*d - m1 - xh*m2)           (attention norm cotangent)
+//   kind 4: out = silu(sc*x + sh)                                  (activation ahead of an avg-pool, ADM down block)
+//   kind 5: out = silu'(y)*sc*(d - m1 - xh*m2)                     (its tangent)
 void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x_bs,
                      const float* base, long base_bs, float* out, long out_bs, int accumulate,
                      int B, int C, int HW, int G, const float* sc, const float* sh, const float* mr,
@@ -109,12 +114,14 @@ void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows
 // ---- small ops ---------------------------------------------------------------
 // temb pipeline: sinusoid(t) -> dense0 -> swish -> dense1 -> swish -> all per-block projections
 void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
-                 const float* w1, const float* b1, float* scratch, hipStream_t st);   // scratch: [temb_ch] swish(temb)
+                 const float* w1, const float* b1, float* scratch, hipStream_t st, int cos_first = 0);
 void launch_temb_proj(const float* tact, int temb_ch, const float* w, const float* b, int cout,
                       float* out, hipStream_t st);
 // out[b][c][y][x] = sum of the 2x2 block of in[b][c][2y..][2x..]   (adjoint of nearest x2)
 void launch_pool2x2_sum(const float* in, long in_bs, float* out, long out_bs, int accumulate,
-                        int B, int C, int Hout, int Wout, hipStream_t st);
+                        int B, int C, int Hout, int Wout, hipStream_t st, float scale = 1.0f);
+void launch_upsample2x(const float* in, long in_bs, float* out, long out_bs, int accumulate, float scale, int B,
+                       int C, int Hin, int Win, hipStream_t st);
 // strided copy / add of [B][C][HW] tensors
 void launch_copy(const float* in, long in_bs, float* out, long out_bs, int accumulate,
                  int B, long per_sample, hipStream_t st);

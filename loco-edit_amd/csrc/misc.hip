@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, long bs
 
 __global__ void gn_finalize_kernel(const double* scratch, int nsplit, int G, int C, float eps,
                                    const float* gamma, const float* beta, float* mr, float* sc, float* sh,
-                                   long sbs) {
+                                   long sbs, const float* ss_scale, const float* ss_shift) {
     const int b = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     const double* s = scratch + ((long)b * G + g) * nsplit * 3;
@@ -106,8 +106,14 @@ __global__ void gn_finalize_kernel(const double* scratch, int nsplit, int G, int
     const int cpg = C / G;
     for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
         float gm = gamma[c];
-        sc[(long)b * sbs + c] = gm * rstd;
-        sh[(long)b * sbs + c] = beta[c] - meanf * rstd * gm;
+        float a = gm * rstd, o = beta[c] - meanf * rstd * gm;
+        if (ss_scale) {   // scale-shift norm: GN(h)*(1+scale)+shift (guided_diffusion unet.py:250-254)
+            float f = 1.0f + ss_scale[c];
+            a *= f;
+            o = o * f + ss_shift[c];
+        }
+        sc[(long)b * sbs + c] = a;
+        sh[(long)b * sbs + c] = o;
     }
 }
 
@@ -121,12 +127,12 @@ static int gn_nsplit(long len, int BG) {
 
 void launch_gn_stats(const float* x, long bs, int B, int C, int HW, int G, float eps, const float* gamma,
                      const float* beta, float* mr, float* sc, float* sh, long stats_bs, double* scratch,
-                     hipStream_t st) {
+                     hipStream_t st, const float* ss_scale, const float* ss_shift) {
     long len = (long)(C / G) * HW;
     int ns = gn_nsplit(len, B * G);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(ns, G, B), dim3(256), 0, st, x, bs, len, scratch);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 63) / 64, B), dim3(64), 0, st, scratch, ns, G, C, eps,
-                       gamma, beta, mr, sc, sh, stats_bs);
+                       gamma, beta, mr, sc, sh, stats_bs, ss_scale, ss_shift);
 }
 
 // ---------------------------------------------------------------------------
@@ -239,6 +245,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* d, long d_bs
         if (KIND == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = fmaf(scc, xx[j], shc);
+        } else if (KIND == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float y = fmaf(scc, xx[j], shc); r[j] = y * sigm(y); }
         } else {
             float mean = mr[(long)b * pbs_g + 2 * g], rstd = mr[(long)b * pbs_g + 2 * g + 1];
             float m1 = tst[(long)b * tbs + g * 2], m2 = tst[(long)b * tbs + g * 2 + 1];
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* d, long d_bs
             for (int j = 0; j < 4; ++j) {
                 float xh = (xx[j] - mean) * rstd;
                 if (KIND == 1) r[j] = scc * (dd[j] - m1 - xh * m2);
+                else if (KIND == 5) r[j] = dsilu(fmaf(scc, xx[j], shc)) * scc * (dd[j] - m1 - xh * m2);
                 else if (KIND == 2) r[j] = bb[j] + rstd * (gm * dsilu(fmaf(scc, xx[j], shc)) * dd[j] - m1 - xh * m2);
                 else r[j] = bb[j] + rstd * (gm * dd[j] - m1 - xh * m2);
             }
@@ -282,6 +292,8 @@ void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x
         case 0: GA(0); break;
         case 1: GA(1); break;
         case 2: GA(2); break;
+        case 4: GA(4); break;
+        case 5: GA(5); break;
         default: GA(3); break;
     }
 #undef GA
@@ -377,15 +389,16 @@ void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows
 // time embedding: [sin, cos] sinusoid (divisor half-1) -> dense0 -> swish -> dense1 -> swish
 // (reference diffusion.py:783-804, 154-157, and the nonlinearity(temb) of :899)
 __global__ void temb_kernel(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
-                            const float* w1, const float* b1, float* out) {
+                            const float* w1, const float* b1, float* out, int cos_first) {
     extern __shared__ float sm[];
     float* emb = sm;           // [ch]
     float* h = sm + ch;        // [temb_ch]
     const int half = ch / 2;
     for (int i = threadIdx.x; i < half; i += blockDim.x) {
         float a = t * freq[i];   // freq table built on the host exactly as torch does (engine.hip)
-        emb[i] = sinf(a);
-        emb[half + i] = cosf(a);
+        // [sin, cos] (Ho-DDPM, diffusion.py:800) or [cos, sin] (guided_diffusion nn.py:118)
+        emb[cos_first ? half + i : i] = sinf(a);
+        emb[cos_first ? i : half + i] = cosf(a);
     }
     if ((ch & 1) && threadIdx.x == 0) emb[ch - 1] = 0.f;
     __syncthreads();
@@ -402,9 +415,9 @@ __global__ void temb_kernel(float t, int ch, int temb_ch, const float* freq, con
     }
 }
 void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0, const float* w1,
-                 const float* b1, float* scratch, hipStream_t st) {
+                 const float* b1, float* scratch, hipStream_t st, int cos_first) {
     hipLaunchKernelGGL(temb_kernel, dim3(1), dim3(512), (ch + temb_ch) * sizeof(float), st, t, ch, temb_ch, freq,
-                       w0, b0, w1, b1, scratch);
+                       w0, b0, w1, b1, scratch, cos_first);
 }
 // out[o] = b[o] + sum_i w[o][i]*tact[i]; one wave per output row
 __global__ __launch_bounds__(256) void temb_proj_kernel(const float* tact, int temb_ch, const float* w,
@@ -424,7 +437,7 @@ void launch_temb_proj(const float* tact, int temb_ch, const float* w, const floa
 
 // ---------------------------------------------------------------------------
 __global__ void pool2x2_kernel(const float* in, long in_bs, float* out, long out_bs, int accumulate, int C,
-                               int Ho, int Wo) {
+                               int Ho, int Wo, float scale) {
     const int b = blockIdx.y;
     const long per = (long)C * Ho * Wo;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
@@ -435,19 +448,45 @@ __global__ void pool2x2_kernel(const float* in, long in_bs, float* out, long out
         const float* p = in + (long)b * in_bs + (c * 2 * Ho + 2 * y) * (2 * Wo) + 2 * x;
         float2 a = *reinterpret_cast<const float2*>(p);
         float2 d = *reinterpret_cast<const float2*>(p + 2 * Wo);
-        float v = (a.x + a.y) + (d.x + d.y);
+        float v = ((a.x + a.y) + (d.x + d.y)) * scale;
         float* o = out + (long)b * out_bs + i;
         if (accumulate) v += *o;
         *o = v;
     }
 }
 void launch_pool2x2_sum(const float* in, long in_bs, float* out, long out_bs, int accumulate, int B, int C,
-                        int Hout, int Wout, hipStream_t st) {
+                        int Hout, int Wout, hipStream_t st, float scale) {
     long per = (long)C * Hout * Wout;
     int blocks = (int)((per + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pool2x2_kernel, dim3(blocks, B), dim3(256), 0, st, in, in_bs, out, out_bs, accumulate, C,
-                       Hout, Wout);
+                       Hout, Wout, scale);
+}
+
+// out[b][c][y][x] (+)= scale * in[b][c][y/2][x/2]   (nearest x2; adjoint of the 2x2 average with scale 0.25)
+__global__ void upsample2x_kernel(const float* in, long in_bs, float* out, long out_bs, int accumulate, int C,
+                                  int Hi, int Wi, float scale) {
+    const int b = blockIdx.y;
+    const int Wo = 2 * Wi, Ho = 2 * Hi;
+    const long per = (long)C * Ho * Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+        int x = (int)(i % Wo);
+        long r = i / Wo;
+        int y = (int)(r % Ho);
+        long c = r / Ho;
+        float v = scale * in[(long)b * in_bs + (c * Hi + (y >> 1)) * Wi + (x >> 1)];
+        float* o = out + (long)b * out_bs + i;
+        if (accumulate) v += *o;
+        *o = v;
+    }
+}
+void launch_upsample2x(const float* in, long in_bs, float* out, long out_bs, int accumulate, float scale, int B,
+                       int C, int Hin, int Win, hipStream_t st) {
+    long per = (long)C * Hin * Win * 4;
+    int blocks = (int)((per + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks, B), dim3(256), 0, st, in, in_bs, out, out_bs, accumulate, C,
+                       Hin, Win, scale);
 }
 
 __global__ void copy_kernel(const float* in, long in_bs, float* out, long out_bs, int accumulate, long per) {

@@ -36,6 +36,7 @@ class LocoCfg(C.Structure):
         ("num_levels", C.c_int32), ("ch_mult", C.c_int32 * 8), ("num_res_blocks", C.c_int32),
         ("num_attn_res", C.c_int32), ("attn_resolutions", C.c_int32 * 8), ("gn_groups", C.c_int32),
         ("gn_eps", C.c_float), ("max_batch", C.c_int32),
+        ("arch", C.c_int32), ("num_head_channels", C.c_int32), ("learn_sigma", C.c_int32),
     ]
 
 
@@ -132,6 +133,8 @@ class LocoEngine:
         for i, r in enumerate(cfg.attn_resolutions):
             c.attn_resolutions[i] = r
         c.gn_groups, c.gn_eps, c.max_batch = cfg.gn_groups, cfg.gn_eps, self.max_batch
+        c.arch = 1 if cfg.arch == "adm" else 0
+        c.num_head_channels, c.learn_sigma = cfg.num_head_channels, int(cfg.learn_sigma)
         self._ctx = C.c_void_p()
         rc = self.lib.loco_create(C.byref(c), C.byref(self._ctx))
         if rc != 0:

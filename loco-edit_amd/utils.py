@@ -15,7 +15,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .config import CELEBA_DDPM, UNetConfig, synth_params
+from .config import CELEBA_DDPM, FFHQ_P2, UNetConfig, synth_params
 from .hip import LocoEngine
 from .scheduler import YHCustomScheduler
 
@@ -25,6 +25,8 @@ MODEL_CONFIGS = {
     "CelebA_HQ": CELEBA_DDPM,        # SDEdit celeba_hq.ckpt (same module tree)
     "LSUN_church_HF": CELEBA_DDPM,   # google/ddpm-ema-church-256 (same architecture)
     "LSUN_bedroom_HF": CELEBA_DDPM,
+    # guided-diffusion / P2 checkpoints (utils.py:112-115 -> g_DDPM with P2_DICT)
+    "FFHQ_P2": FFHQ_P2, "AFHQ_P2": FFHQ_P2, "Flower_P2": FFHQ_P2, "Cub_P2": FFHQ_P2, "Metface_P2": FFHQ_P2,
 }
 
 
@@ -33,6 +35,7 @@ class HipUNet:
 
     def __init__(self, engine: LocoEngine):
         self.engine = engine
+        # the engine returns the eps half only (guided_diffusion unet.py:680-684), so the scheduler never sees logvar
         self.learn_sigma = False
 
     def __call__(self, x: torch.Tensor, t) -> torch.Tensor:

@@ -126,6 +126,112 @@ def unet_forward(p: Dict[str, torch.Tensor], cfg, x: torch.Tensor, t: torch.Tens
 
 
 # --------------------------------------------------------------------------
+# Denoiser B: guided-diffusion / P2 U-Net (reference src/models/guided_diffusion/unet.py, P2_DICT)
+# --------------------------------------------------------------------------
+def timestep_embedding_adm(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """[cos, sin] sinusoid with divisor half -- guided_diffusion/nn.py:103-121."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def _adm_gn(p, name, x, cfg):  # GroupNorm32(32, C), eps 1e-5, computed in fp32 -- nn.py:17-19
+    return F.group_norm(x.float(), cfg.gn_groups, p[name + ".weight"], p[name + ".bias"], cfg.gn_eps).type(x.dtype)
+
+
+def _adm_resblock(p, name, x, emb, cfg, up=False, down=False):
+    """ResBlock with use_scale_shift_norm=True -- unet.py:145-258."""
+    h = F.silu(_adm_gn(p, name + ".in_layers.0", x, cfg))
+    if up:      # Upsample(channels, False): nearest x2 on both branches -- :195-197, 239-244
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    elif down:  # Downsample(channels, False): avg_pool2d(2) on both branches -- :198-200
+        h = F.avg_pool2d(h, 2, 2)
+        x = F.avg_pool2d(x, 2, 2)
+    h = F.conv2d(h, p[name + ".in_layers.2.weight"], p[name + ".in_layers.2.bias"], padding=1)
+    emb_out = F.linear(F.silu(emb), p[name + ".emb_layers.1.weight"], p[name + ".emb_layers.1.bias"])[:, :, None, None]
+    scale, shift = torch.chunk(emb_out, 2, dim=1)
+    h = _adm_gn(p, name + ".out_layers.0", h, cfg) * (1 + scale) + shift     # :250-254
+    h = F.conv2d(F.silu(h), p[name + ".out_layers.3.weight"], p[name + ".out_layers.3.bias"], padding=1)
+    if (name + ".skip_connection.weight") in p:
+        x = F.conv2d(x, p[name + ".skip_connection.weight"], p[name + ".skip_connection.bias"])
+    return x + h
+
+
+def _adm_attn(p, name, x, cfg):
+    """AttentionBlock + QKVAttentionLegacy -- unet.py:261-307, 330-356."""
+    b, c, hh, ww = x.shape
+    xr = x.reshape(b, c, -1)
+    qkv = F.conv1d(_adm_gn(p, name + ".norm", xr, cfg), p[name + ".qkv.weight"], p[name + ".qkv.bias"])
+    n_heads = c // cfg.num_head_channels
+    ch = c
+    ch = (3 * c) // (3 * n_heads)
+    q, k, v = qkv.reshape(b * n_heads, ch * 3, hh * ww).split(ch, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+    w = torch.softmax(w.float(), dim=-1).type(w.dtype)
+    a = torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, hh * ww)
+    h = F.conv1d(a, p[name + ".proj_out.weight"], p[name + ".proj_out.bias"])
+    return (xr + h).reshape(b, c, hh, ww)
+
+
+def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None):
+    """UNetModel.forward returning the eps half -- unet.py:636-684, constructor :398-617."""
+    def rec(name, v):
+        if trace is not None:
+            trace[name] = v.detach().clone()
+        return v
+    t = t.reshape(1) if t.dim() == 0 else t
+    emb = timestep_embedding_adm(t.to(torch.float32), cfg.ch)
+    emb = F.linear(emb, p["time_embed.0.weight"], p["time_embed.0.bias"])
+    emb = F.linear(F.silu(emb), p["time_embed.2.weight"], p["time_embed.2.bias"])
+    hs = []
+    h = rec("input_blocks.0.0", F.conv2d(x, p["input_blocks.0.0.weight"], p["input_blocks.0.0.bias"], padding=1))
+    hs.append(h)
+    res_px = cfg.resolution
+    ib = 1
+    nlev = len(cfg.ch_mult)
+    for lvl in range(nlev):
+        for _ in range(cfg.num_res_blocks):
+            h = rec(f"input_blocks.{ib}.0", _adm_resblock(p, f"input_blocks.{ib}.0", h, emb, cfg))
+            if res_px in cfg.attn_resolutions:
+                h = rec(f"input_blocks.{ib}.1", _adm_attn(p, f"input_blocks.{ib}.1", h, cfg))
+            hs.append(h); ib += 1
+        if lvl != nlev - 1:
+            h = rec(f"input_blocks.{ib}.0", _adm_resblock(p, f"input_blocks.{ib}.0", h, emb, cfg, down=True))
+            hs.append(h); ib += 1
+            res_px //= 2
+    h = rec("middle_block.0", _adm_resblock(p, "middle_block.0", h, emb, cfg))
+    h = rec("middle_block.1", _adm_attn(p, "middle_block.1", h, cfg))
+    h = rec("middle_block.2", _adm_resblock(p, "middle_block.2", h, emb, cfg))
+    ob = 0
+    for lvl in reversed(range(nlev)):
+        for i in range(cfg.num_res_blocks + 1):
+            h = torch.cat([h, hs.pop()], dim=1)
+            h = rec(f"output_blocks.{ob}.0", _adm_resblock(p, f"output_blocks.{ob}.0", h, emb, cfg))
+            j = 1
+            if res_px in cfg.attn_resolutions:
+                h = rec(f"output_blocks.{ob}.{j}", _adm_attn(p, f"output_blocks.{ob}.{j}", h, cfg)); j += 1
+            if lvl and i == cfg.num_res_blocks:
+                h = rec(f"output_blocks.{ob}.{j}", _adm_resblock(p, f"output_blocks.{ob}.{j}", h, emb, cfg, up=True))
+                res_px *= 2
+            ob += 1
+    h = F.silu(_adm_gn(p, "out.0", h, cfg))
+    h = F.conv2d(h, p["out.2.weight"], p["out.2.bias"], padding=1)
+    if cfg.learn_sigma:
+        h = torch.split(h, h.shape[1] // 2, dim=1)[0]      # et only (unet.py:680-684)
+    return h
+
+
+def denoiser(p, cfg, x, t, trace=None):
+    return unet_forward_adm(p, cfg, x, t, trace) if getattr(cfg, "arch", "ddpm") == "adm" else unet_forward(p, cfg, x, t, trace)
+
+
+# --------------------------------------------------------------------------
 # Scheduler (reference src/utils/utils.py:305-461)
 # --------------------------------------------------------------------------
 class Scheduler:
@@ -196,7 +302,7 @@ class OracleEdit:
             if performance_boosting_t > 0 else 1000)  # edit.py:2073
 
     def unet(self, x, t):
-        return unet_forward(self.p, self.cfg, x, t)
+        return denoiser(self.p, self.cfg, x, t)
 
     # -- edit.py:2369-2391
     def get_x0(self, t, x, mask=None):

@@ -72,6 +72,21 @@ def ref_model(PullBackDDPM, cfg, params):
     return m
 
 
+def ref_model_adm(cfg, params):
+    """guided_diffusion UNetModel with the P2 switches (script_util.py:166-190, 379-435)."""
+    from models.guided_diffusion.unet import UNetModel
+    ds = tuple(cfg.resolution // r for r in cfg.attn_resolutions)
+    m = UNetModel(image_size=cfg.resolution, in_channels=3, model_channels=cfg.ch,
+                  out_channels=6 if cfg.learn_sigma else 3, num_res_blocks=cfg.num_res_blocks,
+                  attention_resolutions=ds, dropout=0, channel_mult=tuple(cfg.ch_mult),
+                  num_head_channels=cfg.num_head_channels, use_scale_shift_norm=True, resblock_updown=True)
+    m.device = torch.device("cpu")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+    m.eval()
+    m.requires_grad_(False)
+    return m
+
+
 def ref_edit(redit, YHCustomScheduler, model, tmpdir):
     """Build EditUncondDiffusion without its HF/SAM/dataset constructor work."""
     ed = object.__new__(redit.EditUncondDiffusion)
@@ -122,11 +137,13 @@ def gen_for_config(tag, cfg, redit, YHS, PullBackDDPM, k, k_null, n_iter, mrect,
     from loco_edit_amd.config import synth_params
     torch.manual_seed(0)
     params = synth_params(cfg, seed=0)
-    model = ref_model(PullBackDDPM, cfg, params)
+    model = ref_model_adm(cfg, params) if cfg.arch == "adm" else ref_model(PullBackDDPM, cfg, params)
     ed = ref_edit(redit, YHS, model, tmpdir)
     oed = orc.OracleEdit(orc.to_torch(params), cfg)
     out = {"cfg": dict(resolution=cfg.resolution, ch=cfg.ch, ch_mult=tuple(cfg.ch_mult),
-                       num_res_blocks=cfg.num_res_blocks, attn_resolutions=tuple(cfg.attn_resolutions)),
+                       num_res_blocks=cfg.num_res_blocks, attn_resolutions=tuple(cfg.attn_resolutions),
+                       arch=cfg.arch, num_head_channels=cfg.num_head_channels, learn_sigma=cfg.learn_sigma,
+                       gn_eps=cfg.gn_eps),
            "weights_seed": 0}
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, cfg.in_channels, cfg.resolution, cfg.resolution, generator=g)
@@ -310,7 +327,7 @@ def main():
     import tempfile
     tmpdir = tempfile.mkdtemp(prefix="loco_golden_")
     redit, YHS, extract, PullBackDDPM = import_reference()
-    from loco_edit_amd.config import TINY_DDPM, MID_DDPM, CELEBA_DDPM
+    from loco_edit_amd.config import TINY_DDPM, MID_DDPM, CELEBA_DDPM, TINY_ADM, FFHQ_P2
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     if not a.only or a.only == "sched":
@@ -326,6 +343,17 @@ def main():
         o = gen_for_config("mid", MID_DDPM, redit, YHS, PullBackDDPM, k=3, k_null=0, n_iter=3,
                            mrect=(20, 36, 10, 40), tmpdir=tmpdir, pipeline=False)
         torch.save(o, os.path.join(GOLD, "mid.pt"))
+    if not a.only or a.only == "tiny_adm":
+        print("tiny ADM/P2 config (32x32, ch 32, 4 heads)")
+        o = gen_for_config("tiny_adm", TINY_ADM, redit, YHS, PullBackDDPM, k=4, k_null=0, n_iter=12,
+                           mrect=(12, 20, 8, 18), tmpdir=tmpdir, pipeline=False)
+        torch.save(o, os.path.join(GOLD, "tiny_adm.pt"))
+    if a.only == "p2_256":
+        print("full FFHQ-P2 config (256x256)")
+        o = gen_for_config("p2_256", FFHQ_P2, redit, YHS, PullBackDDPM, k=4, k_null=0, n_iter=0,
+                           mrect=(110, 130, 70, 110), tmpdir=tmpdir, full_tensors=False, pipeline=False)
+        o = {k: v for k, v in o.items() if v is not None}
+        torch.save(o, os.path.join(GOLD, "p2_256.pt"))
     if a.full:
         print("full config (256x256 CelebA-HQ DDPM arch)")
         o = gen_for_config("celeba256", CELEBA_DDPM, redit, YHS, PullBackDDPM, k=5, k_null=0,

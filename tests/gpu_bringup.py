@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 import loco_oracle as orc  # noqa: E402
-from loco_edit_amd.config import TINY_DDPM, MID_DDPM, CELEBA_DDPM, synth_params  # noqa: E402
+from loco_edit_amd.config import TINY_DDPM, MID_DDPM, CELEBA_DDPM, TINY_ADM, FFHQ_P2, synth_params  # noqa: E402
 from loco_edit_amd.hip import LocoEngine  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -27,7 +27,8 @@ def rel(a, b):
 
 
 def run(tag, cfg, max_batch=8, layerwise=True):
-    print(f"==== {tag}: res {cfg.resolution} ch {cfg.ch} mult {cfg.ch_mult}", flush=True)
+    print(f"==== {tag}: arch {cfg.arch} res {cfg.resolution} ch {cfg.ch} mult {cfg.ch_mult} "
+          f"precision {os.environ.get('LOCO_PRECISION', 'bf16x3')}", flush=True)
     params = synth_params(cfg, seed=0)
     eng = LocoEngine(cfg, max_batch=max_batch)
     eng.load_state_dict(params)
@@ -52,7 +53,7 @@ def run(tag, cfg, max_batch=8, layerwise=True):
         p = orc.to_torch(params)
         tr = {}
         with torch.no_grad():
-            eo = orc.unet_forward(p, cfg, x, t, trace=tr)
+            eo = orc.denoiser(p, cfg, x, t, trace=tr)
         print("   forward vs oracle eps: rel %.3e max %.3e" % rel(eps, eo))
         for name, ref in tr.items():
             got = eng.debug_tensor(name, ref.numel()).reshape(ref.shape)
@@ -131,6 +132,10 @@ if __name__ == "__main__":
             run("tiny", TINY_DDPM)
         elif w == "mid":
             run("mid", MID_DDPM)
+        elif w == "tiny_adm":
+            run("tiny_adm", TINY_ADM)
+        elif w == "p2":
+            run("p2_256", FFHQ_P2, max_batch=8, layerwise=("--layers" in sys.argv))
         elif w == "full":
             run("celeba256", CELEBA_DDPM, max_batch=8, layerwise=("--layers" in sys.argv))
         torch.cuda.synchronize()

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import loco_oracle as orc
-from loco_edit_amd.config import CELEBA_DDPM, MID_DDPM, TINY_DDPM, UNetConfig, synth_params
+from loco_edit_amd.config import CELEBA_DDPM, FFHQ_P2, MID_DDPM, TINY_ADM, TINY_DDPM, UNetConfig, synth_params
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -56,7 +56,7 @@ def _sched():
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("tag,cfg", [("tiny", TINY_DDPM), ("mid", MID_DDPM)])
+@pytest.mark.parametrize("tag,cfg", [("tiny", TINY_DDPM), ("mid", MID_DDPM), ("tiny_adm", TINY_ADM)])
 def test_forward_jvp_vjp_vs_golden(tag, cfg, prec, engines, golden):
     g = golden(tag)
     eng = engines(cfg, prec)
@@ -151,6 +151,51 @@ def test_full_size_forward_vs_golden_samples(prec, engines, golden):
         assert torch.allclose(s.cpu(), g["s_modify"], rtol=1e-3)
         cos = (vT.cpu() * g["vT_modify_f16"].float()).sum(dim=1).abs()
         assert cos.min().item() > 0.999
+
+
+def test_p2_full_size_vs_reference_golden(engines, golden):
+    """Denoiser B (FFHQ-P2 / guided-diffusion U-Net, BASELINE.json config 2) at 256x256 against the
+    reference's own UNetModel outputs (sampled eps, J V on the mask, projections of U^T J)."""
+    g = golden("p2_256")
+    eng = engines(FFHQ_P2, "bf16x3")
+    tol = TOL["bf16x3"]
+    eps = eng.unet_forward(g["x"].to(DEV), float(g["t"]))
+    assert rel(eps.reshape(-1)[g["eps_sample_idx"].to(DEV)], g["eps_sample"]) < tol
+    assert abs(eps.double().sum().item() - g["eps_sum"]) < 1e-3 * math.sqrt(g["eps_sqsum"])
+    at = float(_sched().alpha_at(g["t"]))
+    eng.pmp_primal(g["x"].to(DEV), float(g["t"]), at, g["mask"].to(DEV))
+    k = g["JV"].shape[0]
+    v0 = torch.randn(FFHQ_P2.n, k, generator=torch.Generator().manual_seed(g["v0_seed"]))
+    V = torch.linalg.qr(v0)[0].T.contiguous()
+    U = eng.pmp_jvp(V.to(DEV))
+    assert rel(eng.mask_gather(U), g["JV"]) < 2.5 * tol
+    Uin = torch.zeros(k, FFHQ_P2.n)
+    Uin[:, g["mask"].reshape(-1)] = g["JV"]
+    A = eng.pmp_vjp(Uin.to(DEV)).cpu()
+    P = torch.randn(FFHQ_P2.n, 64, generator=torch.Generator().manual_seed(g["UtJ_proj_seed"]))
+    assert rel(A @ P, g["UtJ_proj"]) < 2.5 * tol
+
+
+def test_adm_solver_and_many_probes(engines, golden):
+    """tiny P2-style model: 12-iteration solver vs the reference golden, then the config-2 idiom
+    'rank-r basis from k >> r probes' (pca_rank=k, keep vT[:r]; edit.py:2320 slicing)."""
+    from loco_edit_amd import solver
+    g = golden("tiny_adm")
+    eng = engines(TINY_ADM, "bf16x3")
+    at = float(_sched().alpha_at(g["t"]))
+    x = g["x"].to(DEV)
+    u, s, vT, n_it = solver.local_basis(eng, x, float(g["t"]), at, 4, mask=g["mask"].to(DEV), min_iter=g["n_iter"],
+                                        max_iter=g["n_iter"], v0=g["v0"].to(DEV), verbose=False)
+    assert torch.allclose(s.cpu(), g["s_modify"], rtol=1e-3)
+    assert (vT.cpu() * g["vT_modify"]).sum(dim=1).abs().min().item() > 0.999
+    # 16 probes (two chunks of max_batch=8), keep the top 4: the leading subspace agrees with the 4-probe run
+    v0 = torch.randn(TINY_ADM.n, 16, generator=torch.Generator().manual_seed(9)).to(DEV)
+    u2, s2, vT2, _ = solver.local_basis(eng, x, float(g["t"]), at, 16, mask=g["mask"].to(DEV), min_iter=12,
+                                        max_iter=12, v0=v0, verbose=False)
+    assert vT2.shape == (16, TINY_ADM.n) and bool((s2[:-1] >= s2[1:] - 1e-4).all())
+    assert torch.allclose(s2[:2].cpu(), g["s_modify"][:2], rtol=2e-2)
+    overlap = torch.linalg.svdvals(vT2[:4].cpu() @ g["vT_modify"][:2].T)
+    assert overlap.min().item() > 0.98
 
 
 @pytest.mark.parametrize("prec", PRECS)
