@@ -223,12 +223,23 @@ class EditUncondDiffusion(object):
                 return None, None
             mask = masks[self.args.mask_index].squeeze(dim=0).repeat(3, 1, 1)
             return xT, mask
-        xT = self.run_DDIMinversion(idx=idx)
         if self.dataset_name in ("CelebA_HQ_mask", "Synthetic"):
+            xT = self.run_DDIMinversion(idx=idx)
             mask = self.dataset.getmask(idx=self.args.sample_idx, choose_sem=self.args.choose_sem)
-        else:
-            mask = None
-        return xT, (mask if use_mask or self.dataset_name == "CelebA_HQ_mask" else None)
+            return xT, (mask if use_mask or self.dataset_name == "CelebA_HQ_mask" else None)
+        # FFHQ / AFHQ / ... : SAM masks cached as mask/mask.pt, bool [N,res,res] (edit.py:2252-2267)
+        mpath = os.path.join(self.result_folder, "mask/mask.pt")
+        if not os.path.exists(mpath):
+            raise FileNotFoundError(
+                f"{mpath} missing: SAM mask generation is outside the hot path (SURVEY.md 2.1 #9); "
+                "provide mask.pt (bool [N,res,res]) as the reference's mask_segmentation.py writes it")
+        print("Loading masks......")
+        masks = torch.load(mpath)
+        if self.args.sampling_mode:
+            return None, None
+        xT = self.run_DDIMinversion(idx=idx)
+        mask = masks[self.args.mask_index].squeeze(dim=0).repeat(3, 1, 1) if use_mask else None
+        return xT, mask
 
     @torch.no_grad()
     def run_edit_null_space_projection(self, idx, vis_num, vis_num_pc=5, pca_rank=50, pca_rank_null=10, op='mid',

@@ -149,12 +149,40 @@ class CelebAMaskDataset:
         return torch.tensor(m.astype(bool)).permute(2, 0, 1)
 
 
+class FolderDataset:
+    """Image folder datasets (reference ``ImgDataset`` / ``AFHQDataset``, utils.py:588-672):
+    files sorted by their integer stem (``numeric=True``, FFHQ) or lexicographically (AFHQ);
+    centre-crop to a square, PIL default resize to ``res``, ToTensor, Normalize(0.5, 0.5) -> [1,3,res,res]."""
+
+    def __init__(self, root, res=256, numeric=True):
+        self.root, self.res = root, res
+        names = [n for n in os.listdir(root) if "." in n and n.split(".")[1] in ("jpg", "jpeg", "png")]
+        self.paths = sorted(names, key=(lambda n: int(n.split(".")[0])) if numeric else (lambda n: n.split(".")[0]))
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+        x = Image.open(os.path.join(self.root, self.paths[idx]))
+        w, h = x.size
+        c = min(w, h)
+        x = x.crop(((w - c) / 2, (h - c) / 2, (w + c) / 2, (h + c) / 2)).resize((self.res, self.res))
+        a = np.asarray(x.convert("RGB"), dtype=np.float32) / 255.0
+        return ((torch.from_numpy(a).permute(2, 0, 1) - 0.5) / 0.5).unsqueeze(0)
+
+
 def get_dataset(args):
     """reference utils.py:472-560 (the datasets the unconditional path uses)."""
     if args.dataset_name == "CelebA_HQ_mask":
         return CelebAMaskDataset(args.dataset_root, res=args.image_size)
+    if args.dataset_name in ("FFHQ", "CelebA_HQ"):
+        return FolderDataset(args.dataset_root, res=args.image_size, numeric=True)
+    if args.dataset_name == "AFHQ":
+        return FolderDataset(args.dataset_root, res=args.image_size, numeric=False)
     if args.dataset_name == "Synthetic":
         return SyntheticDataset(args.image_size, args.c_in)
     if args.dataset_name == "Random":
         return None
-    raise ValueError('Invalid dataset name (supported here: CelebA_HQ_mask, Synthetic, Random)')
+    raise ValueError('Invalid dataset name (supported here: CelebA_HQ_mask, FFHQ, AFHQ, CelebA_HQ, Synthetic, Random; '
+                     'the HF-hub datasets need network access)')
