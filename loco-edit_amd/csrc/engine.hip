@@ -883,7 +883,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 g.C = p.T(op.S); g.scm = T; g.scn = 1; g.scb = p.bs(); g.sch = (long)T * T;
                 g.M = T; g.N = T; g.K = CH; g.batch = B; g.batch2 = NH; g.alpha = 1.0f / std::sqrt((float)CH); g.beta = 0.f;
                 launch_gemm(g, st);
-                for (int b = 0; b < B; ++b) launch_softmax_rows(p.T(op.S) + (long)b * p.bs(), (long)NH * T, T, st);
+                launch_softmax_rows(p.T(op.S), (long)NH * T, T, st, B, p.bs());
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
                 h.A = v; h.sam = T; h.sak = 1; h.sab = p.bs(); h.sah = 3L * CH * T;
                 h.Bm = p.T(op.S); h.sbk = 1; h.sbn = T; h.sbb = p.bs(); h.sbh = (long)T * T;
@@ -1028,9 +1028,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 launch_gemm(g, st);
                 g.A = q; g.sab = 0; g.Bm = dk; g.sbb = PS; g.beta = 1.f;
                 launch_gemm(g, st);
-                for (int b = 0; b < B; ++b)
-                    launch_softmax_jac(TT(op.S) + (long)b * PS, TP(op.S), (long)NH * T, T, (long)NH * T,
-                                       1.0f / std::sqrt((float)CH), st);
+                launch_softmax_jac(TT(op.S), TP(op.S), (long)NH * T, T, (long)NH * T, 1.0f / std::sqrt((float)CH), st, B, PS);
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
                 h.A = dv; h.sam = T; h.sak = 1; h.sab = PS; h.sah = HS;
                 h.Bm = TP(op.S); h.sbk = 1; h.sbn = T; h.sbb = 0; h.sbh = SS;
@@ -1210,9 +1208,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 h.C = TG(op.S); h.scm = T; h.scn = 1; h.scb = PS; h.sch = SS;
                 h.M = T; h.N = T; h.K = CH; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
                 launch_gemm(h, st);
-                for (int b = 0; b < B; ++b)
-                    launch_softmax_jac(TG(op.S) + (long)b * PS, TP(op.S), (long)NH * T, T, (long)NH * T,
-                                       1.0f / std::sqrt((float)CH), st);
+                launch_softmax_jac(TG(op.S), TP(op.S), (long)NH * T, T, (long)NH * T, 1.0f / std::sqrt((float)CH), st, B, PS);
                 // g_q[c][i] = sum_j k[c][j] g_S[i][j]
                 GemmArgs gq_; std::memset(&gq_, 0, sizeof(gq_));
                 gq_.A = k; gq_.sam = T; gq_.sak = 1; gq_.sab = 0; gq_.sah = HS;

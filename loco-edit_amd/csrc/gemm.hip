@@ -3,14 +3,14 @@
 // cotangent forms; reference diffusion.py:948-962 torch.bmm calls).  Operands
 // are addressed through (row, col, batch) strides so q/k/v stay in their
 // [channel][token] conv layout and transposes are never materialised.
-// 64x64 tile, 4 waves (one 32x32 block each), BK = 16.
+// 64x64 tile, 4 waves (one 32x32 block each), BK = 32, next tile prefetched into registers.
 #include "kernels.h"
 
 namespace loco {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GBM = 64, GBN = 64, GBK = 16;
+constexpr int GBM = 64, GBN = 64, GBK = 32;
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __shared__ float As[GBK][GBM + 1];
@@ -27,30 +27,41 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    for (int k0 = 0; k0 < g.K; k0 += GBK) {
-        // stage A tile (64 x 16) and B tile (16 x 64); thread order follows the unit-stride dim
+    // per-thread staging coordinates: thread order follows the unit-stride dimension of each operand
+    constexpr int NE = GBM * GBK / 256;     // 8 elements of A and of B per thread and tile
+    int am[NE], ak[NE], bn[NE], bk[NE];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int e = tid + i * 256;
-            int m, k;
-            if (g.sak == 1) { m = e / GBK; k = e % GBK; } else { k = e / GBM; m = e % GBM; }
-            float v = 0.f;
-            if (m0 + m < g.M && k0 + k < g.K) v = A[(long)(m0 + m) * g.sam + (long)(k0 + k) * g.sak];
-            As[k][m] = v;
-            int n, kb;
-            if (g.sbn == 1) { kb = e / GBN; n = e % GBN; } else { n = e / GBK; kb = e % GBK; }
-            float w = 0.f;
-            if (n0 + n < g.N && k0 + kb < g.K) w = B[(long)(k0 + kb) * g.sbk + (long)(n0 + n) * g.sbn];
-            Bs[kb][n] = w;
+    for (int i = 0; i < NE; ++i) {
+        int e = tid + i * 256;
+        if (g.sak == 1) { am[i] = e / GBK; ak[i] = e % GBK; } else { ak[i] = e / GBM; am[i] = e % GBM; }
+        if (g.sbn == 1) { bk[i] = e / GBN; bn[i] = e % GBN; } else { bn[i] = e / GBK; bk[i] = e % GBK; }
+    }
+    float ra[NE], rb[NE];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            bool va = (m0 + am[i] < g.M) && (k0 + ak[i] < g.K);
+            bool vb = (n0 + bn[i] < g.N) && (k0 + bk[i] < g.K);
+            long oa = va ? (long)(m0 + am[i]) * g.sam + (long)(k0 + ak[i]) * g.sak : 0;
+            long ob = vb ? (long)(k0 + bk[i]) * g.sbk + (long)(n0 + bn[i]) * g.sbn : 0;
+            float xa = A[oa], xb = B[ob];
+            ra[i] = va ? xa : 0.f;
+            rb[i] = vb ? xb : 0.f;
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < g.K; k0 += GBK) {
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { As[ak[i]][am[i]] = ra[i]; Bs[bk[i]][bn[i]] = rb[i]; }
+        __syncthreads();
+        if (k0 + GBK < g.K) fetch(k0 + GBK);
 #pragma unroll
         for (int kk = 0; kk < GBK / 2; ++kk) {
             float a = As[2 * kk + khalf][wm * 32 + l31];
             float b = Bs[2 * kk + khalf][wn * 32 + l31];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
-        __syncthreads();
     }
     const int n = n0 + wn * 32 + l31;
     if (n < g.N) {

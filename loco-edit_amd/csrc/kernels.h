@@ -107,9 +107,10 @@ void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x
 
 // ---- attention helpers ------------------------------------------------------
 // rows: [R][T] contiguous; softmax over T in place (S -> P)
-void launch_softmax_rows(float* S, long rows, int T, hipStream_t st);
+void launch_softmax_rows(float* S, long rows, int T, hipStream_t st, int B = 1, long bs = 0);
 // dP = P * (dS - rowsum(P*dS)) * scale, in place on dS; P has prow rows broadcast: row r uses P row (r % prow_mod)
-void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows, float scale, hipStream_t st);
+void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows, float scale, hipStream_t st,
+                        int B = 1, long bs = 0);
 
 // ---- small ops ---------------------------------------------------------------
 // temb pipeline: sinusoid(t) -> dense0 -> swish -> dense1 -> swish -> all per-block projections

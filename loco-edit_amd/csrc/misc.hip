@@ -141,7 +141,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void gn_tstats_partial(const float* d, long d_bs, const float* x, long x_bs,
                                                          int HW, int cpg, const float* sc, const float* sh,
                                                          const float* mr, long pbs_c, long pbs_g,
-                                                         double* scratch) {
+                                                         double* scratch, float* tst, float* tc, long tbs) {
     __shared__ double sm[4];
     const int s = blockIdx.x, nsplit = gridDim.x, g = blockIdx.y, b = blockIdx.z, G = gridDim.y;
     const long len = (long)cpg * HW;
@@ -176,10 +176,27 @@ __global__ __launch_bounds__(256) void gn_tstats_partial(const float* d, long d_
     }
     double t1 = block_sum(s1, sm);
     double t2 = block_sum(s2, sm);
+    if (nsplit > 1) {
+        if (threadIdx.x == 0) {
+            double* o = scratch + (((long)b * G + g) * nsplit + s) * 2;
+            o[0] = t1;
+            o[1] = t2;
+        }
+        return;
+    }
+    // single slice: finalise here (saves the second launch for the small tensors)
+    const double inv_n = 1.0 / (double)len;
+    const float m1 = (float)(t1 * inv_n), m2 = (float)(t2 * inv_n);
     if (threadIdx.x == 0) {
-        double* o = scratch + (((long)b * G + g) * nsplit + s) * 2;
-        o[0] = t1;
-        o[1] = t2;
+        float* o = tst + (long)b * tbs + 2 * g;
+        o[0] = m1;
+        o[1] = m2;
+    }
+    if (tc && threadIdx.x < cpg) {
+        float f = KIND == 0 ? 1.0f : rstd;
+        float* t = tc + (long)b * tbs + 2 * ((long)g * cpg + threadIdx.x);
+        t[0] = f * m1;
+        t[1] = f * m2;
     }
 }
 
@@ -214,13 +231,14 @@ void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int 
     dim3 grid(ns, G, B);
     if (kind == 0)
         hipLaunchKernelGGL(gn_tstats_partial<0>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, HW, cpg, sc, sh, mr,
-                           pbs_c, pbs_g, scratch);
+                           pbs_c, pbs_g, scratch, tst, tc, tst_bs);
     else if (kind == 1)
         hipLaunchKernelGGL(gn_tstats_partial<1>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, HW, cpg, sc, sh, mr,
-                           pbs_c, pbs_g, scratch);
+                           pbs_c, pbs_g, scratch, tst, tc, tst_bs);
     else
         hipLaunchKernelGGL(gn_tstats_partial<2>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, HW, cpg, sc, sh, mr,
-                           pbs_c, pbs_g, scratch);
+                           pbs_c, pbs_g, scratch, tst, tc, tst_bs);
+    if (ns == 1) return;
     long BG = (long)B * G;
     hipLaunchKernelGGL(gn_tstats_finalize, dim3((unsigned)((BG + 255) / 256)), dim3(256), 0, st, scratch, ns, BG,
                        G, 1.0 / (double)len, tst, tc, tst_bs, cpg, mr, pbs_g, kind);
@@ -333,11 +351,11 @@ void launch_gn_cache(const float* x, int C, int HW, int cpg, const float* sc, co
 
 // ---------------------------------------------------------------------------
 // softmax over rows of length T (T <= 1024, multiple of 64): one wave per row
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, long rows, int T) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, long rows, int T, long bs) {
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    float* p = S + row * T;
+    float* p = S + (long)blockIdx.y * bs + row * T;
     float v[16];
     const int per = T / 64;
     float mx = -INFINITY;
@@ -357,16 +375,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, long rows, 
     float inv = 1.0f / sum;
     for (int i = 0; i < per; ++i) p[lane + i * 64] = v[i] * inv;
 }
-void launch_softmax_rows(float* S, long rows, int T, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, rows, T);
+void launch_softmax_rows(float* S, long rows, int T, hipStream_t st, int B, long bs) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4), B), dim3(256), 0, st, S, rows, T, bs);
 }
 
 __global__ __launch_bounds__(256) void softmax_jac_kernel(float* dS, const float* P, long rows, int T,
-                                                          long p_rows, float scale) {
+                                                          long p_rows, float scale, long bs) {
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    float* d = dS + row * T;
+    float* d = dS + (long)blockIdx.y * bs + row * T;
     const float* p = P + (row % p_rows) * T;
     const int per = T / 64;
     float dv[16], pv[16];
@@ -380,9 +398,10 @@ __global__ __launch_bounds__(256) void softmax_jac_kernel(float* dS, const float
     dot = __shfl(dot, 0, 64);
     for (int i = 0; i < per; ++i) d[lane + i * 64] = scale * pv[i] * (dv[i] - dot);
 }
-void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_jac_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, dS, P, rows, T,
-                       p_rows, scale);
+void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows, float scale, hipStream_t st,
+                        int B, long bs) {
+    hipLaunchKernelGGL(softmax_jac_kernel, dim3((unsigned)((rows + 3) / 4), B), dim3(256), 0, st, dS, P, rows, T,
+                       p_rows, scale, bs);
 }
 
 // ---------------------------------------------------------------------------
