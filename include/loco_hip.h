@@ -149,6 +149,9 @@ int  loco_get_precision(loco_ctx* ctx);
 int  loco_bench_conv(loco_ctx* ctx, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t B, int32_t mode,
                      int32_t taps, int32_t tile, int32_t iters, float* ms_avg, void* stream);
 
+/* Diagnostic builds only (-DLOCO_STAMP): copy the first n floats of the split-K workspace to the host. */
+int  loco_debug_read_scratch(loco_ctx* ctx, float* dst_host, int32_t n);
+
 /* Per-kernel HIP-event profile of the convolution launches (bench.py roofline
  * leg).  While enabled every conv launch is bracketed by two events on the
  * caller's stream; loco_profile_report synchronises, then writes one line per

@@ -52,7 +52,7 @@ constexpr int max_halo(int NT, int taps, bool s2) {
     return s2 ? 17 * 17 : 10 * 10;   // NT = 64 : 8x8 output tile
 }
 
-template <int TAPS, int WM, int WN, int TM, int TN, int MODE, bool S2>
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
 __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = WM * TM * 32;
@@ -61,7 +61,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     constexpr int NTS = KS;                          // taps per weight stage (one kernel row)
     constexpr int NROW = (TAPS == 9) ? 3 : 1;        // weight stages per channel chunk
     constexpr bool NEEDP = (MODE == CM_TAN_SILU || MODE == CM_COT_SILU);
-    constexpr int NITEM = (2 * max_halo(NT, TAPS, S2) + NTHR - 1) / NTHR;
+    // GEN: general per-pixel staging (stride 2, upsample, zero insertion, partial channel chunks, caller-owned
+    // tensors); !GEN: 16-byte loads of 4 consecutive pixels from padded arena tensors (stride-1 convs)
+    // STG 0: vector staging; 1: per-pixel staging, stride 1 (also upsample / zero-insert / partial chunks /
+    // caller-owned tensors); 2: per-pixel staging sized for the stride-2 halo
+    constexpr bool GEN = STG != 0;
+    constexpr int NITEM = GEN ? (2 * max_halo(NT, TAPS, STG == 2) + NTHR - 1) / NTHR : 1;
     constexpr int WTOT = NTS * MT * 4;               // 16-byte pieces of one weight stage
     constexpr int NWV = (WTOT + NTHR - 1) / NTHR;
 
@@ -133,6 +138,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         ivoff[i] = (unsigned)(oct * 8 * (int)in_plane + (off >= 0 ? off : 0));
     }
 
+    // ---- vector staging item of this thread (!GEN): 4 consecutive halo pixels x 4 channels (quarter chunk q4)
+    const int nseg = (halo_w + 3) >> 2;
+    int v_q4 = 0, v_pos0 = -1, v_voff = 0, v_cnt = 0;
+    unsigned v_pm = 0;                       // per-pixel validity bits
+    if constexpr (!GEN) {
+        const int per_q = halo_h * nseg;
+        if (tid < 4 * per_q) {
+            v_q4 = tid / per_q;
+            int rem = tid - v_q4 * per_q;
+            int hy = rem / nseg, sg = rem - hy * nseg;
+            int Y = oy0 - a.pad + hy, X0 = ox0 - a.pad + 4 * sg;
+            bool rowok = (Y >= 0 && Y < a.Hin);
+            v_pos0 = hy * halo_w + 4 * sg;
+            v_cnt = halo_w - 4 * sg < 4 ? halo_w - 4 * sg : 4;
+            v_voff = rowok ? Y * a.Win + X0 : 0;          // may be -1 / run 3 floats past the plane: arenas are padded
+#pragma unroll
+            for (int pxi = 0; pxi < 4; ++pxi)
+                if (rowok && X0 + pxi >= 0 && X0 + pxi < a.Win && pxi < v_cnt) v_pm |= 1u << pxi;
+        }
+    }
+
     int hoff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -176,7 +202,87 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     float cA[(MODE == CM_NONE) ? 1 : 16], cB[(MODE == CM_NONE) ? 1 : 16];
     const float* tcb = NEEDP ? a.tc + (long)b * a.tc_bs : nullptr;   // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent)
 
+    float4 hq[GEN ? 1 : 4];                       // !GEN: [channel k][4 pixels]
+    float4 pq[(!GEN && NEEDP) ? 4 : 1][2];        // {S, xhat} of the 4 pixels: 32 bytes per channel
+    float4 cq[(!GEN && MODE != CM_NONE) ? 2 : 1]; // per-channel constants of the 4 channels
+    auto prefetch_hv = [&](int chunk) {
+        const int c0 = chunk * BKC + v_q4 * 4;    // first channel of this thread's quarter chunk
+        const float* pk = inb + (long)c0 * in_plane + v_voff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // 4-byte aligned 16-byte load (global memory tolerates dword alignment)
+            float4 v;
+            __builtin_memcpy(&v, pk + (long)k * in_plane, 16);
+            hq[k] = v;
+            if constexpr (NEEDP) {
+                const float* sk = reinterpret_cast<const float*>(sxb) + 2 * ((long)(c0 + k) * in_plane + v_voff);
+                float4 s0, s1;
+                __builtin_memcpy(&s0, sk, 16);
+                __builtin_memcpy(&s1, sk + 4, 16);
+                pq[k][0] = s0; pq[k][1] = s1;
+            }
+        }
+        if constexpr (MODE != CM_NONE) {
+            if constexpr (NEEDP) {      // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent) of channels c0..c0+3
+                cq[0] = *reinterpret_cast<const float4*>(tcb + 2 * c0);
+                cq[1] = *reinterpret_cast<const float4*>(tcb + 2 * c0 + 4);
+            } else {
+                cq[0] = *reinterpret_cast<const float4*>(scb + c0);
+                cq[1] = *reinterpret_cast<const float4*>(shb + c0);
+            }
+        }
+    };
+    auto stage_hv = [&]() {
+        if (v_pos0 < 0) return;
+        const float hvv[4][4] = {{hq[0].x, hq[0].y, hq[0].z, hq[0].w}, {hq[1].x, hq[1].y, hq[1].z, hq[1].w},
+                                 {hq[2].x, hq[2].y, hq[2].z, hq[2].w}, {hq[3].x, hq[3].y, hq[3].z, hq[3].w}};
+        float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE != CM_NONE) {
+            if constexpr (NEEDP) {
+                ca[0] = cq[0].x; cb[0] = cq[0].y; ca[1] = cq[0].z; cb[1] = cq[0].w;
+                ca[2] = cq[1].x; cb[2] = cq[1].y; ca[3] = cq[1].z; cb[3] = cq[1].w;
+            } else {
+                ca[0] = cq[0].x; ca[1] = cq[0].y; ca[2] = cq[0].z; ca[3] = cq[0].w;
+                cb[0] = cq[1].x; cb[1] = cq[1].y; cb[2] = cq[1].z; cb[3] = cq[1].w;
+            }
+        }
+        const int oct = v_q4 >> 1, half = v_q4 & 1;
+#pragma unroll
+        for (int pxi = 0; pxi < 4; ++pxi) {
+            if (pxi >= v_cnt) break;
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float d = hvv[k][pxi];
+                float v = d;
+                if constexpr (MODE == CM_GN_SILU) {
+                    float y = fmaf(ca[k], d, cb[k]);
+                    v = y * sigmoidf2_(y);
+                } else if constexpr (MODE == CM_GN) {
+                    v = fmaf(ca[k], d, cb[k]);
+                } else if constexpr (NEEDP) {
+                    const float4 sv = pq[k][pxi >> 1];
+                    const float Sv = (pxi & 1) ? sv.z : sv.x, xh = (pxi & 1) ? sv.w : sv.y;
+                    if constexpr (MODE == CM_TAN_SILU) v = Sv * (d - ca[k] - xh * cb[k]);
+                    else v = Sv * d - ca[k] - xh * cb[k];
+                }
+                r[k] = ((v_pm >> pxi) & 1u) ? v : 0.0f;
+            }
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __bf16 hb = (__bf16)r[k];
+                __bf16 lb = (__bf16)(r[k] - (float)hb);
+                h[k] = __builtin_bit_cast(unsigned short, hb);
+                l[k] = __builtin_bit_cast(unsigned short, lb);
+            }
+            const int pos = v_pos0 + pxi;
+            *reinterpret_cast<uint2*>(Hs + rec_off(pos, oct) + half * 8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            *reinterpret_cast<uint2*>(Hs + rec_off(pos, 2 + oct) + half * 8) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+        }
+    };
     auto prefetch_h = [&](int chunk) {
+        if constexpr (!GEN) { prefetch_hv(chunk); return; }
         const int c0 = chunk * BKC;
         if constexpr (MODE != CM_NONE) {
 #pragma unroll
@@ -242,6 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         }
     };
     auto stage_h = [&](int chunk) {
+        if constexpr (!GEN) { stage_hv(); return; }
         const int c0 = chunk * BKC;
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
@@ -313,19 +420,39 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         prefetch_h(cbeg);
         prefetch_w(cbeg, 0);
     }
+#ifdef LOCO_STAMP
+    // diagnostic build: per-phase cycle totals of every wave of workgroup 0 (never in the product build)
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#define STAMP(i) { unsigned long long tn = __builtin_readcyclecounter(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define STAMP(i)
+#endif
     for (int chunk = cbeg; chunk < cend; ++chunk) {
 #pragma unroll
         for (int row = 0; row < NROW; ++row) {
             __syncthreads();
+            STAMP(0)
             stage_w();
+            STAMP(1)
             if (row == 0) stage_h(chunk);
+            STAMP(2)
             __syncthreads();
+            STAMP(3)
             if (row + 1 < NROW) prefetch_w(chunk, row + 1);
             else if (chunk + 1 < cend) prefetch_w(chunk + 1, 0);
             if (row == 0 && chunk + 1 < cend) prefetch_h(chunk + 1);
+            STAMP(4)
             mfma_stage(row);
+            STAMP(5)
         }
     }
+#ifdef LOCO_STAMP
+    if (blockIdx.x == 0 && (tid & 63) == 0) {
+        for (int i = 0; i < 6; ++i) a.partial[wave * 8 + i] = (float)tacc[i];
+    }
+    unsigned long long tep0 = __builtin_readcyclecounter();
+#endif
 
     // epilogue.  D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const long out_plane = (long)a.Hout * a.Wout;
@@ -365,13 +492,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
             }
         }
     }
+#ifdef LOCO_STAMP
+    if (blockIdx.x == 0 && (tid & 63) == 0) a.partial[wave * 8 + 6] = (float)(__builtin_readcyclecounter() - tep0);
+#endif
 }
-
 
 // ---------------------------------------------------------------------------
 int conv_pick_tile(int Cout, int HW);   // conv.hip
 
-template <int TAPS, int WM, int WN, int TM, int TN, int MODE, bool S2>
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
 static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     constexpr int MT = WM * TM * 32, NT = WN * TN * 32;
     constexpr int KS = (TAPS == 9) ? 3 : 1;
@@ -383,20 +512,27 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, S2>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             done = true;
         }
     }
-    hipLaunchKernelGGL((conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, S2>), grid, dim3(WM * WN * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>), grid, dim3(WM * WN * 64), lds, st, a);
 }
 
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE>
 static void launch_one_b(const ConvArgs& a, hipStream_t st) {
-    if constexpr (MODE == CM_NONE && TAPS == 9) {
-        if (a.stride == 2) { launch_one_b2<TAPS, WM, WN, TM, TN, MODE, true>(a, st); return; }
+    const bool general = a.stride != 1 || a.upsample || a.zins || (a.Cin % BKC) != 0 || !a.in_padded;
+    if constexpr (MODE == CM_NONE) {
+        // raw inputs: the per-pixel path measures faster than the vector path (no prologue to amortise)
+        if (a.stride == 2) launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 2>(a, st);
+        else launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 1>(a, st);
+        return;
     }
-    launch_one_b2<TAPS, WM, WN, TM, TN, MODE, false>(a, st);
+    if constexpr (MODE == CM_GN_SILU || MODE == CM_TAN_SILU) {
+        if (general) { launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 1>(a, st); return; }
+    }
+    launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
 }
 
 int g_bf16_tile_override = -1;   // debug / tuning: force a tile variant for the big-image case

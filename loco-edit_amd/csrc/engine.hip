@@ -759,6 +759,10 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
     if (a.nsplit < 1) a.nsplit = 1;
     a.partial = c->partial;
+    {
+        const size_t span = (size_t)c->cfg.max_batch * c->per_sample;
+        a.in_padded = (a.in >= c->arenaP && a.in < c->arenaP + span) || (a.in >= c->arenaT && a.in < c->arenaT + span);
+    }
     if (c->prof_on) {
         loco_ctx::ProfRec r;
         r.name = conv_variant_name(a, taps, c->prec);
@@ -1280,7 +1284,11 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         if (op.kind == OP_RES && op.updown && op.has_nin) { c->err = "resampling ResBlock with a channel change is not supported"; return -2; }
     declare_all(c);
     const size_t MB = (size_t)cfg->max_batch;
-    if (dalloc(c, &c->arenaP, MB * c->per_sample) || dalloc(c, &c->arenaT, MB * c->per_sample)) return -1;
+    {   // 64-float guard bands: the vector halo loads of the convs may touch 1 float before / 3 after a tensor
+        float *p0 = nullptr, *p1 = nullptr;
+        if (dalloc(c, &p0, MB * c->per_sample + 128) || dalloc(c, &p1, MB * c->per_sample + 128)) return -1;
+        c->arenaP = p0 + 64; c->arenaT = p1 + 64;
+    }
     if (dalloc(c, &c->statsP, MB * c->stats_per_sample) || dalloc(c, &c->statsT, MB * c->stats_per_sample)) return -1;
     if (dalloc(c, &c->red, (size_t)1 << 20)) return -1;
     c->partial_floats = (size_t)64 << 20;   // 256 MB split-K workspace
@@ -1294,7 +1302,11 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         if (dalloc(c, &c->gscratch, nblk * 64 * 64 + 4096)) return -1;
     }
     if (dalloc(c, &c->alphas, 256)) return -1;
-    if (dalloc(c, &c->sxcache, (size_t)c->sx_total)) return -1;
+    {
+        float2* sx0 = nullptr;
+        if (dalloc(c, &sx0, (size_t)c->sx_total + 64)) return -1;
+        c->sxcache = sx0 + 32;
+    }
     {
         const char* e = getenv("LOCO_PRECISION");
         c->prec = (e && std::string(e) == "f32") ? 0 : 1;   // default: split-bf16 (fp32-faithful to ~2^-16)
@@ -1608,7 +1620,7 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     a.prim = c->arenaP; a.prim_bs = 0; a.sx = c->sxcache;
     a.w = wf; a.wb = wf;
     a.out = out; a.out_bs = out_e; a.Cout = cout; a.Hout = H; a.Wout = W; a.B = B;
-    a.mode = mode; a.pad = taps == 9 ? 1 : 0;
+    a.mode = mode; a.pad = taps == 9 ? 1 : 0; a.in_padded = 1;
     a.sc = c->statsP; a.sh = c->statsP + cin; a.scsh_bs = 0; a.mr = c->statsP + 2 * cin; a.mr_bs = 0;
     a.gamma_ = c->statsP; a.tst = c->statsT; a.tst_bs = c->stats_per_sample; a.cpg = cin / c->cfg.gn_groups;
     a.tc = c->statsT + 64; a.tc_bs = c->stats_per_sample;
@@ -1627,6 +1639,13 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *ms_avg = ms / iters;
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_debug_read_scratch(loco_ctx* c, float* dst_host, int32_t n) {
+    if (!c) return -2;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(dst_host, c->partial, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

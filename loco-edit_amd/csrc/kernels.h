@@ -43,6 +43,7 @@ struct ConvArgs {
     int pad;         // top/left zero padding in input coords (1: 3x3 s1, 0: 3x3 s2 / 1x1, 2: zero-insert dgrad)
     int upsample;    // input is read through a nearest x2 upsample
     int zins;        // input is read through stride-2 zero insertion (dgrad of the stride-2 conv)
+    int in_padded;   // `in` (and `sx`) live in a padded engine arena: 16-byte loads may start 1 float before / end 3 after a plane
     int accumulate;  // out += result
     int nsplit;      // split-K factor (>1: raw partials go to `partial`, epilogue by conv_splitk_reduce)
     float* partial;

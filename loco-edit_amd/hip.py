@@ -26,7 +26,7 @@ SYMBOLS = [
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop", "loco_debug_tensor",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision",
-    "loco_bench_conv",
+    "loco_bench_conv", "loco_debug_read_scratch",
 ]
 
 
@@ -87,6 +87,7 @@ def load_library():
     lib.loco_set_precision.argtypes = [vp, i32]
     lib.loco_get_precision.argtypes = [vp]
     lib.loco_bench_conv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32), vp]
+    lib.loco_debug_read_scratch.argtypes = [vp, C.POINTER(f32), i32]
     lib.loco_profile_enable.argtypes = [vp, i32]
     lib.loco_profile_report.argtypes = [vp, C.c_char_p, i64]
     lib.loco_debug_tensor.argtypes = [vp, C.c_char_p, vp, i64, vp]
@@ -303,6 +304,11 @@ class LocoEngine:
         self._check(self.lib.loco_bench_conv(self._ctx, cin, cout, H, W, B, mode, taps, tile, iters, C.byref(ms),
                                              _stream()), "loco_bench_conv")
         return float(ms.value)
+
+    def debug_read_scratch(self, n: int):
+        buf = (C.c_float * n)()
+        self._check(self.lib.loco_debug_read_scratch(self._ctx, buf, n), "loco_debug_read_scratch")
+        return list(buf)
 
     def profile_enable(self, on: bool):
         self._check(self.lib.loco_profile_enable(self._ctx, int(on)), "loco_profile_enable")
