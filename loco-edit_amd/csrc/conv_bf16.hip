@@ -477,17 +477,40 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
                 float* ob = a.out + (long)b * a.out_bs;
                 const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
                 const float* b2 = a.bias2 ? a.bias2 + (long)b * a.bias2_bs : nullptr;
+                if (rb || a.accumulate) {
+                    // The residual may alias the output (nin shortcut written in place), so the compiler cannot
+                    // move a residual load above the previous store: gather the 16 residual / accumulate values of
+                    // the tile first (each thread only touches its own elements), then add and store.
+                    float rv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int co = cob + (r & 3) + 8 * (r >> 2);
-                    if (!(full_co || co < a.Cout)) continue;
-                    float v = acc[i][j][r];
-                    if (a.bias) v += a.bias[co];
-                    if (b2) v += b2[co];
-                    const long off = (long)co * out_plane + pix;
-                    if (rb) v += rb[off];
-                    if (a.accumulate) v += ob[off];
-                    ob[off] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        int co = cob + (r & 3) + 8 * (r >> 2);
+                        const bool ok = full_co || co < a.Cout;
+                        const long off = (long)(ok ? co : a.Cout - 1) * out_plane + pix;
+                        float t = 0.f;
+                        if (rb) t = rb[off];
+                        if (a.accumulate) t += ob[off];
+                        rv[r] = t;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = cob + (r & 3) + 8 * (r >> 2);
+                        if (!(full_co || co < a.Cout)) continue;
+                        float v = acc[i][j][r] + rv[r];
+                        if (a.bias) v += a.bias[co];
+                        if (b2) v += b2[co];
+                        ob[(long)co * out_plane + pix] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = cob + (r & 3) + 8 * (r >> 2);
+                        if (!(full_co || co < a.Cout)) continue;
+                        float v = acc[i][j][r];
+                        if (a.bias) v += a.bias[co];
+                        if (b2) v += b2[co];
+                        ob[(long)co * out_plane + pix] = v;
+                    }
                 }
             }
         }

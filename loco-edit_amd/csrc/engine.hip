@@ -125,7 +125,8 @@ struct loco_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-launch conv profile
     bool prof_on = false;
-    struct ProfRec { const char* name; double flops; hipEvent_t e0, e1; };
+    struct ProfRec { const char* name; double flops; hipEvent_t e0, e1; int cin, cout, h, b, ns, mode, taps; };
+    bool prof_shapes = false;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -768,6 +769,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
         r.name = conv_variant_name(a, taps, c->prec);
         r.flops = 2.0 * a.Cin * a.Cout * taps * (double)a.Hout * a.Wout * a.B;
         if (a.zins) r.flops *= 0.25;     // algorithmic work of the stride-2 data gradient
+        r.cin = a.Cin; r.cout = a.Cout; r.h = a.Hout; r.b = a.B; r.ns = a.nsplit; r.mode = a.mode; r.taps = taps;
         r.e0 = c->next_event(); r.e1 = c->next_event();
         (void)hipEventRecord(r.e0, st);
         if (c->prec == 1) launch_conv_bf16x3(a, taps, st); else launch_conv(a, taps, st);
@@ -1652,6 +1654,7 @@ int loco_debug_read_scratch(loco_ctx* c, float* dst_host, int32_t n) {
 int loco_profile_enable(loco_ctx* c, int32_t on) {
     if (!c) return -2;
     c->prof_on = on != 0;
+    c->prof_shapes = on == 2;     // 2: aggregate per layer shape instead of per kernel variant
     if (on) { c->prof.clear(); c->ev_used = 0; }
     return 0;
 }
@@ -1663,7 +1666,13 @@ int loco_profile_report(loco_ctx* c, char* buf, int64_t cap) {
     for (auto& r : c->prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
-        auto& a = agg[r.name];
+        std::string key = r.name;
+        if (c->prof_shapes) {
+            char sb[96];
+            snprintf(sb, sizeof(sb), "|t%d_m%d_ci%d_co%d_h%d_b%d_s%d", r.taps, r.mode, r.cin, r.cout, r.h, r.b, r.ns);
+            key += sb;
+        }
+        auto& a = agg[key];
         a[0] += 1.0; a[1] += ms; a[2] += r.flops;
     }
     std::string out;

@@ -310,12 +310,13 @@ class LocoEngine:
         self._check(self.lib.loco_debug_read_scratch(self._ctx, buf, n), "loco_debug_read_scratch")
         return list(buf)
 
-    def profile_enable(self, on: bool):
+    def profile_enable(self, on):
+        """True/1: per kernel variant; 2: per layer shape; False: off."""
         self._check(self.lib.loco_profile_enable(self._ctx, int(on)), "loco_profile_enable")
 
     def profile_report(self):
         """-> {kernel variant: dict(launches, ms, flops)} for the conv launches since profile_enable(True)."""
-        buf = C.create_string_buffer(1 << 16)
+        buf = C.create_string_buffer(1 << 18)
         self._check(self.lib.loco_profile_report(self._ctx, buf, len(buf)), "loco_profile_report")
         out = {}
         for line in buf.value.decode().splitlines():

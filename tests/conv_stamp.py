@@ -11,7 +11,7 @@ eng.load_state_dict(synth_params(CELEBA_DDPM, 0))
 eng.set_precision("bf16x3")
 names = ["bar1", "stage_w", "stage_h", "bar2", "prefetch", "mfma", "epilogue"]
 for mode in (0, 3, 4):
-    for tile in (5, 0):
+    for tile in (5,):
         ms = eng.bench_conv(128, 128, 256, 256, 5, mode, 9, tile, 3)
         v = eng.debug_read_scratch(64)
         print(f"mode {mode} tile {tile}: {ms*1e3:.1f} us")
