@@ -71,8 +71,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     constexpr int NWV = (WTOT + NTHR - 1) / NTHR;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    unsigned char* Ws = smem_b;                      // [NTS][MT] records
-    unsigned char* Hs = smem_b + NTS * MT * 64;      // [halo_sz] records
+    // double-buffered: weight stage s lives in W buffer s&1, the halo of chunk c in H buffer c&1
+    constexpr int WBYTES = NTS * MT * 64;
+    unsigned char* const Wsb = smem_b;               // 2 x [NTS][MT] records
+    unsigned char* Hsb;                              // 2 x [halo_sz] records (set below, needs halo_sz)
+    unsigned char* Ws = smem_b;                      // buffer being WRITTEN by stage_w / READ by mfma_stage
+    unsigned char* Hs = smem_b;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,6 +110,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     const int halo_w = (TW - 1) * S + KS;
     const int halo_h = (TH - 1) * S + KS;
     const int halo_sz = halo_h * halo_w;
+    const int HBYTES = halo_sz * 64;
+    Hsb = smem_b + 2 * WBYTES;
 
     const int LH = (a.upsample || a.zins) ? a.Hin * 2 : a.Hin;
     const int LW = (a.upsample || a.zins) ? a.Win * 2 : a.Win;
@@ -413,38 +419,58 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         }
     };
 
-    // Stage loop, unrolled over the kernel rows of a chunk so that the load queue is static:
-    // the halo loads of the NEXT chunk are issued (row 0) behind the weight loads of the next
-    // stage, and the waits in rows 1..2 are counted (vmcnt(#halo loads)), never vmcnt(0).
-    if (cbeg < cend) {
-        prefetch_h(cbeg);
-        prefetch_w(cbeg, 0);
-    }
+    // Software pipeline with ONE barrier per stage (s = 3*chunk + row): while the MFMA block of stage s reads
+    // W[s&1] / H[chunk&1], the same phase writes the weights of stage s+1 into W[(s+1)&1] (and, on the last row of
+    // a chunk, the next chunk's halo into H[(chunk+1)&1]) from registers loaded one stage earlier, and issues the
+    // global loads of stage s+2.  Buffers written in stage s were last read in stage s-1, which every wave has
+    // left (barrier); everything read in stage s was written before that barrier.
 #ifdef LOCO_STAMP
-    // diagnostic build: per-phase cycle totals of every wave of workgroup 0 (never in the product build)
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_readcyclecounter();
 #define STAMP(i) { unsigned long long tn = __builtin_readcyclecounter(); tacc[i] += tn - tprev; tprev = tn; }
 #else
 #define STAMP(i)
 #endif
-    for (int chunk = cbeg; chunk < cend; ++chunk) {
+    const int nch = cend - cbeg;
+    if (nch > 0) {
+        prefetch_h(cbeg);
+        prefetch_w(cbeg, 0);
+        Ws = Wsb; Hs = Hsb;
+        stage_w();
+        stage_h(cbeg);
+        if (NROW > 1) prefetch_w(cbeg, 1); else if (nch > 1) prefetch_w(cbeg + 1, 0);
+        if (nch > 1) prefetch_h(cbeg + 1);
+        __syncthreads();
+    }
+    for (int ci = 0; ci < nch; ++ci) {
+        const int chunk = cbeg + ci;
 #pragma unroll
         for (int row = 0; row < NROW; ++row) {
-            __syncthreads();
+            const int s_ = ci * NROW + row;
+            const bool last_row = (row == NROW - 1);
+            const bool more = !(last_row && ci + 1 >= nch);          // a stage s+1 exists
             STAMP(0)
-            stage_w();
+            if (more) {                                              // registers hold the weights of stage s+1
+                Ws = Wsb + ((s_ + 1) & 1) * WBYTES;
+                stage_w();
+                if (last_row) { Hs = Hsb + ((ci + 1) & 1) * HBYTES; stage_h(chunk + 1); }
+            }
             STAMP(1)
-            if (row == 0) stage_h(chunk);
+            // loads of stage s+2 (weights) and of chunk+2 (halo, once its registers are free)
+            if (row + 2 < NROW) prefetch_w(chunk, row + 2);
+            else if (ci + 1 < nch) {
+                const int r2 = row + 2 - NROW;
+                if (r2 < NROW) prefetch_w(chunk + 1, r2);
+                else if (ci + 2 < nch) prefetch_w(chunk + 2, r2 - NROW);
+            }
+            if (last_row && ci + 2 < nch) prefetch_h(chunk + 2);
             STAMP(2)
-            __syncthreads();
-            STAMP(3)
-            if (row + 1 < NROW) prefetch_w(chunk, row + 1);
-            else if (chunk + 1 < cend) prefetch_w(chunk + 1, 0);
-            if (row == 0 && chunk + 1 < cend) prefetch_h(chunk + 1);
-            STAMP(4)
+            Ws = Wsb + (s_ & 1) * WBYTES;
+            Hs = Hsb + (ci & 1) * HBYTES;
             mfma_stage(row);
-            STAMP(5)
+            STAMP(3)
+            __syncthreads();
+            STAMP(4)
         }
     }
 #ifdef LOCO_STAMP
@@ -530,13 +556,13 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     int TW = a.Wout < 32 ? a.Wout : 32;
     int TH = NT / TW;
     int halo_w = (TW - 1) * a.stride + KS, halo_h = (TH - 1) * a.stride + KS;
-    size_t lds = (size_t)KS * MT * 64 + (size_t)halo_w * halo_h * 64;
+    size_t lds = 2 * ((size_t)KS * MT * 64 + (size_t)halo_w * halo_h * 64);
     dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             done = true;
         }
     }
@@ -573,7 +599,9 @@ int conv_bf16_pick_tile(int Cout, int HW, int Bsplit) {
 
 template <int TAPS, int MODE>
 static void launch_tile_b(const ConvArgs& a, hipStream_t st) {
-    switch (conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B * a.nsplit)) {
+    int tile = conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B * a.nsplit);
+    if (a.stride == 2 && (tile == 5 || tile == 4)) tile = 0;   // the double-buffered stride-2 halo of a 256-pixel tile exceeds LDS
+    switch (tile) {
         case 4: launch_one_b<TAPS, 2, 2, 2, 4, MODE>(a, st); break;   // 128 x 256, 4 waves (64 x 128 each)
         case 5: launch_one_b<TAPS, 2, 4, 2, 2, MODE>(a, st); break;   // 128 x 256, 8 waves (64 x 64 each)
         case 0: launch_one_b<TAPS, 2, 2, 2, 2, MODE>(a, st); break;
