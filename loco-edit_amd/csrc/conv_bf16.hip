@@ -587,14 +587,29 @@ static void launch_one_b(const ConvArgs& a, hipStream_t st) {
 int g_bf16_tile_override = -1;   // debug / tuning: force a tile variant for the big-image case
 
 int conv_bf16_pick_tile(int Cout, int HW, int Bsplit) {
+    (void)Bsplit;
     int t = conv_pick_tile(Cout, HW);
     if (t == 0 && HW >= 256) {
         if (g_bf16_tile_override >= 0) return g_bf16_tile_override;
-        // 128 x 256 tile with 8 waves once it still fills the chip (>= 2 workgroups per CU)
-        long blocks = (long)(HW / 256) * ((Cout + 127) / 128) * Bsplit;
-        if (blocks >= 256) return 5;
+        return 5;      // 128 x 256 tile, 8 waves: fastest measured variant down to 160 workgroups
     }
     return t;
+}
+
+// split-K factor for the split-bf16 kernels: splitting costs a partial round trip + a reduce launch, so only
+// split when the un-split grid would leave more than half of the CUs idle
+int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B) {
+    const int HW = Hout * Wout;
+    int t = conv_bf16_pick_tile(Cout, HW, B);
+    static const int MTs[6] = {128, 128, 32, 64, 128, 128}, NTs[6] = {128, 64, 128, 64, 256, 256};
+    long blocks = (long)(HW / NTs[t]) * ((Cout + MTs[t] - 1) / MTs[t]) * B;
+    int nchunks = (Cin + BKC - 1) / BKC;
+    if (blocks >= 128 || nchunks < 8) return 1;
+    int want = (int)((256 + blocks - 1) / blocks);
+    int maxs = nchunks / 4;
+    if (want > maxs) want = maxs;
+    if (want > 32) want = 32;
+    return want < 1 ? 1 : want;
 }
 
 template <int TAPS, int MODE>

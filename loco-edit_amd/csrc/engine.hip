@@ -756,7 +756,8 @@ void conv_defaults(ConvArgs& a) {
 
 // run a conv with automatic split-K selection
 void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
-    a.nsplit = conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
+    a.nsplit = c->prec == 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B)
+                            : conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
     if (a.nsplit < 1) a.nsplit = 1;
     a.partial = c->partial;

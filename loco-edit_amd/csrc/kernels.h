@@ -64,6 +64,7 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec);
 // workspace (floats) a conv launch with these args needs for split-K partials
 size_t conv_partial_floats(const ConvArgs& a);
 int conv_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int taps);
+int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B);
 
 // Generic strided batched GEMM  C[b](m,n) = alpha * sum_k A[b](m,k) B[b](k,n) + beta*C + bias[m] + R[b](m,n)
 struct GemmArgs {
