@@ -1,0 +1,124 @@
+"""Checkpoint key maps.
+
+The engine consumes the state_dict layout of the reference's vendored modules.  The shipped scripts load
+``google/ddpm-ema-celebahq-256`` through diffusers (``utils.py:93-100,122-125``); diffusers is not vendored and
+there is no network here, so the map below is written from the published ``UNet2DModel`` naming (the inverse of
+diffusers' ``convert_ddpm_original_checkpoint_to_diffusers.py``) and is only self-consistency tested
+(**parity unpinned** until a real checkpoint is available).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .config import UNetConfig, param_shapes
+
+_RES = {"norm1": "norm1", "conv1": "conv1", "time_emb_proj": "temb_proj", "norm2": "norm2", "conv2": "conv2",
+        "conv_shortcut": "nin_shortcut"}
+_ATTN = {"group_norm": "norm", "query": "q", "key": "k", "value": "v", "proj_attn": "proj_out",
+         "to_q": "q", "to_k": "k", "to_v": "v", "to_out.0": "proj_out"}
+
+
+def is_hf_unet2d(sd: Dict[str, torch.Tensor]) -> bool:
+    return any(k.startswith("down_blocks.") for k in sd) and "conv_norm_out.weight" in sd
+
+
+def hf_unet2d_to_vendored(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """diffusers ``UNet2DModel`` (DDPM flavour) keys -> ``models/ddpm/diffusion.py`` keys.
+    Attention projections are ``nn.Linear`` [C,C] in diffusers and 1x1 ``Conv2d`` [C,C,1,1] in the vendored module."""
+    nlev = len(cfg.ch_mult)
+    out: Dict[str, torch.Tensor] = {}
+
+    def put(name, v):
+        out[name] = v
+
+    for k, v in sd.items():
+        p = k.split(".")
+        suffix = p[-1]                      # weight / bias
+        if k.startswith("time_embedding.linear_1."):
+            put(f"temb.dense.0.{suffix}", v)
+        elif k.startswith("time_embedding.linear_2."):
+            put(f"temb.dense.1.{suffix}", v)
+        elif p[0] in ("conv_in", "conv_out"):
+            put(k, v)
+        elif p[0] == "conv_norm_out":
+            put(f"norm_out.{suffix}", v)
+        elif p[0] in ("down_blocks", "up_blocks"):
+            lvl = int(p[1]) if p[0] == "down_blocks" else nlev - 1 - int(p[1])
+            side = "down" if p[0] == "down_blocks" else "up"
+            if p[2] == "resnets":
+                put(f"{side}.{lvl}.block.{p[3]}.{_RES[p[4]]}.{suffix}", v)
+            elif p[2] == "attentions":
+                sub = ".".join(p[4:-1])
+                name = _ATTN[sub]
+                if name != "norm" and suffix == "weight" and v.dim() == 2:
+                    v = v[:, :, None, None]
+                put(f"{side}.{lvl}.attn.{p[3]}.{name}.{suffix}", v)
+            elif p[2] == "downsamplers":
+                put(f"down.{lvl}.downsample.conv.{suffix}", v)
+            elif p[2] == "upsamplers":
+                put(f"up.{lvl}.upsample.conv.{suffix}", v)
+            else:
+                raise KeyError(k)
+        elif p[0] == "mid_block":
+            if p[1] == "resnets":
+                put(f"mid.block_{int(p[2]) + 1}.{_RES[p[3]]}.{suffix}", v)
+            elif p[1] == "attentions":
+                sub = ".".join(p[3:-1])
+                name = _ATTN[sub]
+                if name != "norm" and suffix == "weight" and v.dim() == 2:
+                    v = v[:, :, None, None]
+                put(f"mid.attn_1.{name}.{suffix}", v)
+            else:
+                raise KeyError(k)
+        else:
+            raise KeyError(f"unexpected key {k}")
+    want = param_shapes(cfg)
+    missing = [n for n in want if n not in out]
+    if missing:
+        raise KeyError(f"{len(missing)} parameters missing after conversion, first: {missing[0]}")
+    for n, shp in want.items():
+        if tuple(out[n].shape) != tuple(shp):
+            raise ValueError(f"shape mismatch for {n}: {tuple(out[n].shape)} vs {tuple(shp)}")
+    return out
+
+
+def vendored_to_hf_unet2d(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """Inverse map (used by the round-trip test and to export checkpoints for a diffusers user)."""
+    nlev = len(cfg.ch_mult)
+    inv_res = {v: k for k, v in _RES.items()}
+    inv_attn = {"norm": "group_norm", "q": "query", "k": "key", "v": "value", "proj_out": "proj_attn"}
+    out = {}
+    for k, v in sd.items():
+        p = k.split(".")
+        suffix = p[-1]
+        if k.startswith("temb.dense.0."):
+            out[f"time_embedding.linear_1.{suffix}"] = v
+        elif k.startswith("temb.dense.1."):
+            out[f"time_embedding.linear_2.{suffix}"] = v
+        elif p[0] in ("conv_in", "conv_out"):
+            out[k] = v
+        elif p[0] == "norm_out":
+            out[f"conv_norm_out.{suffix}"] = v
+        elif p[0] in ("down", "up"):
+            blk = "down_blocks" if p[0] == "down" else "up_blocks"
+            idx = int(p[1]) if p[0] == "down" else nlev - 1 - int(p[1])
+            if p[2] == "block":
+                out[f"{blk}.{idx}.resnets.{p[3]}.{inv_res[p[4]]}.{suffix}"] = v
+            elif p[2] == "attn":
+                if p[4] != "norm" and suffix == "weight":
+                    v = v.reshape(v.shape[0], v.shape[1])
+                out[f"{blk}.{idx}.attentions.{p[3]}.{inv_attn[p[4]]}.{suffix}"] = v
+            elif p[2] == "downsample":
+                out[f"{blk}.{idx}.downsamplers.0.conv.{suffix}"] = v
+            elif p[2] == "upsample":
+                out[f"{blk}.{idx}.upsamplers.0.conv.{suffix}"] = v
+        elif p[0] == "mid":
+            if p[1].startswith("block_"):
+                out[f"mid_block.resnets.{int(p[1][-1]) - 1}.{inv_res[p[2]]}.{suffix}"] = v
+            else:
+                if p[2] != "norm" and suffix == "weight":
+                    v = v.reshape(v.shape[0], v.shape[1])
+                out[f"mid_block.attentions.0.{inv_attn[p[2]]}.{suffix}"] = v
+    return out

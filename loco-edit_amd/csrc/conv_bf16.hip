@@ -483,6 +483,97 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     // epilogue.  D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const long out_plane = (long)a.Hout * a.Wout;
     const bool full_co = (co0 + MT <= a.Cout);
+    if (a.fs_out) {
+        // ---- epilogue with FUSED GroupNorm tangent / cotangent statistics of the consumer norm ----
+        // (needs nsplit == 1, a full cout tile, no accumulate, cpg in {4,8,16,32}: guaranteed by the engine).
+        // Per lane: accumulator pair index ai = i*4 + (r>>2) collects z and xhat*z over the lane's pixels for
+        // the 4 consecutive channels (r&3) of that quad; quads are merged into groups after the lane reduction.
+        float s1[TM * 4], s2[TM * 4], irs[TM * 4];
+#pragma unroll
+        for (int q = 0; q < TM * 4; ++q) { s1[q] = 0.f; s2[q] = 0.f; irs[q] = 1.f; }
+        if (a.fs_kind == 1) {
+#pragma unroll
+            for (int q = 0; q < TM * 4; ++q) {
+                int co = co0 + (wm * TM + (q >> 2)) * 32 + 8 * (q & 3) + 4 * khalf;
+                irs[q] = 1.0f / a.fs_mr[2 * (co / a.fs_cpg) + 1];
+            }
+        }
+        float* ob = a.out + (long)b * a.out_bs;
+        const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+        const float* b2 = a.bias2 ? a.bias2 + (long)b * a.bias2_bs : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int p = (wn * TN + j) * 32 + l31;
+            int ty = p / TW, tx = p - ty * TW;
+            const unsigned pix = (unsigned)((oy0 + ty) * a.Wout + ox0 + tx);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int cob = co0 + (wm * TM + i) * 32 + 4 * khalf;
+                float rv[16];
+                float2 sxv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long off = (long)(cob + (r & 3) + 8 * (r >> 2)) * out_plane + pix;
+                    rv[r] = rb ? rb[off] : 0.f;
+                    sxv[r] = a.fs_sx[off];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cob + (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r] + rv[r];
+                    if (a.bias) v += a.bias[co];
+                    if (b2) v += b2[co];
+                    ob[(long)co * out_plane + pix] = v;
+                    const int q = i * 4 + (r >> 2);
+                    const float z = a.fs_kind == 1 ? v * sxv[r].x * irs[q] : v;
+                    s1[q] += z;
+                    s2[q] += sxv[r].y * z;
+                }
+            }
+        }
+        // reduce over the 32 pixel lanes of each half wave
+#pragma unroll
+        for (int q = 0; q < TM * 4; ++q) {
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                s1[q] += __shfl_xor(s1[q], o, 64);
+                s2[q] += __shfl_xor(s2[q], o, 64);
+            }
+        }
+        // all waves are past their last LDS read of the stage loop once they pass this barrier
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_b);        // [wave][khalf][TM*4][2]
+        if (l31 == 0) {
+#pragma unroll
+            for (int q = 0; q < TM * 4; ++q) {
+                red[((wave * 2 + khalf) * TM * 4 + q) * 2] = s1[q];
+                red[((wave * 2 + khalf) * TM * 4 + q) * 2 + 1] = s2[q];
+            }
+        }
+        __syncthreads();
+        // one thread per channel group of the workgroup's MT couts: sum the quads of the group over the WN waves
+        const int cpg = a.fs_cpg, ngrp = MT / cpg;
+        if (tid < ngrp) {
+            float t1 = 0.f, t2 = 0.f;
+            const int c_lo = tid * cpg;                           // first local cout of the group
+            for (int cl = c_lo; cl < c_lo + cpg; cl += 4) {       // quads of 4 consecutive couts
+                int blk = cl >> 5, rowin = cl & 31;               // 32-cout block, row inside it
+                int wmq = blk / TM, iq = blk - wmq * TM;
+                int kh = (rowin >> 2) & 1, qq = rowin >> 3;       // row = (r&3) + 8*(r>>2) + 4*khalf
+                for (int w2 = 0; w2 < WN; ++w2) {
+                    int wv = wmq * WN + w2;
+                    t1 += red[((wv * 2 + kh) * TM * 4 + iq * 4 + qq) * 2];
+                    t2 += red[((wv * 2 + kh) * TM * 4 + iq * 4 + qq) * 2 + 1];
+                }
+            }
+            const int g = (co0 + c_lo) / cpg;
+            const int npt = (a.Hout * a.Wout) / NT;
+            float* o = a.fs_out + (((long)b * a.fs_G + g) * npt + tile_id) * 2;
+            o[0] = t1;
+            o[1] = t2;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         int p = (wn * TN + j) * 32 + l31;
@@ -612,10 +703,19 @@ int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B) {
     return want < 1 ? 1 : want;
 }
 
-template <int TAPS, int MODE>
-static void launch_tile_b(const ConvArgs& a, hipStream_t st) {
+static int bf16_tile_of(const ConvArgs& a) {
     int tile = conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B * a.nsplit);
     if (a.stride == 2 && (tile == 5 || tile == 4)) tile = 0;   // the double-buffered stride-2 halo of a 256-pixel tile exceeds LDS
+    return tile;
+}
+int conv_bf16_tile_pixels(const ConvArgs& a) {
+    static const int NTs[6] = {128, 64, 128, 64, 256, 256};
+    return NTs[bf16_tile_of(a)];
+}
+
+template <int TAPS, int MODE>
+static void launch_tile_b(const ConvArgs& a, hipStream_t st) {
+    const int tile = bf16_tile_of(a);
     switch (tile) {
         case 4: launch_one_b<TAPS, 2, 2, 2, 4, MODE>(a, st); break;   // 128 x 256, 4 waves (64 x 128 each)
         case 5: launch_one_b<TAPS, 2, 4, 2, 2, MODE>(a, st); break;   // 128 x 256, 8 waves (64 x 64 each)

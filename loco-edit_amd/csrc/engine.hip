@@ -67,6 +67,7 @@ struct Op {
     int heads = 1;                // ATTN
     bool in_is_skip = false;
     bool has_nin = false;
+    bool n1_ready = false;        // per pass: the producer's conv epilogue already delivered norm1's tangent statistics
     // parameter name stems in the reference state_dict
     std::string pn_n1, pn_c1, pn_emb, pn_n2, pn_c2, pn_skip, pn_qkv, pn_proj, pn_conv;
     ConvP c1, c2, nin, qkvc, proj, conv;     // conv: CONV_IN / DOWN / UP / OUT
@@ -760,6 +761,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
                             : conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
     if (a.nsplit < 1) a.nsplit = 1;
+    if (a.nsplit > 1 || c->prec != 1 || a.accumulate) a.fs_out = nullptr;   // fused statistics need the final value in-kernel
     a.partial = c->partial;
     {
         const size_t span = (size_t)c->cfg.max_batch * c->per_sample;
@@ -951,9 +953,39 @@ void set_tan(loco_ctx* c, ConvArgs& a, const NormP& n, const float* prim) {
     a.sx = (n.sx_off >= 0 && c->sxcache) ? c->sxcache + n.sx_off : nullptr;
 }
 
+constexpr size_t RED_BYTES = (size_t)4 << 20;   // reduction scratch (GN partial sums, fused-statistics partials)
+// Fused consumer-norm statistics in a conv epilogue (bf16x3 path): request before run_conv, finalise after.
+bool fuse_request(loco_ctx* c, ConvArgs& a, const NormP& n, int kind) {
+    const int G = c->cfg.gn_groups, cpg = n.C / G;
+    if (c->prec != 1 || n.sx_off < 0 || !c->sxcache) return false;
+    if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) || (a.Cout % 128) != 0 || a.Cout != n.C) return false;
+    // Opt-in (LOCO_FUSED_STATS=1): measured on MI355X the fused epilogue costs more than the separate statistics
+    // kernels save (378.8 vs 349.8 ms/step) -- the {S, xhat} cache read is exposed at one workgroup per CU, while
+    // the stand-alone reduction streams it at full HBM rate.  Kept for conv variants with an overlapped epilogue.
+    static const bool enabled = getenv("LOCO_FUSED_STATS") != nullptr;
+    if (!enabled) return false;
+    const int HW = a.Hout * a.Wout, NT = conv_bf16_tile_pixels(a);
+    if (HW % NT != 0 || (size_t)a.B * G * (HW / NT) * 2 * sizeof(float) > RED_BYTES) return false;
+    NS sp = nstats(c, c->statsP, n);
+    a.fs_out = reinterpret_cast<float*>(c->red);
+    a.fs_sx = c->sxcache + n.sx_off;
+    a.fs_mr = sp.mr; a.fs_cpg = cpg; a.fs_kind = kind; a.fs_G = G;
+    return true;
+}
+void fuse_finalize(loco_ctx* c, const ConvArgs& a, const NormP& n, int kind, hipStream_t st) {
+    const int G = c->cfg.gn_groups, cpg = n.C / G;
+    const int HW = a.Hout * a.Wout;
+    const int NT = conv_bf16_tile_pixels(a);
+    NS sp = nstats(c, c->statsP, n);
+    NS stt = nstats(c, c->statsT, n);
+    launch_fs_finalize(a.fs_out, HW / NT, a.B, G, cpg, 1.0 / ((double)cpg * HW), sp.mr, kind, stt.tst, stt.tc,
+                       c->stats_per_sample, st);
+}
+
 int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
     const loco_unet_cfg& cfg = c->cfg;
     const long PS = c->per_sample;
+    for (auto& op : c->ops) op.n1_ready = false;
     auto TP = [&](int id) { return c->arenaP + c->tens[id].off; };   // primal
     auto TT = [&](int id) { return c->arenaT + c->tens[id].off; };   // tangent
     for (auto& op : c->ops) {
@@ -971,7 +1003,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
             case OP_RES: {
                 const Tens& ti = c->tens[op.in];
                 const int HWi = ti.H * ti.W;
-                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HWi, B, st);
+                if (!op.n1_ready) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HWi, B, st);
                 ConvArgs a; conv_defaults(a);
                 a.Cin = ti.C;
                 setw(a, op.c1, false);
@@ -992,8 +1024,10 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                     }
                 }
                 a.out = TT(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                fuse_request(c, a, op.n2, 0);
                 run_conv(c, a, 9, st);
-                tangent_stats(c, op.n2, TT(op.h1), PS, TP(op.h1), HW, B, st);
+                if (a.fs_out) fuse_finalize(c, a, op.n2, 0, st);
+                else tangent_stats(c, op.n2, TT(op.h1), PS, TP(op.h1), HW, B, st);
                 const float* xin = op.updown ? TT(op.xu) : TT(op.in);
                 const float* res = xin;
                 if (op.has_nin) {
@@ -1009,7 +1043,14 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 setw(b, op.c2, false); b.res = res; b.res_bs = PS;
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.out = TT(op.out); b.out_bs = PS; b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
-                run_conv(c, b, 9, st);
+                {
+                    // the block output feeds the next op's norm1 when that op reads exactly this tensor (no concat)
+                    Op* nxt = (&op - &c->ops[0] + 1 < (long)c->ops.size()) ? &op + 1 : nullptr;
+                    bool want = nxt && nxt->in == op.out && (nxt->kind == OP_RES || nxt->kind == OP_OUT);
+                    if (want) want = fuse_request(c, b, nxt->n1, 0);
+                    run_conv(c, b, 9, st);
+                    if (want && b.fs_out) { fuse_finalize(c, b, nxt->n1, 0, st); nxt->n1_ready = true; }
+                }
                 break;
             }
             case OP_ATTN: {
@@ -1063,7 +1104,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
             }
             case OP_OUT: {
                 const Tens& ti = c->tens[op.in];
-                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), ti.H * ti.W, B, st);
+                if (!op.n1_ready) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), ti.H * ti.W, B, st);
                 ConvArgs a; conv_defaults(a);
                 a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false);
@@ -1104,8 +1145,10 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 a.in = ge; a.in_bs = c->n_in; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
                 setw(a, op.conv, true);
                 a.out = TG(op.a1); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
+                fuse_request(c, a, op.n1, 1);
                 run_conv(c, a, 9, st);
-                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), ti.H * ti.W, B, 1, st);
+                if (a.fs_out) fuse_finalize(c, a, op.n1, 1, st);
+                else cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), ti.H * ti.W, B, 1, st);
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 0, B, ti.C, ti.H * ti.W, G,
@@ -1139,8 +1182,10 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
                 setw(a, op.c2, true);
                 a.out = TG(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                fuse_request(c, a, op.n2, 1);
                 run_conv(c, a, 9, st);
-                cot_stats(c, op.n2, TG(op.h1), PS, TP(op.h1), HW, B, 1, st);
+                if (a.fs_out) fuse_finalize(c, a, op.n2, 1, st);
+                else cot_stats(c, op.n2, TG(op.h1), PS, TP(op.h1), HW, B, 1, st);
                 // dgrad conv1 of the norm2/silu cotangent of g_a2 (fused in the staging), at conv1's resolution
                 ConvArgs b; conv_defaults(b);
                 b.in = TG(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
@@ -1148,9 +1193,12 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.mode = CM_COT_SILU;
                 b.out_bs = PS; b.Cout = ti.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
+                bool n1_fused = false;
                 if (op.updown == 0) {
                     b.out = TG(op.a1);
+                    fuse_request(c, b, op.n1, 1);
                     run_conv(c, b, 9, st);
+                    if (b.fs_out) { fuse_finalize(c, b, op.n1, 1, st); n1_fused = true; }
                 } else if (op.updown == 1) {
                     b.out = TG(op.ap);                                     // cotangent of the pooled activation
                     run_conv(c, b, 9, st);
@@ -1160,7 +1208,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                     run_conv(c, b, 9, st);
                     launch_pool2x2_sum(TG(op.xu), PS, TG(op.a1), PS, 0, B, ti.C, ti.H, ti.W, st);           // nearest^T
                 }
-                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), HWi, B, 1, st);
+                if (!n1_fused) cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), HWi, B, 1, st);
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 int acc = op.in_is_skip ? 1 : 0;
@@ -1293,7 +1341,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         c->arenaP = p0 + 64; c->arenaT = p1 + 64;
     }
     if (dalloc(c, &c->statsP, MB * c->stats_per_sample) || dalloc(c, &c->statsT, MB * c->stats_per_sample)) return -1;
-    if (dalloc(c, &c->red, (size_t)1 << 20)) return -1;
+    if (dalloc(c, &c->red, RED_BYTES)) return -1;
     c->partial_floats = (size_t)64 << 20;   // 256 MB split-K workspace
     if (dalloc(c, &c->partial, c->partial_floats)) return -1;
     if (dalloc(c, &c->eps_buf, MB * c->n_in) || dalloc(c, &c->gx0, MB * c->n_in) || dalloc(c, &c->ge, MB * c->n_in))

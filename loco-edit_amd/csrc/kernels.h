@@ -43,6 +43,9 @@ struct ConvArgs {
     int pad;         // top/left zero padding in input coords (1: 3x3 s1, 0: 3x3 s2 / 1x1, 2: zero-insert dgrad)
     int upsample;    // input is read through a nearest x2 upsample
     int zins;        // input is read through stride-2 zero insertion (dgrad of the stride-2 conv)
+    // fused statistics of the consumer GroupNorm in the epilogue (bf16x3 path): partial sums of z and xhat*z per
+    // (b, group, pixel tile) -> fs_out[((b*fs_G + g)*ntile + tile)*2]; z = out (fs_kind 0) or out*S/rstd (fs_kind 1)
+    float* fs_out; const float2* fs_sx; const float* fs_mr; int fs_cpg, fs_kind, fs_G;
     int in_padded;   // `in` (and `sx`) live in a padded engine arena: 16-byte loads may start 1 float before / end 3 after a plane
     int accumulate;  // out += result
     int nsplit;      // split-K factor (>1: raw partials go to `partial`, epilogue by conv_splitk_reduce)
@@ -65,6 +68,8 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec);
 size_t conv_partial_floats(const ConvArgs& a);
 int conv_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int taps);
 int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B);
+int conv_bf16_pick_tile(int Cout, int HW, int Bsplit);
+int conv_bf16_tile_pixels(const ConvArgs& a);
 
 // Generic strided batched GEMM  C[b](m,n) = alpha * sum_k A[b](m,k) B[b](k,n) + beta*C + bias[m] + R[b](m,n)
 struct GemmArgs {
@@ -102,6 +107,9 @@ void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int 
 //   kind 3: out (+)= base + rstd*(gamma*d - m1 - xh*m2)           (attention norm cotangent)
 //   kind 4: out = silu(sc*x + sh)                                  (activation ahead of an avg-pool, ADM down block)
 //   kind 5: out = silu'(y)*sc*(d - m1 - xh*m2)                     (its tangent)
+// finalise fused conv-epilogue statistics: sums the per-tile partials, writes tst {m1,m2} and the per-channel tc
+void launch_fs_finalize(const float* part, int ntile, int B, int G, int cpg, double inv_n, const float* mr, int kind,
+                        float* tst, float* tc, long tbs, hipStream_t st);
 void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x_bs,
                      const float* base, long base_bs, float* out, long out_bs, int accumulate,
                      int B, int C, int HW, int G, const float* sc, const float* sh, const float* mr,

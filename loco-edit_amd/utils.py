@@ -56,6 +56,9 @@ def get_custom_diffusion_model(args) -> HipUNet:
         sd = torch.load(ckpt, map_location="cpu")
         if "state_dict" in sd:
             sd = sd["state_dict"]
+        from .checkpoints import hf_unet2d_to_vendored, is_hf_unet2d
+        if is_hf_unet2d(sd):          # diffusers UNet2DModel naming (google/ddpm-*-256): map to the vendored keys
+            sd = hf_unet2d_to_vendored(sd, cfg)
         engine.load_state_dict(sd)
     else:
         seed = getattr(args, "synthetic_weights", None)

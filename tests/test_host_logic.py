@@ -99,3 +99,19 @@ def test_edit_batch_alphas():
     assert got["a"] == [-8.0, -4.0, 0.0, 4.0, 8.0]
     e.edit_batch(torch.zeros(1, 3, 4, 4), torch.zeros(48), 1)
     assert got["a"] == [-8.0, 0.0, 8.0]
+
+
+def test_hf_key_map_round_trip():
+    """diffusers UNet2DModel <-> vendored DDPM key map (row a15; self-consistency only, parity unpinned)."""
+    from loco_edit_amd.checkpoints import hf_unet2d_to_vendored, is_hf_unet2d, vendored_to_hf_unet2d
+    from loco_edit_amd.config import synth_params
+    sd = {k: torch.from_numpy(v) for k, v in synth_params(TINY_DDPM, 0).items()}
+    hf = vendored_to_hf_unet2d(sd, TINY_DDPM)
+    assert is_hf_unet2d(hf) and not is_hf_unet2d(sd)
+    assert "down_blocks.1.attentions.0.query.weight" in hf and hf["down_blocks.1.attentions.0.query.weight"].dim() == 2
+    assert "up_blocks.0.resnets.2.conv_shortcut.weight" in hf and "mid_block.resnets.1.time_emb_proj.bias" in hf
+    back = hf_unet2d_to_vendored(hf, TINY_DDPM)
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    bad = dict(hf); bad.pop("conv_norm_out.bias"); bad["conv_norm_out.weight"] = hf["conv_norm_out.weight"]
+    with pytest.raises(KeyError):
+        hf_unet2d_to_vendored(bad, TINY_DDPM)
