@@ -15,18 +15,33 @@
 // pixels / couts is bank-conflict free.  Next stage's global loads are issued
 // before the MFMA block of the current one.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace loco {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef LOCO_EXP
+#define LOCO_EXP 0     // development: what-if variants that drop one ingredient of the stage (timing only, wrong results)
+#endif
 constexpr int BKC = 16;
+#ifdef LOCO_DEV_TILE0
+constexpr int NDUMMY = 0;   // (timing experiment only: invalid lanes clobber record 0)
+#else
+constexpr int NDUMMY = 8;
+#endif
+//   // spare halo records per buffer: non-participating lanes store there instead of branching
 
 __device__ __forceinline__ float sigmoidf2_(float y) { return 1.0f / (1.0f + __expf(-y)); }
 
 // byte offset of logical 16-byte chunk q (0..3) inside the 64-byte record of index p
 __device__ __forceinline__ int rec_off(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
+// Halo records use a PADDED pitch instead of the XOR swizzle: 80 bytes = 20 dwords, so 16 consecutive records hit 16
+// disjoint 4-dword bank groups (ds_read_b128 conflict-free) AND the offset stays affine in the record index -- a tap
+// shift is then a wave-uniform addend, where the swizzle needed one precomputed VGPR offset per (tap, operand).
+constexpr int HP = 80;
+__device__ __forceinline__ int hrec_off(int p, int q) { return p * HP + (q << 4); }
 
 __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
     unsigned h[8], l[8];
@@ -53,7 +68,11 @@ constexpr int max_halo(int NT, int taps, bool s2) {
 }
 
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
+#ifdef LOCO_DEV_TILE0
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_bf16x3(ConvArgs a) {
+#else
 __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
+#endif
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = WM * TM * 32;
     constexpr int NT = WN * TN * 32;
@@ -100,17 +119,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         if ((NTC & 7) == 0) { int q = L >> 3; zid = q % Z; T = (q / Z) * 8 + (L & 7); }
         else { zid = L % Z; T = L / Z; }
         tile_id = T % ntile; cot_id = T / ntile;
+        // integer division runs on the VALU: pin the (wave-uniform) results back into SGPRs so everything derived
+        // from them (chunk range, tile origin, batch bases) is scalar arithmetic and saddr-form addressing
+        tile_id = __builtin_amdgcn_readfirstlane(tile_id);
+        cot_id = __builtin_amdgcn_readfirstlane(cot_id);
+        zid = __builtin_amdgcn_readfirstlane(zid);
     }
-    const int oy0 = (tile_id / tiles_x) * TH;
-    const int ox0 = (tile_id % tiles_x) * TW;
+    const int oy0 = __builtin_amdgcn_readfirstlane((tile_id / tiles_x) * TH);
+    const int ox0 = __builtin_amdgcn_readfirstlane((tile_id % tiles_x) * TW);
     const int co0 = cot_id * MT;
-    const int b = zid / a.nsplit;
-    const int split = zid % a.nsplit;
+    const int b = __builtin_amdgcn_readfirstlane(zid / a.nsplit);
+    const int split = __builtin_amdgcn_readfirstlane(zid % a.nsplit);
 
     const int halo_w = (TW - 1) * S + KS;
     const int halo_h = (TH - 1) * S + KS;
     const int halo_sz = halo_h * halo_w;
-    const int HBYTES = halo_sz * 64;
+    const int HBYTES = (halo_sz + NDUMMY) * HP;     // + dump records for the lanes without a halo item
     Hsb = smem_b + 2 * WBYTES;
 
     const int LH = (a.upsample || a.zins) ? a.Hin * 2 : a.Hin;
@@ -148,6 +172,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     const int nseg = (halo_w + 3) >> 2;
     int v_q4 = 0, v_pos0 = -1, v_voff = 0, v_cnt = 0;
     unsigned v_pm = 0;                       // per-pixel validity bits
+    int v_rec[4] = {0, 0, 0, 0};             // LDS record of each of the 4 pixels (a dump record when not staged)
+    unsigned v_goff = 0;                     // byte offset of the item's first pixel / channel from (chunk base - 16 floats)
     if constexpr (!GEN) {
         const int per_q = halo_h * nseg;
         if (tid < 4 * per_q) {
@@ -163,6 +189,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
             for (int pxi = 0; pxi < 4; ++pxi)
                 if (rowok && X0 + pxi >= 0 && X0 + pxi < a.Win && pxi < v_cnt) v_pm |= 1u << pxi;
         }
+#pragma unroll
+        for (int pxi = 0; pxi < 4; ++pxi)
+            v_rec[pxi] = (v_pos0 >= 0 && pxi < v_cnt) ? v_pos0 + pxi : (NDUMMY ? halo_sz + (tid & (NDUMMY - 1)) : 0);
+        // the row start may sit one float before the plane (left border): bias by 16 floats so the offset stays >= 0
+        v_goff = (unsigned)(((long)v_q4 * 4 * in_plane + v_voff + 16) * 4);
     }
 
     int hoff[TN];
@@ -172,6 +203,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         int ty = p / TW, tx = p - ty * TW;
         hoff[j] = ty * S * halo_w + tx * S;
     }
+    int hbyte[TN];                           // byte offset of the lane's hi operand chunk inside a halo buffer
+#pragma unroll
+    for (int j = 0; j < TN; ++j) hbyte[j] = hrec_off(hoff[j], khalf);
     // A-operand (weight) record offsets inside one tap block: cout-local index fixed per lane
     int aoff_hi[TM], aoff_lo[TM];
 #pragma unroll
@@ -190,7 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nchunks = (a.Cin + BKC - 1) / BKC;
-    const int cps = (nchunks + a.nsplit - 1) / a.nsplit;
+    const int cps = __builtin_amdgcn_readfirstlane((nchunks + a.nsplit - 1) / a.nsplit);
     const int cbeg = split * cps;
     const int cend = (cbeg + cps < nchunks) ? cbeg + cps : nchunks;
 
@@ -203,92 +237,86 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
 
     float hv[NITEM][8];
     float2 pv[NEEDP ? NITEM : 1][8];
-    uint4 wv[NWV];
     // per-channel constants of the chunk in flight: wave-uniform (scalar loads), selected per lane by octet
     float cA[(MODE == CM_NONE) ? 1 : 16], cB[(MODE == CM_NONE) ? 1 : 16];
     const float* tcb = NEEDP ? a.tc + (long)b * a.tc_bs : nullptr;   // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent)
 
-    float4 hq[GEN ? 1 : 4];                       // !GEN: [channel k][4 pixels]
-    float4 pq[(!GEN && NEEDP) ? 4 : 1][2];        // {S, xhat} of the 4 pixels: 32 bytes per channel
-    float4 cq[(!GEN && MODE != CM_NONE) ? 2 : 1]; // per-channel constants of the 4 channels
-    auto prefetch_hv = [&](int chunk) {
-        const int c0 = chunk * BKC + v_q4 * 4;    // first channel of this thread's quarter chunk
-        const float* pk = inb + (long)c0 * in_plane + v_voff;
+    // !GEN: the item (4 channels x 4 pixels) is staged in NPART parts of KP channels, one part per weight stage, so
+    // only KP channels are live in registers at a time (3x3: 2 parts of 2 channels; 1x1: the whole item).  Parts
+    // split the CHANNELS, not the pixels: every load stays a full 16-byte run of 4 pixels.
+    constexpr int NPART = (!GEN && NROW == 3) ? 2 : 1;
+    constexpr int KP = 4 / NPART;
+    float dq[GEN ? 1 : KP][4];                    // !GEN: [channel of the part][pixel]
+    float2 sq[(!GEN && NEEDP) ? KP : 1][4];       // {S, xhat} of those pixels
+    float cqa[(!GEN && MODE != CM_NONE) ? KP : 1], cqb[(!GEN && MODE != CM_NONE) ? KP : 1];   // per-channel constants
+    auto prefetch_hv = [&](int chunk, int part) {
+        // wave-uniform chunk base (SGPR pair) + 32-bit per-lane byte offset: global_load saddr form, no 64-bit VALU
+        // (32-bit scalar offset arithmetic: one sample's tensor is far below 4 GB)
+        const unsigned cb = (unsigned)chunk * ((unsigned)(BKC * 4) * (unsigned)in_plane);
+        const char* pk = reinterpret_cast<const char*>(inb - 16) + cb;
+        const char* sk = reinterpret_cast<const char*>(reinterpret_cast<const float*>(sxb) - 32) + 2u * cb;
+        const unsigned pl = (unsigned)in_plane * 4u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // 4-byte aligned 16-byte load (global memory tolerates dword alignment)
-            float4 v;
-            __builtin_memcpy(&v, pk + (long)k * in_plane, 16);
-            hq[k] = v;
-            if constexpr (NEEDP) {
-                const float* sk = reinterpret_cast<const float*>(sxb) + 2 * ((long)(c0 + k) * in_plane + v_voff);
-                float4 s0, s1;
-                __builtin_memcpy(&s0, sk, 16);
-                __builtin_memcpy(&s1, sk + 4, 16);
-                pq[k][0] = s0; pq[k][1] = s1;
-            }
+        for (int kk = 0; kk < KP; ++kk) {
+            const unsigned po = v_goff + (unsigned)(part * KP + kk) * pl;
+            // 4-byte aligned 16-byte loads (global memory tolerates dword alignment)
+            __builtin_memcpy(&dq[kk][0], pk + po, 16);
+            if constexpr (NEEDP) __builtin_memcpy(&sq[kk][0], sk + 2u * po, 32);
         }
+        const int c0 = chunk * BKC + v_q4 * 4 + part * KP;    // first channel of this part
         if constexpr (MODE != CM_NONE) {
-            if constexpr (NEEDP) {      // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent) of channels c0..c0+3
-                cq[0] = *reinterpret_cast<const float4*>(tcb + 2 * c0);
-                cq[1] = *reinterpret_cast<const float4*>(tcb + 2 * c0 + 4);
+            if constexpr (NEEDP) {      // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent) per channel
+                float t[2 * KP];
+                __builtin_memcpy(t, tcb + 2 * c0, sizeof(t));
+#pragma unroll
+                for (int kk = 0; kk < KP; ++kk) { cqa[kk] = t[2 * kk]; cqb[kk] = t[2 * kk + 1]; }
             } else {
-                cq[0] = *reinterpret_cast<const float4*>(scb + c0);
-                cq[1] = *reinterpret_cast<const float4*>(shb + c0);
+                __builtin_memcpy(cqa, scb + c0, sizeof(float) * KP);
+                __builtin_memcpy(cqb, shb + c0, sizeof(float) * KP);
             }
         }
     };
-    auto stage_hv = [&]() {
-        if (v_pos0 < 0) return;
-        const float hvv[4][4] = {{hq[0].x, hq[0].y, hq[0].z, hq[0].w}, {hq[1].x, hq[1].y, hq[1].z, hq[1].w},
-                                 {hq[2].x, hq[2].y, hq[2].z, hq[2].w}, {hq[3].x, hq[3].y, hq[3].z, hq[3].w}};
-        float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE != CM_NONE) {
-            if constexpr (NEEDP) {
-                ca[0] = cq[0].x; cb[0] = cq[0].y; ca[1] = cq[0].z; cb[1] = cq[0].w;
-                ca[2] = cq[1].x; cb[2] = cq[1].y; ca[3] = cq[1].z; cb[3] = cq[1].w;
-            } else {
-                ca[0] = cq[0].x; ca[1] = cq[0].y; ca[2] = cq[0].z; ca[3] = cq[0].w;
-                cb[0] = cq[1].x; cb[1] = cq[1].y; cb[2] = cq[1].z; cb[3] = cq[1].w;
-            }
-        }
+    auto stage_hv = [&](int part) {
         const int oct = v_q4 >> 1, half = v_q4 & 1;
 #pragma unroll
         for (int pxi = 0; pxi < 4; ++pxi) {
-            if (pxi >= v_cnt) break;
-            float r[4];
+            float r[KP];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float d = hvv[k][pxi];
+            for (int kk = 0; kk < KP; ++kk) {
+                float d = dq[kk][pxi];
                 float v = d;
                 if constexpr (MODE == CM_GN_SILU) {
-                    float y = fmaf(ca[k], d, cb[k]);
+                    float y = fmaf(cqa[kk], d, cqb[kk]);
                     v = y * sigmoidf2_(y);
                 } else if constexpr (MODE == CM_GN) {
-                    v = fmaf(ca[k], d, cb[k]);
+                    v = fmaf(cqa[kk], d, cqb[kk]);
                 } else if constexpr (NEEDP) {
-                    const float4 sv = pq[k][pxi >> 1];
-                    const float Sv = (pxi & 1) ? sv.z : sv.x, xh = (pxi & 1) ? sv.w : sv.y;
-                    if constexpr (MODE == CM_TAN_SILU) v = Sv * (d - ca[k] - xh * cb[k]);
-                    else v = Sv * d - ca[k] - xh * cb[k];
+                    const float Sv = sq[kk][pxi].x, xh = sq[kk][pxi].y;
+                    if constexpr (MODE == CM_TAN_SILU) v = Sv * (d - cqa[kk] - xh * cqb[kk]);
+                    else v = Sv * d - cqa[kk] - xh * cqb[kk];
                 }
-                r[k] = ((v_pm >> pxi) & 1u) ? v : 0.0f;
+                r[kk] = ((v_pm >> pxi) & 1u) ? v : 0.0f;
             }
-            unsigned h[4], l[4];
+            unsigned h[KP], l[KP];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                __bf16 hb = (__bf16)r[k];
-                __bf16 lb = (__bf16)(r[k] - (float)hb);
-                h[k] = __builtin_bit_cast(unsigned short, hb);
-                l[k] = __builtin_bit_cast(unsigned short, lb);
+            for (int kk = 0; kk < KP; ++kk) {
+                __bf16 hb = (__bf16)r[kk];
+                __bf16 lb = (__bf16)(r[kk] - (float)hb);
+                h[kk] = __builtin_bit_cast(unsigned short, hb);
+                l[kk] = __builtin_bit_cast(unsigned short, lb);
             }
-            const int pos = v_pos0 + pxi;
-            *reinterpret_cast<uint2*>(Hs + rec_off(pos, oct) + half * 8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-            *reinterpret_cast<uint2*>(Hs + rec_off(pos, 2 + oct) + half * 8) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+            unsigned char* dst = Hs + hrec_off(v_rec[pxi], oct) + half * 8 + part * (KP * 2);
+            if constexpr (KP == 4) {
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+            } else {
+                *reinterpret_cast<unsigned*>(dst) = h[0] | (h[1] << 16);
+                *reinterpret_cast<unsigned*>(dst + 32) = l[0] | (l[1] << 16);
+            }
         }
     };
-    auto prefetch_h = [&](int chunk) {
-        if constexpr (!GEN) { prefetch_hv(chunk); return; }
+    auto prefetch_h = [&](int chunk, int part) {
+        if constexpr (!GEN) { prefetch_hv(chunk, part); return; }
         const int c0 = chunk * BKC;
         if constexpr (MODE != CM_NONE) {
 #pragma unroll
@@ -328,33 +356,35 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
             }
         }
     };
+    // Weight pieces of this thread: byte offset from the (chunk, row) base.  Records past the padded cout range
+    // are CLAMPED to the last one instead of zeroed: a D row only depends on its own A row, and rows >= Cout are
+    // never stored, so the duplicate is harmless and the loads stay unconditional.
+    // The pre-split, pre-swizzled weight records go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x
+    // 16 bytes land contiguously at a wave-uniform LDS base), so a weight stage costs no VGPRs and no ds_write.
     unsigned wrel[NWV];
-    bool wval[NWV];
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
         int e = tid + i * NTHR;
+        if (e >= WTOT) e = WTOT - 1;
         int tap = e / (MT * 4), rem = e - tap * (MT * 4);
         int rec = co0 + (rem >> 2);
-        wval[i] = (e < WTOT) && (rec < wpitch);
-        wrel[i] = wval[i] ? (unsigned)((tap * wpitch + rec) * 4 + (rem & 3)) : 0u;
+        if (rec >= wpitch) rec = wpitch - 1;
+        wrel[i] = (unsigned)((tap * wpitch + rec) * 4 + (rem & 3)) * 16u;
     }
-    auto prefetch_w = [&](int chunk, int row) {
-        const uint4* wbase = wg + ((long)chunk * TAPS + row * NTS) * wpitch * 4;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef const __attribute__((address_space(1))) unsigned char glb_u8;
+    auto dma_w = [&](int chunk, int row, unsigned char* Wdst) {
+        const unsigned char* wbase = reinterpret_cast<const unsigned char*>(wg) +
+                                     (unsigned)(chunk * TAPS + row * NTS) * ((unsigned)wpitch * 64u);
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
-            uint4 v = wbase[wrel[i]];
-            wv[i] = wval[i] ? v : make_uint4(0u, 0u, 0u, 0u);
+            const int e0 = (wave * 64 + i * NTHR);                 // first piece of this wave's 1 KiB slab
+            if ((WTOT % NTHR) == 0 || e0 < WTOT)                   // wave-uniform
+                __builtin_amdgcn_global_load_lds((glb_u8*)(wbase + wrel[i]), (lds_u8*)(Wdst + e0 * 16), 16, 0, 0);
         }
     };
-    auto stage_w = [&]() {
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            int e = tid + i * NTHR;
-            if (e < WTOT) *reinterpret_cast<uint4*>(Ws + (long)e * 16) = wv[i];
-        }
-    };
-    auto stage_h = [&](int chunk) {
-        if constexpr (!GEN) { stage_hv(); return; }
+    auto stage_h = [&](int chunk, int part) {
+        if constexpr (!GEN) { stage_hv(part); return; }
         const int c0 = chunk * BKC;
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
@@ -387,43 +417,51 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
             }
             uint4 hi, lo;
             split8(v, hi, lo);
-            *reinterpret_cast<uint4*>(Hs + rec_off(ipos[i], ioct[i])) = hi;
-            *reinterpret_cast<uint4*>(Hs + rec_off(ipos[i], 2 + ioct[i])) = lo;
+            *reinterpret_cast<uint4*>(Hs + hrec_off(ipos[i], ioct[i])) = hi;
+            *reinterpret_cast<uint4*>(Hs + hrec_off(ipos[i], 2 + ioct[i])) = lo;
         }
     };
 
-    auto mfma_stage = [&](int row) {
+    // MFMA operand fragments of one tap; two sets alternate so the ds_reads of tap t+1 are in flight under the
+    // MFMAs of tap t (one exposed LDS latency per stage instead of one per operand)
+    struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+    auto load_frag = [&](Frag& f, int row, int tp) {
+        const int tapoff = (TAPS == 9) ? row * halo_w + tp : 0;
 #pragma unroll
-        for (int tp = 0; tp < NTS; ++tp) {
-            const int tapoff = (TAPS == 9) ? row * halo_w + tp : 0;
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        for (int i = 0; i < TM; ++i) {
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_hi[i]);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_lo[i]);
+        }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_hi[i]);
-                al[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_lo[i]);
-            }
+        for (int j = 0; j < TN; ++j) {
+            const unsigned char* hp = Hs + tapoff * HP + hbyte[j];     // uniform tap shift + per-lane record base
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(hp);
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(hp + 32);
+        }
+    };
+    auto mma_frag = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                int p = hoff[j] + tapoff;
-                bh[j] = *reinterpret_cast<const bf16x8*>(Hs + rec_off(p, khalf));
-                bl[j] = *reinterpret_cast<const bf16x8*>(Hs + rec_off(p, 2 + khalf));
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
     };
 
-    // Software pipeline with ONE barrier per stage (s = 3*chunk + row): while the MFMA block of stage s reads
-    // W[s&1] / H[chunk&1], the same phase writes the weights of stage s+1 into W[(s+1)&1] (and, on the last row of
-    // a chunk, the next chunk's halo into H[(chunk+1)&1]) from registers loaded one stage earlier, and issues the
-    // global loads of stage s+2.  Buffers written in stage s were last read in stage s-1, which every wave has
-    // left (barrier); everything read in stage s was written before that barrier.
+    // Software pipeline with ONE barrier per stage (s = NROW*chunk + row).  Stage s multiplies out of W[s&1] /
+    // H[chunk&1].  It opens by launching the LDS-DMA of stage s+1's weights into W[(s+1)&1]; between its taps it
+    // converts one part of the NEXT chunk's halo (loaded into registers at the end of an earlier stage) into
+    // H[(chunk+1)&1]; it closes with vmcnt(0) (the DMA, issued a whole stage ago, has landed), the register loads of
+    // the next halo part, and a RAW barrier so those loads stay in flight across it.  Buffers written in stage s
+    // were last read in stage s-1, which every wave has left; everything read in stage s was complete before the
+    // barrier that opened it.  The stage body is BRANCH-FREE (one basic block): past the end the loads are clamped
+    // to the last chunk and the stores land in buffers nobody reads, so the scheduler can sink the staging VALU /
+    // LDS-write work into the shadow of the MFMAs.
+    //   halo schedule, 3x3 vector path (2 parts A,B):  row0: store A | load B   row1: store B   row2: load A'
+    //   3x3 per-pixel path (1 part):                   row0: load           row2: store
+    //   1x1:                                           every stage: store | load
 #ifdef LOCO_STAMP
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_readcyclecounter();
@@ -432,45 +470,81 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
 #define STAMP(i)
 #endif
     const int nch = cend - cbeg;
+    const int clast = cend - 1;
+    auto cclamp = [&](int c) { return __builtin_amdgcn_readfirstlane(c < clast ? c : clast); };   // keep it scalar
+    auto stage_end = [&]() {
+        // all LDS writes of this wave retired, LDS-DMA landed; then a bare s_barrier (no vmcnt drain of newer loads)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     if (nch > 0) {
-        prefetch_h(cbeg);
-        prefetch_w(cbeg, 0);
-        Ws = Wsb; Hs = Hsb;
-        stage_w();
-        stage_h(cbeg);
-        if (NROW > 1) prefetch_w(cbeg, 1); else if (nch > 1) prefetch_w(cbeg + 1, 0);
-        if (nch > 1) prefetch_h(cbeg + 1);
-        __syncthreads();
+        dma_w(cbeg, 0, Wsb);
+        Hs = Hsb;
+#pragma unroll
+        for (int part = 0; part < NPART; ++part) {
+            prefetch_h(cbeg, part);
+            stage_h(cbeg, part);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NROW == 1 || NPART == 2) prefetch_h(cclamp(cbeg + 1), 0);      // pending part expected by the first stage
+        stage_end();
     }
     for (int ci = 0; ci < nch; ++ci) {
         const int chunk = cbeg + ci;
 #pragma unroll
         for (int row = 0; row < NROW; ++row) {
             const int s_ = ci * NROW + row;
-            const bool last_row = (row == NROW - 1);
-            const bool more = !(last_row && ci + 1 >= nch);          // a stage s+1 exists
+            unsigned char* const Wcur = Wsb + (s_ & 1) * WBYTES;
+            unsigned char* const Wnxt = Wsb + ((s_ + 1) & 1) * WBYTES;
+            unsigned char* const Hcur = Hsb + (ci & 1) * HBYTES;
+            unsigned char* const Hnxt = Hsb + ((ci + 1) & 1) * HBYTES;
+            // which halo part of the next chunk this row converts (-1: none) and which it loads at its end
+            constexpr bool one = (NROW == 1);
+            const int st_part = one ? 0 : (NPART == 2 ? (row == 0 ? 0 : row == 1 ? 1 : -1) : (row == 2 ? 0 : -1));
+            // vector path: a part's registers are re-loaded right after they are converted (mid-stage), so the
+            // loads have one to two whole stages to land; per-pixel path: loads at the end of row 0
+            const int ld_part = one ? 0 : (NPART == 2 ? (row == 0 ? 1 : row == 1 ? 0 : -1) : (row == 0 ? 0 : -1));
+            const int ld_chunk = one ? chunk + 2 : ((NPART == 2 && row == 1) ? chunk + 2 : chunk + 1);
+            constexpr bool MIDLOAD = !GEN;          // issue the loads inside the stage, behind the conversion
+            // vector-memory instructions of one part's loads (for the counted wait that leaves them in flight)
+            constexpr int NLD = KP + (NEEDP ? 2 * KP + 1 : (MODE != CM_NONE ? 2 : 0));
             STAMP(0)
-            if (more) {                                              // registers hold the weights of stage s+1
-                Ws = Wsb + ((s_ + 1) & 1) * WBYTES;
-                stage_w();
-                if (last_row) { Hs = Hsb + ((ci + 1) & 1) * HBYTES; stage_h(chunk + 1); }
+            // Regions fenced by sched_barrier(0): the machine scheduler would otherwise sink every ds_read to just
+            // before its first use and expose one LDS latency per operand.
+            {
+                const int r1 = (row + 1) % NROW, dc = (row + 1) / NROW;
+                if (!(LOCO_EXP & 8)) dma_w(cclamp(chunk + dc), r1, Wnxt);
             }
+            Ws = Wcur; Hs = Hcur;
+            Frag f0, f1;
+#define X_MMA(f) do { if (!(LOCO_EXP & 1)) mma_frag(f); } while (0)
+#define X_LOAD(f, r, t) do { if (!(LOCO_EXP & 4) || (ci == 0 && r == 0)) load_frag(f, r, t); } while (0)
+            X_LOAD(f0, row, 0);
+            if (NTS > 1) X_LOAD(f1, row, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            X_MMA(f0);
             STAMP(1)
-            // loads of stage s+2 (weights) and of chunk+2 (halo, once its registers are free)
-            if (row + 2 < NROW) prefetch_w(chunk, row + 2);
-            else if (ci + 1 < nch) {
-                const int r2 = row + 2 - NROW;
-                if (r2 < NROW) prefetch_w(chunk + 1, r2);
-                else if (ci + 2 < nch) prefetch_w(chunk + 2, r2 - NROW);
-            }
-            if (last_row && ci + 2 < nch) prefetch_h(chunk + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NTS > 2) X_LOAD(f0, row, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NTS > 1) X_MMA(f1);
+            if (!(LOCO_EXP & 2) && st_part >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), st_part); Hs = Hcur; }   // VALU under tap 1's MFMAs
             STAMP(2)
-            Ws = Wsb + (s_ & 1) * WBYTES;
-            Hs = Hsb + (ci & 1) * HBYTES;
-            mfma_stage(row);
+            __builtin_amdgcn_sched_barrier(0);       // (also keeps the re-load below from being hoisted above the conversion's wait)
+            if (MIDLOAD && !(LOCO_EXP & 18) && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
             STAMP(3)
-            __syncthreads();
+            if (NTS > 2) X_MMA(f0);
             STAMP(4)
+            __builtin_amdgcn_sched_barrier(0);
+            // the LDS-DMA of this stage (older than the part loads just issued) must have landed before the barrier
+            if (MIDLOAD && ld_part >= 0 && !(LOCO_EXP & 18)) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!MIDLOAD && !(LOCO_EXP & 18) && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+            }
+            if (!(LOCO_EXP & 32)) stage_end();
         }
     }
 #ifdef LOCO_STAMP
@@ -647,7 +721,7 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     int TW = a.Wout < 32 ? a.Wout : 32;
     int TH = NT / TW;
     int halo_w = (TW - 1) * a.stride + KS, halo_h = (TH - 1) * a.stride + KS;
-    size_t lds = 2 * ((size_t)KS * MT * 64 + (size_t)halo_w * halo_h * 64);
+    size_t lds = 2 * ((size_t)KS * MT * 64 + ((size_t)halo_w * halo_h + NDUMMY) * HP);
     dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
     if (lds > 64 * 1024) {
         static bool done = false;
@@ -664,8 +738,10 @@ template <int TAPS, int WM, int WN, int TM, int TN, int MODE>
 static void launch_one_b(const ConvArgs& a, hipStream_t st) {
     const bool general = a.stride != 1 || a.upsample || a.zins || (a.Cin % BKC) != 0 || !a.in_padded;
     if constexpr (MODE == CM_NONE) {
-        // raw inputs: the per-pixel path measures faster than the vector path (no prologue to amortise)
+        // raw inputs: 3x3 convs take the vector path when the layout allows (measured 66.1 -> 62.8 ms/step);
+        // 1x1 convs stay on the per-pixel path (38.1 vs 39.2 ms/step)
         if (a.stride == 2) launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 2>(a, st);
+        else if (TAPS == 9 && !general) launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
         else launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 1>(a, st);
         return;
     }
@@ -727,6 +803,15 @@ static void launch_tile_b(const ConvArgs& a, hipStream_t st) {
 }
 
 void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st) {
+#ifdef LOCO_DEV_ONE   // development aid: instantiate only the dominant variant (fast recompiles for ISA inspection)
+#ifdef LOCO_DEV_TILE0
+    launch_one_b2<9, 2, 2, 2, 2, CM_TAN_SILU, 0>(a, st); (void)taps;
+#elif defined(LOCO_DEV_TILE4)
+    launch_one_b2<9, 2, 2, 2, 4, CM_TAN_SILU, 0>(a, st); (void)taps;
+#else
+    launch_one_b2<9, 2, 4, 2, 2, CM_TAN_SILU, 0>(a, st); (void)taps;
+#endif
+#else
     if (taps == 9) {
         switch (a.mode) {
             case CM_NONE: launch_tile_b<9, CM_NONE>(a, st); break;
@@ -742,6 +827,7 @@ void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st) {
         }
     }
     launch_conv_splitk_reduce(a, st);
+#endif
 }
 
 }  // namespace loco
