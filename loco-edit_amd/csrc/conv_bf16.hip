@@ -483,6 +483,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         Hs = Hsb;
 #pragma unroll
         for (int part = 0; part < NPART; ++part) {
+            if (LOCO_EXP & 128) continue;                         // what-if: no prologue halo
             prefetch_h(cbeg, part);
             stage_h(cbeg, part);
         }
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     // epilogue.  D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const long out_plane = (long)a.Hout * a.Wout;
     const bool full_co = (co0 + MT <= a.Cout);
+    if ((LOCO_EXP & 64) && acc[0][0][0] != 12345.f) return;      // what-if: no epilogue
     if (a.fs_out) {
         // ---- epilogue with FUSED GroupNorm tangent / cotangent statistics of the consumer norm ----
         // (needs nsplit == 1, a full cout tile, no accumulate, cpg in {4,8,16,32}: guaranteed by the engine).
