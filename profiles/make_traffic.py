@@ -10,7 +10,7 @@ under-reports 16-B-per-lane streaming reads by 2x; these kernels read 4 B per la
 import collections, csv, glob, json, os, re, sys
 
 def load(d, cn):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = (glob.glob(os.path.join(d, "*counter_collection.csv")) + glob.glob(os.path.join(d, "*", "*counter_collection.csv")))[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == cn:
@@ -21,7 +21,8 @@ def norm(name):
     m = re.match(r"void loco::(conv_mfma_\w+)<([\d, ]+?)(?:, (?:true|false))?>\(", name)
     if not m:
         return None
-    return f"{m.group(1)}<{m.group(2).replace(' ', '')}>"
+    # bench.py names a variant by <TAPS,WM,WN,TM,TN,MODE>; the staging flavour (7th parameter) is merged
+    return f"{m.group(1)}<{','.join(m.group(2).replace(' ', '').split(',')[:6])}>"
 
 fd, wd, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
@@ -32,7 +33,7 @@ for k in F:
     w = sum(W.get(k, [0])) / max(1, len(W.get(k, [0]))) * 1024
     rows.append((k, len(F[k]), f, w))
     if n:
-        if n in out:   # stride-2 / stride-1 instantiations share a variant name: launch-weighted mean
+        if n in out:   # staging flavours share a variant name: launch-weighted mean
             o = out[n]
             tot = o["launches"] + len(F[k])
             o["bytes"] = (o["bytes"] * o["launches"] + (f + w) * len(F[k])) / tot
