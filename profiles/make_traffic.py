@@ -1,9 +1,11 @@
 """Aggregate two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as the MI355X guide
 prescribes) into profiles/traffic.json: HBM-side bytes per launch for each conv kernel variant.
-Units: FETCH_SIZE / WRITE_SIZE are KiB.  gfx950 caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE
-under-reports 16-B-per-lane streaming reads by 2x; these kernels read 4 B per lane (dword loads, plus
-16-B weight records that hit L2), for which the counter matched the analytical byte count within 3 %
-(see DESIGN.md section 4), so no correction is applied.
+Units: FETCH_SIZE / WRITE_SIZE are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports
+exactly half of the bytes of 16-B-per-lane streaming reads.  The vector-staged conv variants (7th template
+parameter 0) read activations, the primal {S, xhat} cache and the weight records with 16-B-per-lane loads /
+LDS-DMA, so their FETCH bytes are DOUBLED; the per-pixel variants (7th parameter 1, 2) read activations with
+dword loads, for which the raw counter matched the analytical byte count within 3 % in round 1 (DESIGN.md
+section 4) and is left as is.  WRITE_SIZE is exact for these stores.
 
     python profiles/make_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write r01
 """
@@ -27,9 +29,13 @@ def norm(name):
 fd, wd, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 out, rows = {}, []
+def fetch_corr(name):
+    m = re.match(r"void loco::conv_mfma_bf16x3<([\d, ]+)>", name)
+    return 2.0 if m and m.group(1).replace(" ", "").split(",")[-1] == "0" else 1.0
+
 for k in F:
     n = norm(k)
-    f = sum(F[k]) / len(F[k]) * 1024
+    f = sum(F[k]) / len(F[k]) * 1024 * fetch_corr(k)
     w = sum(W.get(k, [0])) / max(1, len(W.get(k, [0]))) * 1024
     rows.append((k, len(F[k]), f, w))
     if n:
@@ -43,7 +49,7 @@ for k in F:
 here = os.path.dirname(os.path.abspath(__file__))
 json.dump({k: round(v["bytes"]) for k, v in out.items()}, open(os.path.join(here, "traffic.json"), "w"), indent=1)
 with open(os.path.join(here, f"{tag}_pmc_traffic_per_kernel.csv"), "w") as fh:
-    fh.write("kernel,launches,fetch_bytes_per_launch,write_bytes_per_launch\n")
+    fh.write("kernel,launches,fetch_bytes_per_launch_corrected,write_bytes_per_launch\n")
     for k, n, f, w in sorted(rows, key=lambda r: -r[1] * (r[2] + r[3])):
         fh.write(f"\"{k}\",{n},{f:.0f},{w:.0f}\n")
 print(json.dumps({k: round(v['bytes'] / 1e6, 1) for k, v in out.items()}, indent=1))
