@@ -115,10 +115,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     {
         const int ntile = (a.Hout * a.Wout) / NT, ncot = (a.Cout + MT - 1) / MT, Z = a.B * a.nsplit;
         const int NTC = ntile * ncot, L = blockIdx.x;
-        int T;
-        if ((NTC & 7) == 0) { int q = L >> 3; zid = q % Z; T = (q / Z) * 8 + (L & 7); }
-        else { zid = L % Z; T = L / Z; }
-        tile_id = T % ntile; cot_id = T / ntile;
+        int T = 0;
+        if ((ntile & 7) == 0) {
+            // same XCD (L mod 8), adjacent in dispatch order: first the cout tiles of one (pixel tile, probe) -- they
+            // read the same input patch -- then the other probes of that pixel tile (same primal cache and weights)
+            int q = L >> 3;
+            cot_id = q % ncot; q /= ncot;
+            zid = q % Z;
+            tile_id = (q / Z) * 8 + (L & 7);
+        } else {
+            if ((NTC & 7) == 0) { int q = L >> 3; zid = q % Z; T = (q / Z) * 8 + (L & 7); }
+            else { zid = L % Z; T = L / Z; }
+            tile_id = T % ntile; cot_id = T / ntile;
+        }
         // integer division runs on the VALU: pin the (wave-uniform) results back into SGPRs so everything derived
         // from them (chunk range, tile origin, batch bases) is scalar arithmetic and saddr-form addressing
         tile_id = __builtin_amdgcn_readfirstlane(tile_id);
@@ -246,10 +255,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     // split the CHANNELS, not the pixels: every load stays a full 16-byte run of 4 pixels.
     constexpr int NPART = (!GEN && NROW == 3) ? 2 : 1;
     constexpr int KP = 4 / NPART;
-    float dq[GEN ? 1 : KP][4];                    // !GEN: [channel of the part][pixel]
-    float2 sq[(!GEN && NEEDP) ? KP : 1][4];       // {S, xhat} of those pixels
-    float cqa[(!GEN && MODE != CM_NONE) ? KP : 1], cqb[(!GEN && MODE != CM_NONE) ? KP : 1];   // per-channel constants
-    auto prefetch_hv = [&](int chunk, int part) {
+    struct HaloRegs {
+        float dq[GEN ? 1 : KP][4];                    // !GEN: [channel of the part][pixel]
+        float2 sq[(!GEN && NEEDP) ? KP : 1][4];       // {S, xhat} of those pixels
+        float cqa[(!GEN && MODE != CM_NONE) ? KP : 1], cqb[(!GEN && MODE != CM_NONE) ? KP : 1];   // per-channel constants
+    };
+    HaloRegs hr;                                      // the part in flight inside the stage loop
+    auto prefetch_hv = [&](HaloRegs& R, int chunk, int part) {
         // wave-uniform chunk base (SGPR pair) + 32-bit per-lane byte offset: global_load saddr form, no 64-bit VALU
         // (32-bit scalar offset arithmetic: one sample's tensor is far below 4 GB)
         const unsigned cb = (unsigned)chunk * ((unsigned)(BKC * 4) * (unsigned)in_plane);
@@ -260,8 +272,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         for (int kk = 0; kk < KP; ++kk) {
             const unsigned po = v_goff + (unsigned)(part * KP + kk) * pl;
             // 4-byte aligned 16-byte loads (global memory tolerates dword alignment)
-            __builtin_memcpy(&dq[kk][0], pk + po, 16);
-            if constexpr (NEEDP) __builtin_memcpy(&sq[kk][0], sk + 2u * po, 32);
+            __builtin_memcpy(&R.dq[kk][0], pk + po, 16);
+            if constexpr (NEEDP) __builtin_memcpy(&R.sq[kk][0], sk + 2u * po, 32);
         }
         const int c0 = chunk * BKC + v_q4 * 4 + part * KP;    // first channel of this part
         if constexpr (MODE != CM_NONE) {
@@ -269,31 +281,31 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
                 float t[2 * KP];
                 __builtin_memcpy(t, tcb + 2 * c0, sizeof(t));
 #pragma unroll
-                for (int kk = 0; kk < KP; ++kk) { cqa[kk] = t[2 * kk]; cqb[kk] = t[2 * kk + 1]; }
+                for (int kk = 0; kk < KP; ++kk) { R.cqa[kk] = t[2 * kk]; R.cqb[kk] = t[2 * kk + 1]; }
             } else {
-                __builtin_memcpy(cqa, scb + c0, sizeof(float) * KP);
-                __builtin_memcpy(cqb, shb + c0, sizeof(float) * KP);
+                __builtin_memcpy(R.cqa, scb + c0, sizeof(float) * KP);
+                __builtin_memcpy(R.cqb, shb + c0, sizeof(float) * KP);
             }
         }
     };
-    auto stage_hv = [&](int part) {
+    auto stage_hv = [&](const HaloRegs& R, int part) {
         const int oct = v_q4 >> 1, half = v_q4 & 1;
 #pragma unroll
         for (int pxi = 0; pxi < 4; ++pxi) {
             float r[KP];
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk) {
-                float d = dq[kk][pxi];
+                float d = R.dq[kk][pxi];
                 float v = d;
                 if constexpr (MODE == CM_GN_SILU) {
-                    float y = fmaf(cqa[kk], d, cqb[kk]);
+                    float y = fmaf(R.cqa[kk], d, R.cqb[kk]);
                     v = y * sigmoidf2_(y);
                 } else if constexpr (MODE == CM_GN) {
-                    v = fmaf(cqa[kk], d, cqb[kk]);
+                    v = fmaf(R.cqa[kk], d, R.cqb[kk]);
                 } else if constexpr (NEEDP) {
-                    const float Sv = sq[kk][pxi].x, xh = sq[kk][pxi].y;
-                    if constexpr (MODE == CM_TAN_SILU) v = Sv * (d - cqa[kk] - xh * cqb[kk]);
-                    else v = Sv * d - cqa[kk] - xh * cqb[kk];
+                    const float Sv = R.sq[kk][pxi].x, xh = R.sq[kk][pxi].y;
+                    if constexpr (MODE == CM_TAN_SILU) v = Sv * (d - R.cqa[kk] - xh * R.cqb[kk]);
+                    else v = Sv * d - R.cqa[kk] - xh * R.cqb[kk];
                 }
                 r[kk] = ((v_pm >> pxi) & 1u) ? v : 0.0f;
             }
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         }
     };
     auto prefetch_h = [&](int chunk, int part) {
-        if constexpr (!GEN) { prefetch_hv(chunk, part); return; }
+        if constexpr (!GEN) { prefetch_hv(hr, chunk, part); return; }
         const int c0 = chunk * BKC;
         if constexpr (MODE != CM_NONE) {
 #pragma unroll
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         }
     };
     auto stage_h = [&](int chunk, int part) {
-        if constexpr (!GEN) { stage_hv(part); return; }
+        if constexpr (!GEN) { stage_hv(hr, part); return; }
         const int c0 = chunk * BKC;
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
@@ -481,11 +493,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     if (nch > 0) {
         dma_w(cbeg, 0, Wsb);
         Hs = Hsb;
+        if constexpr (!GEN && NPART == 2) {
+            // both parts of the first chunk are loaded together (a second register set that only lives here) so the
+            // workgroup pays one memory latency, not two, before its first stage
+            if (!(LOCO_EXP & 128)) {
+                HaloRegs hr2;
+                prefetch_hv(hr, cbeg, 0);
+                prefetch_hv(hr2, cbeg, 1);
+                stage_hv(hr, 0);
+                stage_hv(hr2, 1);
+            }
+        } else {
 #pragma unroll
-        for (int part = 0; part < NPART; ++part) {
-            if (LOCO_EXP & 128) continue;                         // what-if: no prologue halo
-            prefetch_h(cbeg, part);
-            stage_h(cbeg, part);
+            for (int part = 0; part < NPART; ++part) {
+                if (LOCO_EXP & 128) continue;                     // what-if: no prologue halo
+                prefetch_h(cbeg, part);
+                stage_h(cbeg, part);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (NROW == 1 || NPART == 2) prefetch_h(cclamp(cbeg + 1), 0);      // pending part expected by the first stage

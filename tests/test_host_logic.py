@@ -115,3 +115,60 @@ def test_hf_key_map_round_trip():
     bad = dict(hf); bad.pop("conv_norm_out.bias"); bad["conv_norm_out.weight"] = hf["conv_norm_out.weight"]
     with pytest.raises(KeyError):
         hf_unet2d_to_vendored(bad, TINY_DDPM)
+
+
+# ---------------------------------------------------------------------------
+# evaluation harness: SSIM / masked MSE
+def test_eval_ssim_properties_and_scipy_crosscheck():
+    import numpy as np
+    from scipy.ndimage import correlate
+    from loco_edit_amd.eval import ssim
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 40, 48, generator=g) * 255
+    y = (x + 20 * torch.randn(2, 3, 40, 48, generator=g)).clamp(0, 255)
+    assert abs(float(ssim(x, x)) - 1.0) < 1e-12                       # identity
+    sxy, syx = float(ssim(x, y)), float(ssim(y, x))
+    assert abs(sxy - syx) < 1e-12 and 0.0 < sxy < 1.0                 # symmetric, degraded
+    assert float(ssim(x, (x + 60 * torch.randn(x.shape, generator=g)).clamp(0, 255))) < sxy   # monotone in noise
+    # independent restatement with scipy (reflect padding == scipy mode 'mirror'), one image / channel
+    k = np.arange(11) - 5.0
+    w = np.exp(-(k / 1.5) ** 2 / 2); w /= w.sum(); W = np.outer(w, w)
+    a, b = x[0, 0].double().numpy(), y[0, 0].double().numpy()
+    L = max(float(x[:1, :1].max() - x[:1, :1].min()), float(y[:1, :1].max() - y[:1, :1].min()))
+    c1, c2 = (0.01 * L) ** 2, (0.03 * L) ** 2
+    f = lambda z: correlate(z, W, mode="mirror")
+    ma, mb = f(a), f(b)
+    saa, sbb, sab = f(a * a) - ma * ma, f(b * b) - mb * mb, f(a * b) - ma * mb
+    m = ((2 * ma * mb + c1) * (2 * sab + c2)) / ((ma * ma + mb * mb + c1) * (saa + sbb + c2))
+    ref = m[5:-5, 5:-5].mean()
+    assert abs(float(ssim(x[:1, :1], y[:1, :1])) - ref) < 1e-9
+
+
+def test_eval_masked_mse_and_folder_pairing(tmp_path):
+    from loco_edit_amd.eval import masked_mse, evaluate_folders, lpips
+    from loco_edit_amd.utils import save_image
+    x = torch.zeros(1, 3, 8, 8); y = torch.zeros(1, 3, 8, 8)
+    mask = torch.zeros(3, 8, 8, dtype=torch.bool); mask[:, 2:4, 2:6] = True
+    y[0][mask] = 2.0
+    assert float(masked_mse(x, y, mask[None])) == 4.0
+    assert float(masked_mse(x, y, ~mask[None])) == 0.0
+    with pytest.raises(ValueError):
+        masked_mse(x, y, torch.zeros_like(mask)[None])
+    with pytest.raises(NotImplementedError):
+        lpips(x, y)
+    p, o = tmp_path / "p", tmp_path / "o"
+    os.makedirs(p / "mask"); os.makedirs(o)
+    img = torch.rand(3, 16, 16, generator=torch.Generator().manual_seed(1))
+    m16 = torch.zeros(16, 16, dtype=torch.bool); m16[4:8, 4:8] = True
+    for i in range(2):
+        save_image(img[None], str(o / f"{i}.png"), padding=0)
+        e = img.clone(); e[:, 4:8, 4:8] = 1.0 - e[:, 4:8, 4:8]
+        save_image(e[None], str(p / f"{i}.png"), padding=0)
+        torch.save(m16, str(p / "mask" / f"{i}.pt"))
+    r_in = evaluate_folders(str(p), str(o), "mmse")
+    r_out = evaluate_folders(str(p), str(o), "mmse", outside_mask=True)
+    assert r_in["n"] == 2 and r_in["mean"] > 100.0 and r_out["mean"] == 0.0     # 8-bit PNG scale; edit confined to the mask
+    assert 0.0 < evaluate_folders(str(p), str(o), "ssim")["mean"] < 1.0
+    os.rename(str(p / "1.png"), str(p / "2.png"))
+    with pytest.raises(ValueError):
+        evaluate_folders(str(p), str(o), "ssim")
