@@ -1,0 +1,817 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on v_mfma_f32_32x32x16_bf16 with SPLIT-bf16
+// operands ("bf16x3"): every fp32 operand is carried as hi + lo bf16 halves and each
+// product is three MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate).  The dropped
+// lo*lo term and the rounding of lo are <= 2^-16 relative per product, i.e. the
+// result is fp32-faithful to ~1.5e-5 while running on the 2.5 PF/s matrix pipe
+// (effective peak 2500/3 = 833 TF/s vs 157 TF/s for the f32-input MFMA).
+//
+// Structure (same GEMM view as conv.hip: D[cout][pixel]): a workgroup owns MT couts
+// x NT pixels; Cin is walked in chunks of 16 channels (one MFMA k-step).  The halo
+// patch of a chunk is converted ONCE into LDS pixel records [hi k0-7|hi k8-15|lo k0-7|
+// lo k8-15] (80-byte pitch: conflict-free ds_read_b128 with affine offsets) with the
+// GroupNorm/SiLU forward, tangent or cotangent map applied in fp32 BEFORE the split;
+// weights are staged one kernel row (3 taps) at a time from a pre-split, pre-swizzled
+// global layout by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write); their
+// 64-byte records are XOR-swizzled (chunk ^= (index>>2)&3) for the A-operand reads.
+// One raw s_barrier per stage; the stage body is branch-free and fenced into
+// scheduling regions so LDS reads, halo conversion and re-loads sit under the MFMAs
+// (see the pipeline comment in the kernel and profiles/r01_conv_whatif.md).
+//
+// Development switches (never set in the shipped build): LOCO_EXP=<bitmask> drops one
+// ingredient of the stage for what-if timing (results are wrong by construction),
+// LOCO_DEV_ONE / LOCO_DEV_TILE0 / LOCO_DEV_TILE4 instantiate a single variant for
+// fast ISA inspection, LOCO_STAMP records per-phase cycle counters.
+// This header holds the kernel template and its per-(TAPS, MODE) launcher; conv_bf16_inst_*.hip instantiate
+// disjoint subsets so the variants compile in parallel, conv_bf16.hip holds the tile heuristics and the dispatch.
+#pragma once
+#include "kernels.h"
+#include <cstdlib>
+
+namespace loco {
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef LOCO_EXP
+#define LOCO_EXP 0     // development: what-if variants that drop one ingredient of the stage (timing only, wrong results)
+#endif
+constexpr int BKC = 16;
+#ifdef LOCO_DEV_TILE0
+constexpr int NDUMMY = 0;   // (timing experiment only: invalid lanes clobber record 0)
+#else
+constexpr int NDUMMY = 8;   // spare halo records per buffer: lanes without a halo item store there instead of branching
+#endif
+
+__device__ __forceinline__ float sigmoidf2_(float y) { return 1.0f / (1.0f + __expf(-y)); }
+
+// byte offset of logical 16-byte chunk q (0..3) inside the 64-byte record of index p
+__device__ __forceinline__ int rec_off(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
+// Halo records use a PADDED pitch instead of the XOR swizzle: 80 bytes = 20 dwords, so 16 consecutive records hit 16
+// disjoint 4-dword bank groups (ds_read_b128 conflict-free) AND the offset stays affine in the record index -- a tap
+// shift is then a wave-uniform addend, where the swizzle needed one precomputed VGPR offset per (tap, operand).
+constexpr int HP = 80;
+__device__ __forceinline__ int hrec_off(int p, int q) { return p * HP + (q << 4); }
+
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 hb = (__bf16)v[j];
+        float r = v[j] - (float)hb;
+        __bf16 lb = (__bf16)r;
+        h[j] = __builtin_bit_cast(unsigned short, hb);
+        l[j] = __builtin_bit_cast(unsigned short, lb);
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+constexpr int max_halo(int NT, int taps, bool s2) {
+    if (taps == 1) return NT;
+    // TW = 32 (or the image width when smaller); worst case over the supported widths
+    if (NT >= 128) {
+        int th = NT / 32;
+        return s2 ? (2 * th + 1) * 65 : (th + 2) * 34;
+    }
+    return s2 ? 17 * 17 : 10 * 10;   // NT = 64 : 8x8 output tile
+}
+
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
+#ifdef LOCO_DEV_TILE0
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_bf16x3(ConvArgs a) {
+#else
+__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
+#endif
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int MT = WM * TM * 32;
+    constexpr int NT = WN * TN * 32;
+    constexpr int KS = (TAPS == 9) ? 3 : 1;
+    constexpr int NTS = KS;                          // taps per weight stage (one kernel row)
+    constexpr int NROW = (TAPS == 9) ? 3 : 1;        // weight stages per channel chunk
+    constexpr bool NEEDP = (MODE == CM_TAN_SILU || MODE == CM_COT_SILU);
+    // GEN: general per-pixel staging (stride 2, upsample, zero insertion, partial channel chunks, caller-owned
+    // tensors); !GEN: 16-byte loads of 4 consecutive pixels from padded arena tensors (stride-1 convs)
+    // STG 0: vector staging; 1: per-pixel staging, stride 1 (also upsample / zero-insert / partial chunks /
+    // caller-owned tensors); 2: per-pixel staging sized for the stride-2 halo
+    constexpr bool GEN = STG != 0;
+    constexpr int NITEM = GEN ? (2 * max_halo(NT, TAPS, STG == 2) + NTHR - 1) / NTHR : 1;
+    constexpr int WTOT = NTS * MT * 4;               // 16-byte pieces of one weight stage
+    constexpr int NWV = (WTOT + NTHR - 1) / NTHR;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    // double-buffered: weight stage s lives in W buffer s&1, the halo of chunk c in H buffer c&1
+    constexpr int WBYTES = NTS * MT * 64;
+    unsigned char* const Wsb = smem_b;               // 2 x [NTS][MT] records
+    unsigned char* Hsb;                              // 2 x [halo_sz] records (set below, needs halo_sz)
+    unsigned char* Ws = smem_b;                      // W / H buffer the operand reads and the halo conversion address
+    unsigned char* Hs = smem_b;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int khalf = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int S = a.stride;
+    const int TW = a.Wout < 32 ? a.Wout : 32;
+    const int TH = NT / TW;
+    const int tiles_x = a.Wout / TW;
+    // Block order: the probes (and K-splits) of one (pixel tile, cout tile) are adjacent in dispatch order
+    // and land on the same XCD, so the shared primal {S, xhat} cache and the weights of the tile are
+    // served from that XCD's L2 instead of HBM once per probe (blocks L and L+8 share an XCD).
+    int tile_id, cot_id, zid;
+    {
+        const int ntile = (a.Hout * a.Wout) / NT, ncot = (a.Cout + MT - 1) / MT, Z = a.B * a.nsplit;
+        const int NTC = ntile * ncot, L = blockIdx.x;
+        int T = 0;
+        if ((ntile & 7) == 0) {
+            // same XCD (L mod 8), adjacent in dispatch order: first the cout tiles of one (pixel tile, probe) -- they
+            // read the same input patch -- then the other probes of that pixel tile (same primal cache and weights)
+            int q = L >> 3;
+            cot_id = q % ncot; q /= ncot;
+            zid = q % Z;
+            tile_id = (q / Z) * 8 + (L & 7);
+        } else {
+            if ((NTC & 7) == 0) { int q = L >> 3; zid = q % Z; T = (q / Z) * 8 + (L & 7); }
+            else { zid = L % Z; T = L / Z; }
+            tile_id = T % ntile; cot_id = T / ntile;
+        }
+        // integer division runs on the VALU: pin the (wave-uniform) results back into SGPRs so everything derived
+        // from them (chunk range, tile origin, batch bases) is scalar arithmetic and saddr-form addressing
+        tile_id = __builtin_amdgcn_readfirstlane(tile_id);
+        cot_id = __builtin_amdgcn_readfirstlane(cot_id);
+        zid = __builtin_amdgcn_readfirstlane(zid);
+    }
+    const int oy0 = __builtin_amdgcn_readfirstlane((tile_id / tiles_x) * TH);
+    const int ox0 = __builtin_amdgcn_readfirstlane((tile_id % tiles_x) * TW);
+    const int co0 = cot_id * MT;
+    const int b = __builtin_amdgcn_readfirstlane(zid / a.nsplit);
+    const int split = __builtin_amdgcn_readfirstlane(zid % a.nsplit);
+
+    const int halo_w = (TW - 1) * S + KS;
+    const int halo_h = (TH - 1) * S + KS;
+    const int halo_sz = halo_h * halo_w;
+    const int HBYTES = (halo_sz + NDUMMY) * HP;     // + dump records for the lanes without a halo item
+    Hsb = smem_b + 2 * WBYTES;
+
+    const int LH = (a.upsample || a.zins) ? a.Hin * 2 : a.Hin;
+    const int LW = (a.upsample || a.zins) ? a.Win * 2 : a.Win;
+    const long in_plane = (long)a.Hin * a.Win;
+
+    // staging items of this thread: (octet of 8 channels, halo position).  Loads are issued
+    // UNCONDITIONALLY from clamped addresses (uniform base + 32-bit per-lane offset) and masked
+    // afterwards: per-element branches around loads serialise them (one vmcnt(0) per element).
+    int ipos[NITEM], ioct[NITEM];
+    unsigned ivoff[NITEM];
+    bool ival[NITEM];
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+        int it = tid + i * NTHR;
+        int oct = it / halo_sz, pos = it - oct * halo_sz;
+        int off = -1;
+        if (it < 2 * halo_sz) {
+            int hy = pos / halo_w, hx = pos - hy * halo_w;
+            int Y = oy0 * S - a.pad + hy, X = ox0 * S - a.pad + hx;
+            if (Y >= 0 && Y < LH && X >= 0 && X < LW) {
+                if (a.upsample) off = (Y >> 1) * a.Win + (X >> 1);
+                else if (a.zins) off = ((Y | X) & 1) ? -1 : (Y >> 1) * a.Win + (X >> 1);
+                else off = Y * a.Win + X;
+            }
+        } else {
+            pos = -1; oct = 0;
+        }
+        ipos[i] = pos; ioct[i] = oct;
+        ival[i] = off >= 0;
+        ivoff[i] = (unsigned)(oct * 8 * (int)in_plane + (off >= 0 ? off : 0));
+    }
+
+    // ---- vector staging item of this thread (!GEN): 4 consecutive halo pixels x 4 channels (quarter chunk q4)
+    const int nseg = (halo_w + 3) >> 2;
+    int v_q4 = 0, v_pos0 = -1, v_voff = 0, v_cnt = 0;
+    unsigned v_pm = 0;                       // per-pixel validity bits
+    int v_rec[4] = {0, 0, 0, 0};             // LDS record of each of the 4 pixels (a dump record when not staged)
+    unsigned v_goff = 0;                     // byte offset of the item's first pixel / channel from (chunk base - 16 floats)
+    if constexpr (!GEN) {
+        const int per_q = halo_h * nseg;
+        if (tid < 4 * per_q) {
+            v_q4 = tid / per_q;
+            int rem = tid - v_q4 * per_q;
+            int hy = rem / nseg, sg = rem - hy * nseg;
+            int Y = oy0 - a.pad + hy, X0 = ox0 - a.pad + 4 * sg;
+            bool rowok = (Y >= 0 && Y < a.Hin);
+            v_pos0 = hy * halo_w + 4 * sg;
+            v_cnt = halo_w - 4 * sg < 4 ? halo_w - 4 * sg : 4;
+            v_voff = rowok ? Y * a.Win + X0 : 0;          // may be -1 / run 3 floats past the plane: arenas are padded
+#pragma unroll
+            for (int pxi = 0; pxi < 4; ++pxi)
+                if (rowok && X0 + pxi >= 0 && X0 + pxi < a.Win && pxi < v_cnt) v_pm |= 1u << pxi;
+        }
+#pragma unroll
+        for (int pxi = 0; pxi < 4; ++pxi)
+            v_rec[pxi] = (v_pos0 >= 0 && pxi < v_cnt) ? v_pos0 + pxi : (NDUMMY ? halo_sz + (tid & (NDUMMY - 1)) : 0);
+        // the row start may sit one float before the plane (left border): bias by 16 floats so the offset stays >= 0
+        v_goff = (unsigned)(((long)v_q4 * 4 * in_plane + v_voff + 16) * 4);
+    }
+
+    int hoff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int p = (wn * TN + j) * 32 + l31;
+        int ty = p / TW, tx = p - ty * TW;
+        hoff[j] = ty * S * halo_w + tx * S;
+    }
+    int hbyte[TN];                           // byte offset of the lane's hi operand chunk inside a halo buffer
+#pragma unroll
+    for (int j = 0; j < TN; ++j) hbyte[j] = hrec_off(hoff[j], khalf);
+    // A-operand (weight) record offsets inside one tap block: cout-local index fixed per lane
+    int aoff_hi[TM], aoff_lo[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int p = (wm * TM + i) * 32 + l31;
+        aoff_hi[i] = rec_off(p, khalf);
+        aoff_lo[i] = rec_off(p, 2 + khalf);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nchunks = (a.Cin + BKC - 1) / BKC;
+    const int cps = __builtin_amdgcn_readfirstlane((nchunks + a.nsplit - 1) / a.nsplit);
+    const int cbeg = split * cps;
+    const int cend = (cbeg + cps < nchunks) ? cbeg + cps : nchunks;
+
+    const float* inb = a.in + (long)b * a.in_bs;
+    const float2* sxb = NEEDP ? a.sx : nullptr;                     // primal (S, xhat) cache, B = 1
+    const float* scb = (MODE == CM_GN_SILU || MODE == CM_GN) ? a.sc + (long)b * a.scsh_bs : nullptr;
+    const float* shb = (MODE == CM_GN_SILU || MODE == CM_GN) ? a.sh + (long)b * a.scsh_bs : nullptr;
+    const int wpitch = (a.Cout + 31) & ~31;                         // records per tap in the global layout
+    const uint4* wg = reinterpret_cast<const uint4*>(a.wb);
+
+    float hv[NITEM][8];
+    float2 pv[NEEDP ? NITEM : 1][8];
+    // per-channel constants of the chunk in flight: wave-uniform (scalar loads), selected per lane by octet
+    float cA[(MODE == CM_NONE) ? 1 : 16], cB[(MODE == CM_NONE) ? 1 : 16];
+    const float* tcb = NEEDP ? a.tc + (long)b * a.tc_bs : nullptr;   // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent)
+
+    // !GEN: the item (4 channels x 4 pixels) is staged in NPART parts of KP channels, one part per weight stage, so
+    // only KP channels are live in registers at a time (3x3: 2 parts of 2 channels; 1x1: the whole item).  Parts
+    // split the CHANNELS, not the pixels: every load stays a full 16-byte run of 4 pixels.
+    constexpr int NPART = (!GEN && NROW == 3) ? 2 : 1;
+    constexpr int KP = 4 / NPART;
+    struct HaloRegs {
+        float dq[GEN ? 1 : KP][4];                    // !GEN: [channel of the part][pixel]
+        float2 sq[(!GEN && NEEDP) ? KP : 1][4];       // {S, xhat} of those pixels
+        float cqa[(!GEN && MODE != CM_NONE) ? KP : 1], cqb[(!GEN && MODE != CM_NONE) ? KP : 1];   // per-channel constants
+    };
+    HaloRegs hr;                                      // the part in flight inside the stage loop
+    auto prefetch_hv = [&](HaloRegs& R, int chunk, int part) {
+        // wave-uniform chunk base (SGPR pair) + 32-bit per-lane byte offset: global_load saddr form, no 64-bit VALU
+        // (32-bit scalar offset arithmetic: one sample's tensor is far below 4 GB)
+        const unsigned cb = (unsigned)chunk * ((unsigned)(BKC * 4) * (unsigned)in_plane);
+        const char* pk = reinterpret_cast<const char*>(inb - 16) + cb;
+        const char* sk = reinterpret_cast<const char*>(reinterpret_cast<const float*>(sxb) - 32) + 2u * cb;
+        const unsigned pl = (unsigned)in_plane * 4u;
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) {
+            const unsigned po = v_goff + (unsigned)(part * KP + kk) * pl;
+            // 4-byte aligned 16-byte loads (global memory tolerates dword alignment)
+            __builtin_memcpy(&R.dq[kk][0], pk + po, 16);
+            if constexpr (NEEDP) __builtin_memcpy(&R.sq[kk][0], sk + 2u * po, 32);
+        }
+        const int c0 = chunk * BKC + v_q4 * 4 + part * KP;    // first channel of this part
+        if constexpr (MODE != CM_NONE) {
+            if constexpr (NEEDP) {      // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent) per channel
+                float t[2 * KP];
+                __builtin_memcpy(t, tcb + 2 * c0, sizeof(t));
+#pragma unroll
+                for (int kk = 0; kk < KP; ++kk) { R.cqa[kk] = t[2 * kk]; R.cqb[kk] = t[2 * kk + 1]; }
+            } else {
+                __builtin_memcpy(R.cqa, scb + c0, sizeof(float) * KP);
+                __builtin_memcpy(R.cqb, shb + c0, sizeof(float) * KP);
+            }
+        }
+    };
+    auto stage_hv = [&](const HaloRegs& R, int part) {
+        const int oct = v_q4 >> 1, half = v_q4 & 1;
+#pragma unroll
+        for (int pxi = 0; pxi < 4; ++pxi) {
+            float r[KP];
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk) {
+                float d = R.dq[kk][pxi];
+                float v = d;
+                if constexpr (MODE == CM_GN_SILU) {
+                    float y = fmaf(R.cqa[kk], d, R.cqb[kk]);
+                    v = y * sigmoidf2_(y);
+                } else if constexpr (MODE == CM_GN) {
+                    v = fmaf(R.cqa[kk], d, R.cqb[kk]);
+                } else if constexpr (NEEDP) {
+                    const float Sv = R.sq[kk][pxi].x, xh = R.sq[kk][pxi].y;
+                    if constexpr (MODE == CM_TAN_SILU) v = Sv * (d - R.cqa[kk] - xh * R.cqb[kk]);
+                    else v = Sv * d - R.cqa[kk] - xh * R.cqb[kk];
+                }
+                r[kk] = ((v_pm >> pxi) & 1u) ? v : 0.0f;
+            }
+            unsigned h[KP], l[KP];
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk) {
+                __bf16 hb = (__bf16)r[kk];
+                __bf16 lb = (__bf16)(r[kk] - (float)hb);
+                h[kk] = __builtin_bit_cast(unsigned short, hb);
+                l[kk] = __builtin_bit_cast(unsigned short, lb);
+            }
+            unsigned char* dst = Hs + hrec_off(v_rec[pxi], oct) + half * 8 + part * (KP * 2);
+            if constexpr (KP == 4) {
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+            } else {
+                *reinterpret_cast<unsigned*>(dst) = h[0] | (h[1] << 16);
+                *reinterpret_cast<unsigned*>(dst + 32) = l[0] | (l[1] << 16);
+            }
+        }
+    };
+    auto prefetch_h = [&](int chunk, int part) {
+        if constexpr (!GEN) { prefetch_hv(hr, chunk, part); return; }
+        const int c0 = chunk * BKC;
+        if constexpr (MODE != CM_NONE) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                int c = c0 + kk < a.Cin ? c0 + kk : a.Cin - 1;
+                if constexpr (NEEDP) { cA[kk] = tcb[2 * c]; cB[kk] = tcb[2 * c + 1]; }
+                else { cA[kk] = scb[c]; cB[kk] = shb[c]; }
+            }
+        }
+        if (c0 + BKC <= a.Cin) {
+            // fast path: all 16 channels exist -> wave-uniform plane base + per-lane 32-bit offset
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* pk = inb + (long)(c0 + k) * in_plane;
+                const float2* sk = NEEDP ? sxb + (long)(c0 + k) * in_plane : nullptr;
+#pragma unroll
+                for (int i = 0; i < NITEM; ++i) {
+                    hv[i][k] = pk[ivoff[i]];
+                    if constexpr (NEEDP) pv[i][k] = sk[ivoff[i]];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NITEM; ++i) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int c = c0 + ioct[i] * 8 + k;
+                    int cc = c < a.Cin ? c : a.Cin - 1;
+                    unsigned vo = ivoff[i] - (unsigned)(ioct[i] * 8 * (int)in_plane);
+                    float v = inb[(long)cc * in_plane + vo];
+                    hv[i][k] = c < a.Cin ? v : 0.0f;
+                    if constexpr (NEEDP) {
+                        float2 pp = sxb[(long)cc * in_plane + vo];
+                        pv[i][k] = c < a.Cin ? pp : make_float2(0.f, 0.f);
+                    }
+                }
+            }
+        }
+    };
+    // Weight pieces of this thread: byte offset from the (chunk, row) base.  Records past the padded cout range
+    // are CLAMPED to the last one instead of zeroed: a D row only depends on its own A row, and rows >= Cout are
+    // never stored, so the duplicate is harmless and the loads stay unconditional.
+    // The pre-split, pre-swizzled weight records go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x
+    // 16 bytes land contiguously at a wave-uniform LDS base), so a weight stage costs no VGPRs and no ds_write.
+    unsigned wrel[NWV];
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+        int e = tid + i * NTHR;
+        if (e >= WTOT) e = WTOT - 1;
+        int tap = e / (MT * 4), rem = e - tap * (MT * 4);
+        int rec = co0 + (rem >> 2);
+        if (rec >= wpitch) rec = wpitch - 1;
+        wrel[i] = (unsigned)((tap * wpitch + rec) * 4 + (rem & 3)) * 16u;
+    }
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef const __attribute__((address_space(1))) unsigned char glb_u8;
+    auto dma_w = [&](int chunk, int row, unsigned char* Wdst) {
+        const unsigned char* wbase = reinterpret_cast<const unsigned char*>(wg) +
+                                     (unsigned)(chunk * TAPS + row * NTS) * ((unsigned)wpitch * 64u);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int e0 = (wave * 64 + i * NTHR);                 // first piece of this wave's 1 KiB slab
+            if ((WTOT % NTHR) == 0 || e0 < WTOT)                   // wave-uniform
+                __builtin_amdgcn_global_load_lds((glb_u8*)(wbase + wrel[i]), (lds_u8*)(Wdst + e0 * 16), 16, 0, 0);
+        }
+    };
+    auto stage_h = [&](int chunk, int part) {
+        if constexpr (!GEN) { stage_hv(hr, part); return; }
+        const int c0 = chunk * BKC;
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            if (ipos[i] < 0) continue;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int c = c0 + ioct[i] * 8 + k;
+                float r = 0.0f;
+                if (ival[i] && c < a.Cin) {
+                    float d = hv[i][k];
+                    if constexpr (MODE == CM_NONE) {
+                        r = d;
+                    } else {
+                        const float ca = ioct[i] ? cA[8 + k] : cA[k];
+                        const float cb = ioct[i] ? cB[8 + k] : cB[k];
+                        if constexpr (MODE == CM_GN_SILU) {
+                            float y = fmaf(ca, d, cb);
+                            r = y * sigmoidf2_(y);
+                        } else if constexpr (MODE == CM_GN) {
+                            r = fmaf(ca, d, cb);
+                        } else {
+                            float Sv = pv[i][k].x, xh = pv[i][k].y;
+                            if constexpr (MODE == CM_TAN_SILU) r = Sv * (d - ca - xh * cb);
+                            else r = Sv * d - ca - xh * cb;
+                        }
+                    }
+                }
+                v[k] = r;
+            }
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            *reinterpret_cast<uint4*>(Hs + hrec_off(ipos[i], ioct[i])) = hi;
+            *reinterpret_cast<uint4*>(Hs + hrec_off(ipos[i], 2 + ioct[i])) = lo;
+        }
+    };
+
+    // MFMA operand fragments of one tap; two sets alternate so the ds_reads of tap t+1 are in flight under the
+    // MFMAs of tap t (one exposed LDS latency per stage instead of one per operand)
+    struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+    auto load_frag = [&](Frag& f, int row, int tp) {
+        const int tapoff = (TAPS == 9) ? row * halo_w + tp : 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_hi[i]);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_lo[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned char* hp = Hs + tapoff * HP + hbyte[j];     // uniform tap shift + per-lane record base
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(hp);
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(hp + 32);
+        }
+    };
+    auto mma_frag = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    // Software pipeline with ONE barrier per stage (s = NROW*chunk + row).  Stage s multiplies out of W[s&1] /
+    // H[chunk&1].  It opens by launching the LDS-DMA of stage s+1's weights into W[(s+1)&1]; between its taps it
+    // converts one part of the NEXT chunk's halo (loaded into registers at the end of an earlier stage) into
+    // H[(chunk+1)&1]; it closes with vmcnt(0) (the DMA, issued a whole stage ago, has landed), the register loads of
+    // the next halo part, and a RAW barrier so those loads stay in flight across it.  Buffers written in stage s
+    // were last read in stage s-1, which every wave has left; everything read in stage s was complete before the
+    // barrier that opened it.  The stage body is BRANCH-FREE (one basic block): past the end the loads are clamped
+    // to the last chunk and the stores land in buffers nobody reads, so the scheduler can sink the staging VALU /
+    // LDS-write work into the shadow of the MFMAs.
+    //   halo schedule, 3x3 vector path (2 parts A,B):  row0: store A | load B   row1: store B   row2: load A'
+    //   3x3 per-pixel path (1 part):                   row0: load           row2: store
+    //   1x1:                                           every stage: store | load
+#ifdef LOCO_STAMP
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#define STAMP(i) { unsigned long long tn = __builtin_readcyclecounter(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define STAMP(i)
+#endif
+    const int nch = cend - cbeg;
+    const int clast = cend - 1;
+    auto cclamp = [&](int c) { return __builtin_amdgcn_readfirstlane(c < clast ? c : clast); };   // keep it scalar
+    auto stage_end = [&]() {
+        // all LDS writes of this wave retired, LDS-DMA landed; then a bare s_barrier (no vmcnt drain of newer loads)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    if (nch > 0) {
+        dma_w(cbeg, 0, Wsb);
+        Hs = Hsb;
+        if constexpr (!GEN && NPART == 2) {
+            // both parts of the first chunk are loaded together (a second register set that only lives here) so the
+            // workgroup pays one memory latency, not two, before its first stage
+            if (!(LOCO_EXP & 128)) {
+                HaloRegs hr2;
+                prefetch_hv(hr, cbeg, 0);
+                prefetch_hv(hr2, cbeg, 1);
+                stage_hv(hr, 0);
+                stage_hv(hr2, 1);
+            }
+        } else {
+#pragma unroll
+            for (int part = 0; part < NPART; ++part) {
+                if (LOCO_EXP & 128) continue;                     // what-if: no prologue halo
+                prefetch_h(cbeg, part);
+                stage_h(cbeg, part);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NROW == 1 || NPART == 2) prefetch_h(cclamp(cbeg + 1), 0);      // pending part expected by the first stage
+        stage_end();
+    }
+    for (int ci = 0; ci < nch; ++ci) {
+        const int chunk = cbeg + ci;
+#pragma unroll
+        for (int row = 0; row < NROW; ++row) {
+            const int s_ = ci * NROW + row;
+            unsigned char* const Wcur = Wsb + (s_ & 1) * WBYTES;
+            unsigned char* const Wnxt = Wsb + ((s_ + 1) & 1) * WBYTES;
+            unsigned char* const Hcur = Hsb + (ci & 1) * HBYTES;
+            unsigned char* const Hnxt = Hsb + ((ci + 1) & 1) * HBYTES;
+            // which halo part of the next chunk this row converts (-1: none) and which it loads at its end
+            constexpr bool one = (NROW == 1);
+            const int st_part = one ? 0 : (NPART == 2 ? (row == 0 ? 0 : row == 1 ? 1 : -1) : (row == 2 ? 0 : -1));
+            // vector path: a part's registers are re-loaded right after they are converted (mid-stage), so the
+            // loads have one to two whole stages to land; per-pixel path: loads at the end of row 0
+            const int ld_part = one ? 0 : (NPART == 2 ? (row == 0 ? 1 : row == 1 ? 0 : -1) : (row == 0 ? 0 : -1));
+            const int ld_chunk = one ? chunk + 2 : ((NPART == 2 && row == 1) ? chunk + 2 : chunk + 1);
+            constexpr bool MIDLOAD = !GEN;          // issue the loads inside the stage, behind the conversion
+            // vector-memory instructions of one part's loads (for the counted wait that leaves them in flight)
+            constexpr int NLD = KP + (NEEDP ? 2 * KP + 1 : (MODE != CM_NONE ? 2 : 0));
+            STAMP(0)
+            // Regions fenced by sched_barrier(0): the machine scheduler would otherwise sink every ds_read to just
+            // before its first use and expose one LDS latency per operand.
+            {
+                const int r1 = (row + 1) % NROW, dc = (row + 1) / NROW;
+                if (!(LOCO_EXP & 8)) dma_w(cclamp(chunk + dc), r1, Wnxt);
+            }
+            Ws = Wcur; Hs = Hcur;
+            Frag f0, f1;
+#define X_MMA(f) do { if (!(LOCO_EXP & 1)) mma_frag(f); } while (0)
+#define X_LOAD(f, r, t) do { if (!(LOCO_EXP & 4) || (ci == 0 && r == 0)) load_frag(f, r, t); } while (0)
+            X_LOAD(f0, row, 0);
+            if (NTS > 1) X_LOAD(f1, row, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            X_MMA(f0);
+            STAMP(1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (NTS > 2) X_LOAD(f0, row, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NTS > 1) X_MMA(f1);
+            if (!(LOCO_EXP & 2) && st_part >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), st_part); Hs = Hcur; }   // VALU under tap 1's MFMAs
+            STAMP(2)
+            __builtin_amdgcn_sched_barrier(0);       // (also keeps the re-load below from being hoisted above the conversion's wait)
+            if (MIDLOAD && !(LOCO_EXP & 18) && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+            STAMP(3)
+            if (NTS > 2) X_MMA(f0);
+            STAMP(4)
+            __builtin_amdgcn_sched_barrier(0);
+            // the LDS-DMA of this stage (older than the part loads just issued) must have landed before the barrier
+            if (MIDLOAD && ld_part >= 0 && !(LOCO_EXP & 18)) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!MIDLOAD && !(LOCO_EXP & 18) && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+            }
+            if (!(LOCO_EXP & 32)) stage_end();
+        }
+    }
+#ifdef LOCO_STAMP
+    if (blockIdx.x == 0 && (tid & 63) == 0) {
+        for (int i = 0; i < 6; ++i) a.partial[wave * 8 + i] = (float)tacc[i];
+    }
+    unsigned long long tep0 = __builtin_readcyclecounter();
+#endif
+
+    // epilogue.  D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const long out_plane = (long)a.Hout * a.Wout;
+    const bool full_co = (co0 + MT <= a.Cout);
+    if ((LOCO_EXP & 64) && acc[0][0][0] != 12345.f) return;      // what-if: no epilogue
+    if (a.fs_out) {
+        // ---- epilogue with FUSED GroupNorm tangent / cotangent statistics of the consumer norm ----
+        // (needs nsplit == 1, a full cout tile, no accumulate, cpg in {4,8,16,32}: guaranteed by the engine).
+        // Per lane: accumulator pair index ai = i*4 + (r>>2) collects z and xhat*z over the lane's pixels for
+        // the 4 consecutive channels (r&3) of that quad; quads are merged into groups after the lane reduction.
+        float s1[TM * 4], s2[TM * 4], irs[TM * 4];
+#pragma unroll
+        for (int q = 0; q < TM * 4; ++q) { s1[q] = 0.f; s2[q] = 0.f; irs[q] = 1.f; }
+        if (a.fs_kind == 1) {
+#pragma unroll
+            for (int q = 0; q < TM * 4; ++q) {
+                int co = co0 + (wm * TM + (q >> 2)) * 32 + 8 * (q & 3) + 4 * khalf;
+                irs[q] = 1.0f / a.fs_mr[2 * (co / a.fs_cpg) + 1];
+            }
+        }
+        float* ob = a.out + (long)b * a.out_bs;
+        const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+        const float* b2 = a.bias2 ? a.bias2 + (long)b * a.bias2_bs : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int p = (wn * TN + j) * 32 + l31;
+            int ty = p / TW, tx = p - ty * TW;
+            const unsigned pix = (unsigned)((oy0 + ty) * a.Wout + ox0 + tx);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int cob = co0 + (wm * TM + i) * 32 + 4 * khalf;
+                float rv[16];
+                float2 sxv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long off = (long)(cob + (r & 3) + 8 * (r >> 2)) * out_plane + pix;
+                    rv[r] = rb ? rb[off] : 0.f;
+                    sxv[r] = a.fs_sx[off];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cob + (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r] + rv[r];
+                    if (a.bias) v += a.bias[co];
+                    if (b2) v += b2[co];
+                    ob[(long)co * out_plane + pix] = v;
+                    const int q = i * 4 + (r >> 2);
+                    const float z = a.fs_kind == 1 ? v * sxv[r].x * irs[q] : v;
+                    s1[q] += z;
+                    s2[q] += sxv[r].y * z;
+                }
+            }
+        }
+        // reduce over the 32 pixel lanes of each half wave
+#pragma unroll
+        for (int q = 0; q < TM * 4; ++q) {
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                s1[q] += __shfl_xor(s1[q], o, 64);
+                s2[q] += __shfl_xor(s2[q], o, 64);
+            }
+        }
+        // all waves are past their last LDS read of the stage loop once they pass this barrier
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_b);        // [wave][khalf][TM*4][2]
+        if (l31 == 0) {
+#pragma unroll
+            for (int q = 0; q < TM * 4; ++q) {
+                red[((wave * 2 + khalf) * TM * 4 + q) * 2] = s1[q];
+                red[((wave * 2 + khalf) * TM * 4 + q) * 2 + 1] = s2[q];
+            }
+        }
+        __syncthreads();
+        // one thread per channel group of the workgroup's MT couts: sum the quads of the group over the WN waves
+        const int cpg = a.fs_cpg, ngrp = MT / cpg;
+        if (tid < ngrp) {
+            float t1 = 0.f, t2 = 0.f;
+            const int c_lo = tid * cpg;                           // first local cout of the group
+            for (int cl = c_lo; cl < c_lo + cpg; cl += 4) {       // quads of 4 consecutive couts
+                int blk = cl >> 5, rowin = cl & 31;               // 32-cout block, row inside it
+                int wmq = blk / TM, iq = blk - wmq * TM;
+                int kh = (rowin >> 2) & 1, qq = rowin >> 3;       // row = (r&3) + 8*(r>>2) + 4*khalf
+                for (int w2 = 0; w2 < WN; ++w2) {
+                    int wv = wmq * WN + w2;
+                    t1 += red[((wv * 2 + kh) * TM * 4 + iq * 4 + qq) * 2];
+                    t2 += red[((wv * 2 + kh) * TM * 4 + iq * 4 + qq) * 2 + 1];
+                }
+            }
+            const int g = (co0 + c_lo) / cpg;
+            const int npt = (a.Hout * a.Wout) / NT;
+            float* o = a.fs_out + (((long)b * a.fs_G + g) * npt + tile_id) * 2;
+            o[0] = t1;
+            o[1] = t2;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int p = (wn * TN + j) * 32 + l31;
+        int ty = p / TW, tx = p - ty * TW;
+        int oy = oy0 + ty, ox = ox0 + tx;
+        const unsigned pix = (unsigned)(oy * a.Wout + ox);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int cob = co0 + (wm * TM + i) * 32 + 4 * khalf;
+            if (a.nsplit > 1) {
+                float* pb = a.partial + (((long)split * a.B + b) * a.Cout) * out_plane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co = cob + (r & 3) + 8 * (r >> 2);
+                    if (full_co || co < a.Cout) pb[(long)co * out_plane + pix] = acc[i][j][r];
+                }
+            } else {
+                float* ob = a.out + (long)b * a.out_bs;
+                const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+                const float* b2 = a.bias2 ? a.bias2 + (long)b * a.bias2_bs : nullptr;
+                if (rb || a.accumulate) {
+                    // The residual may alias the output (nin shortcut written in place), so the compiler cannot
+                    // move a residual load above the previous store: gather the 16 residual / accumulate values of
+                    // the tile first (each thread only touches its own elements), then add and store.
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = cob + (r & 3) + 8 * (r >> 2);
+                        const bool ok = full_co || co < a.Cout;
+                        const long off = (long)(ok ? co : a.Cout - 1) * out_plane + pix;
+                        float t = 0.f;
+                        if (rb) t = rb[off];
+                        if (a.accumulate) t += ob[off];
+                        rv[r] = t;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = cob + (r & 3) + 8 * (r >> 2);
+                        if (!(full_co || co < a.Cout)) continue;
+                        float v = acc[i][j][r] + rv[r];
+                        if (a.bias) v += a.bias[co];
+                        if (b2) v += b2[co];
+                        ob[(long)co * out_plane + pix] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = cob + (r & 3) + 8 * (r >> 2);
+                        if (!(full_co || co < a.Cout)) continue;
+                        float v = acc[i][j][r];
+                        if (a.bias) v += a.bias[co];
+                        if (b2) v += b2[co];
+                        ob[(long)co * out_plane + pix] = v;
+                    }
+                }
+            }
+        }
+    }
+#ifdef LOCO_STAMP
+    if (blockIdx.x == 0 && (tid & 63) == 0) a.partial[wave * 8 + 6] = (float)(__builtin_readcyclecounter() - tep0);
+#endif
+}
+
+// ---------------------------------------------------------------------------
+
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
+static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
+    constexpr int MT = WM * TM * 32, NT = WN * TN * 32;
+    constexpr int KS = (TAPS == 9) ? 3 : 1;
+    int TW = a.Wout < 32 ? a.Wout : 32;
+    int TH = NT / TW;
+    int halo_w = (TW - 1) * a.stride + KS, halo_h = (TH - 1) * a.stride + KS;
+    size_t lds = 2 * ((size_t)KS * MT * 64 + ((size_t)halo_w * halo_h + NDUMMY) * HP);
+    dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>), grid, dim3(WM * WN * 64), lds, st, a);
+}
+
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE>
+static void launch_one_b(const ConvArgs& a, hipStream_t st) {
+    const bool general = a.stride != 1 || a.upsample || a.zins || (a.Cin % BKC) != 0 || !a.in_padded;
+    if constexpr (MODE == CM_NONE) {
+        // raw inputs: 3x3 convs take the vector path when the layout allows (measured 66.1 -> 62.8 ms/step);
+        // 1x1 convs stay on the per-pixel path (38.1 vs 39.2 ms/step)
+        if (a.stride == 2) launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 2>(a, st);
+        else if (TAPS == 9 && !general) launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
+        else launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 1>(a, st);
+        return;
+    }
+    if constexpr (MODE == CM_GN_SILU || MODE == CM_TAN_SILU) {
+        if (general) { launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 1>(a, st); return; }
+    }
+    launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
+}
+
+
+int bf16_tile_of(const ConvArgs& a);     // conv_bf16.hip
+
+template <int TAPS, int MODE>
+void launch_tile_b(const ConvArgs& a, hipStream_t st) {
+#ifdef LOCO_DEV_ONE   // development aid: instantiate only one tile variant (fast recompiles for ISA inspection)
+#ifdef LOCO_DEV_TILE0
+    launch_one_b2<TAPS, 2, 2, 2, 2, MODE, 0>(a, st);
+#elif defined(LOCO_DEV_TILE4)
+    launch_one_b2<TAPS, 2, 2, 2, 4, MODE, 0>(a, st);
+#else
+    launch_one_b2<TAPS, 2, 4, 2, 2, MODE, 0>(a, st);
+#endif
+    return;
+#else
+    const int tile = bf16_tile_of(a);
+    switch (tile) {
+        case 4: launch_one_b<TAPS, 2, 2, 2, 4, MODE>(a, st); break;   // 128 x 256, 4 waves (64 x 128 each)
+        case 5: launch_one_b<TAPS, 2, 4, 2, 2, MODE>(a, st); break;   // 128 x 256, 8 waves (64 x 64 each)
+        case 0: launch_one_b<TAPS, 2, 2, 2, 2, MODE>(a, st); break;
+        case 1: launch_one_b<TAPS, 4, 1, 1, 2, MODE>(a, st); break;
+        case 2: launch_one_b<TAPS, 1, 4, 1, 1, MODE>(a, st); break;
+        default: launch_one_b<TAPS, 2, 2, 1, 1, MODE>(a, st); break;
+    }
+#endif
+}
+
+
+}  // namespace loco
