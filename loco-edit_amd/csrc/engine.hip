@@ -1546,7 +1546,7 @@ int loco_orthonormalize(loco_ctx* c, float* A, int32_t k, int64_t n, float* s, v
     launch_rotate_rows(A, c->tmpA, k, n, c->Q, c->W, 0, st);
     // singular values of the input = sqrt(eigenvalues of A A^T)
     HIPCHK(c, hipMemcpyAsync(A, c->tmpA, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    launch_sign_fix(A, k, n, s, c->W, st);
+    launch_sign_fix(A, k, n, s, c->W, reinterpret_cast<float*>(c->red), st);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

@@ -161,7 +161,7 @@ void launch_jacobi_eig(double* G, int k, double* w, double* Q, hipStream_t st);
 // A <- diag(scale) * Q * A   (k x n, in place, via temp copy), scale from w: mode 0: 1/sqrt(max(w,tiny)); mode 1: none
 void launch_rotate_rows(const float* Ain, float* Aout, int k, long n, const double* Q, const double* w,
                         int mode, hipStream_t st);
-void launch_sign_fix(float* A, int k, long n, float* s_out, const double* w, hipStream_t st);
+void launch_sign_fix(float* A, int k, long n, float* s_out, const double* w, float* scratch, hipStream_t st);   // scratch: k * ceil(n/4096) floats
 // Cholesky factor of G (k x k double, lower) in one workgroup, then A <- L^{-1} A
 void launch_cholesky(double* G, int k, hipStream_t st);
 void launch_trsm_rows(const float* Ain, float* Aout, int k, long n, const double* L, hipStream_t st);

@@ -48,12 +48,19 @@ __global__ __launch_bounds__(256) void cross_gram_partial(const float* A, int k1
         if (lane == 0) part[(long)blockIdx.x * k1 * k2 + pr] = acc;
     }
 }
-__global__ void gram_reduce(const double* part, int nblk, int kk, double* G) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= kk) return;
+// one workgroup per Gram entry: fixed-order strided partial sums, then an LDS tree (deterministic)
+__global__ __launch_bounds__(256) void gram_reduce(const double* part, int nblk, int kk, double* G) {
+    __shared__ double red[256];
+    const int p = blockIdx.x;
     double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += part[(long)b * kk + p];
-    G[p] = acc;
+    for (int b = threadIdx.x; b < nblk; b += 256) acc += part[(long)b * kk + p];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) G[p] = red[0];
 }
 void launch_cross_gram(const float* A, int k1, const float* B, int k2, long n, double* C, double* scratch,
                        hipStream_t st) {
@@ -63,7 +70,7 @@ void launch_cross_gram(const float* A, int k1, const float* B, int k2, long n, d
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_gram_partial),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(cross_gram_partial, dim3(nblk), dim3(256), lds, st, A, k1, B, k2, n, scratch);
-    hipLaunchKernelGGL(gram_reduce, dim3((k1 * k2 + 255) / 256), dim3(256), 0, st, scratch, nblk, k1 * k2, C);
+    hipLaunchKernelGGL(gram_reduce, dim3(k1 * k2), dim3(256), 0, st, scratch, nblk, k1 * k2, C);
 }
 void launch_gram(const float* A, int k, long n, double* G, double* scratch, hipStream_t st) {
     launch_cross_gram(A, k, A, k, n, G, scratch, st);
@@ -194,13 +201,16 @@ void launch_rotate_rows(const float* Ain, float* Aout, int k, long n, const doub
                        k, n, Q, w, mode);
 }
 
-// per row: flip so that the entry of largest magnitude is positive; also emit s = sqrt(max(w,0))
-__global__ __launch_bounds__(256) void sign_fix_kernel(float* A, long n, float* s_out, const double* w) {
+// per row: flip so that the entry of largest magnitude is positive; also emit s = sqrt(max(w,0)).
+// Two passes over SEG-element segments so the whole chip works on the k rows: candidates, then decide + flip.
+constexpr int SIGN_SEG = 4096;
+__global__ __launch_bounds__(256) void sign_cand_kernel(const float* A, long n, int nseg, float* cand) {
     __shared__ float bestv[256];
-    float* row = A + (long)blockIdx.x * n;
+    const float* row = A + (long)blockIdx.y * n;
+    const long c0 = (long)blockIdx.x * SIGN_SEG;
     float bv = 0.f;
-    for (long c = threadIdx.x; c < n; c += 256) {
-        float v = row[c];
+    for (int c = threadIdx.x; c < SIGN_SEG && c0 + c < n; c += 256) {
+        float v = row[c0 + c];
         if (fabsf(v) > fabsf(bv)) bv = v;
     }
     bestv[threadIdx.x] = bv;
@@ -210,16 +220,37 @@ __global__ __launch_bounds__(256) void sign_fix_kernel(float* A, long n, float* 
             bestv[threadIdx.x] = bestv[threadIdx.x + s];
         __syncthreads();
     }
-    const bool flip = bestv[0] < 0.f;
-    if (flip)
-        for (long c = threadIdx.x; c < n; c += 256) row[c] = -row[c];
-    if (threadIdx.x == 0 && s_out) {
-        double ev = w[blockIdx.x];
-        s_out[blockIdx.x] = (float)sqrt(ev > 0 ? ev : 0.0);
+    if (threadIdx.x == 0) cand[(long)blockIdx.y * nseg + blockIdx.x] = bestv[0];
+}
+__global__ __launch_bounds__(256) void sign_apply_kernel(float* A, long n, int nseg, const float* cand, float* s_out,
+                                                         const double* w) {
+    __shared__ float bestv[256];
+    float bv = 0.f;
+    for (int i = threadIdx.x; i < nseg; i += 256) {
+        float v = cand[(long)blockIdx.y * nseg + i];
+        if (fabsf(v) > fabsf(bv)) bv = v;
+    }
+    bestv[threadIdx.x] = bv;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s && fabsf(bestv[threadIdx.x + s]) > fabsf(bestv[threadIdx.x]))
+            bestv[threadIdx.x] = bestv[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (bestv[0] < 0.f) {
+        float* row = A + (long)blockIdx.y * n;
+        const long c0 = (long)blockIdx.x * SIGN_SEG;
+        for (int c = threadIdx.x; c < SIGN_SEG && c0 + c < n; c += 256) row[c0 + c] = -row[c0 + c];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && s_out) {
+        double ev = w[blockIdx.y];
+        s_out[blockIdx.y] = (float)sqrt(ev > 0 ? ev : 0.0);
     }
 }
-void launch_sign_fix(float* A, int k, long n, float* s_out, const double* w, hipStream_t st) {
-    hipLaunchKernelGGL(sign_fix_kernel, dim3(k), dim3(256), 0, st, A, n, s_out, w);
+void launch_sign_fix(float* A, int k, long n, float* s_out, const double* w, float* scratch, hipStream_t st) {
+    const int nseg = (int)((n + SIGN_SEG - 1) / SIGN_SEG);
+    hipLaunchKernelGGL(sign_cand_kernel, dim3(nseg, k), dim3(256), 0, st, A, n, nseg, scratch);
+    hipLaunchKernelGGL(sign_apply_kernel, dim3(nseg, k), dim3(256), 0, st, A, n, nseg, scratch, s_out, w);
 }
 
 // in-place lower Cholesky of a k x k double matrix (row-major), one workgroup
