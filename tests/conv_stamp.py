@@ -9,7 +9,7 @@ from loco_edit_amd.config import CELEBA_DDPM, synth_params
 eng = H.LocoEngine(CELEBA_DDPM, max_batch=8)
 eng.load_state_dict(synth_params(CELEBA_DDPM, 0))
 eng.set_precision("bf16x3")
-names = ["tail+barrier", "dma+tap0", "tap1", "halo_store", "tap2", "-", "epilogue"]
+names = ["Ybarrier->X", "X work", "X barrier", "Y mfma", "Y vmcnt", "-", "epilogue"]
 for mode in (3,):
     for tile in (5,):
         ms = eng.bench_conv(128, 128, 256, 256, 5, mode, 9, tile, 3)
