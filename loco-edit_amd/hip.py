@@ -15,7 +15,8 @@ import torch
 
 from .config import UNetConfig
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libloco_hip.so")
+# LOCO_HIP_LIB: alternative build of the same library (A/B timing of kernel variants); default = the in-tree build
+_LIB_PATH = os.environ.get("LOCO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libloco_hip.so")
 _lib = None
 
 # every symbol include/loco_hip.h declares
