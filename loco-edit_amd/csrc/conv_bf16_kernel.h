@@ -564,9 +564,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
             if (NTS > 2) X_LOAD(f0, row, 2);
             __builtin_amdgcn_sched_barrier(0);
             if (NTS > 1) X_MMA(f1);
-            if (!(LOCO_EXP & 2) && st_part >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), st_part); Hs = Hcur; }   // VALU under tap 1's MFMAs
+            // halo conversion, then the re-load of its registers, share one scheduling region with the MFMAs of taps
+            // 1 and 2 (a fence between them measured 2.7 ms/step slower; conversion under tap 0 13 ms slower)
+            if (!(LOCO_EXP & 2) && st_part >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), st_part); Hs = Hcur; }
             STAMP(2)
-            __builtin_amdgcn_sched_barrier(0);       // (also keeps the re-load below from being hoisted above the conversion's wait)
             if (MIDLOAD && !(LOCO_EXP & 18) && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
             STAMP(3)
             if (NTS > 2) X_MMA(f0);
