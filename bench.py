@@ -121,11 +121,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # LOCO_BENCH_BACKEND=gloo lets several ranks share one GPU (a smoke test of the sharded path on a 1-GPU box);
+    # the default is RCCL with one GPU per rank
+    backend = os.environ.get("LOCO_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend)
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
@@ -170,13 +178,16 @@ def main():
     # ---- roofline leg: per-kernel HIP-event profile of one more identical step
     roofline = None
     F = eng.unet_flops()
-    if rank == 0 and not a.no_profile:
-        eng.profile_enable(True)
+    if not a.no_profile:
+        # every rank runs the extra step (it contains the all-gather); only rank 0 records the per-kernel events
+        if rank == 0:
+            eng.profile_enable(True)
         torch.cuda.synchronize()
         tp0 = time.perf_counter()
         step()
         torch.cuda.synchronize()
         t_prof = time.perf_counter() - tp0
+    if rank == 0 and not a.no_profile:
         rep = eng.profile_report()
         eng.profile_enable(False)
         dom = max(rep.items(), key=lambda kv: kv[1]["ms"])

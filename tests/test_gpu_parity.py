@@ -343,3 +343,23 @@ def test_run_edit_null_space_projection_end_to_end(tmp_path):
     assert torch.allclose(xt2, xt, rtol=1e-5, atol=1e-5)
     pngs = [f for f in os.listdir(ed.result_folder) if f.endswith(".png")]
     assert any("Edit-random" in f for f in pngs)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu():
+    """The sharded bench path end to end (rendezvous, probe sharding, the per-iteration all-gather, barrier +
+    max-over-ranks timing, the extra profiled step on every rank, one JSON line from rank 0) with two ranks on one
+    GPU over gloo; the 8-GPU RCCL run itself is the driver's."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LOCO_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["probes_total"] == 10 and d["value"] > 0
+    assert d["roofline"] is not None and d["cpu_baseline"] is None
