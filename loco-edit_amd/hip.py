@@ -275,6 +275,10 @@ class LocoEngine:
         self._check(self.lib.loco_mask_gather(self._ctx, _ptr(U), k, _ptr(out), _stream()), "loco_mask_gather")
         return out
 
+    def mask_count(self) -> int:
+        """L = number of selected elements of the mask given to the last ``pmp_primal`` (n when unmasked)."""
+        return int(self.lib.loco_mask_count(self._ctx))
+
     # ---- introspection
     def unet_flops(self) -> float:
         return float(self.lib.loco_unet_flops(self._ctx))

@@ -29,6 +29,9 @@ class JacobianOperator:
         self.engine = engine
         self.n = engine.n
         engine.pmp_primal(x.contiguous(), float(t), at, mask, use_et=noise)
+        if mask is not None and hasattr(engine, "mask_count") and engine.mask_count() == 0:
+            # the reference would run the power iteration on a 0-row Jacobian and return NaN directions
+            raise ValueError("empty mask: J = d x0_hat[mask] / d x_t has no rows")
 
     def jvp(self, V: torch.Tensor) -> torch.Tensor:   # [k,n] -> dense masked [k,n]
         return self.engine.pmp_jvp(V)

@@ -363,3 +363,25 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["probes_total"] == 10 and d["value"] > 0
     assert d["roofline"] is not None and d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_edge_cases_empty_mask_single_probe_full_mask(engines):
+    """Empty mask is rejected (the reference would produce NaN directions); a single probe and an all-true mask
+    (L = n, same operator as mask=None) run through the solver."""
+    from loco_edit_amd import solver
+    cfg = TINY_DDPM
+    eng = engines(cfg, "f32")
+    s = _sched()
+    t = float(s.timesteps[40]); at = float(s.alpha_at(t))
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=g).to(DEV)
+    empty = torch.zeros(3, cfg.resolution, cfg.resolution, dtype=torch.bool, device=DEV)
+    with pytest.raises(ValueError):
+        solver.local_basis(eng, x, t, at, 2, mask=empty, min_iter=2, max_iter=3, verbose=False)
+    v0 = torch.randn(cfg.n, 1, generator=g)
+    u, sv, vT, n_it = solver.local_basis(eng, x, t, at, 1, mask=~empty, min_iter=2, max_iter=4, v0=v0, verbose=False)
+    u2, sv2, vT2, _ = solver.local_basis(eng, x, t, at, 1, mask=None, min_iter=2, max_iter=4, v0=v0, verbose=False)
+    assert vT.shape == (1, cfg.n) and u.shape == (cfg.n, 1) and torch.isfinite(vT).all()
+    assert abs(float(vT.norm()) - 1.0) < 1e-4
+    assert float((vT * vT2).sum().abs()) > 0.99999 and abs(float(sv[0] - sv2[0])) < 1e-4 * float(sv2[0])
