@@ -379,7 +379,6 @@ void launch_conv(const ConvArgs& a, int taps, hipStream_t st) {
             default: launch_tile<1, CM_GN>(a, st); break;
         }
     }
-    launch_conv_splitk_reduce(a, st);
 }
 
 void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st) {

@@ -62,7 +62,6 @@ void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st) {
             default: launch_tile_b<1, CM_GN>(a, st); break;
         }
     }
-    launch_conv_splitk_reduce(a, st);
 }
 
 }  // namespace loco

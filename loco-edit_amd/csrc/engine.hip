@@ -785,40 +785,45 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
             if (s > 1) { tail_probes = (int)(r / per_probe); tail_split = s; }
         }
     }
-    auto launch = [&]() {
-        if (!tail_probes) {
-            if (c->prec == 1) launch_conv_bf16x3(a, taps, st); else launch_conv(a, taps, st);
-            return;
+    // one conv kernel (+ its split-K reduce), each timed as its own profile record so the per-kernel averages agree
+    // with rocprofv3's
+    auto one = [&](const ConvArgs& x) {
+        loco_ctx::ProfRec r, rr;
+        if (c->prof_on) {
+            r.name = conv_variant_name(x, taps, c->prec);
+            r.flops = 2.0 * x.Cin * x.Cout * taps * (double)x.Hout * x.Wout * x.B;
+            if (x.zins) r.flops *= 0.25;     // algorithmic work of the stride-2 data gradient
+            r.cin = x.Cin; r.cout = x.Cout; r.h = x.Hout; r.b = x.B; r.ns = x.nsplit; r.mode = x.mode; r.taps = taps;
+            r.e0 = c->next_event(); r.e1 = c->next_event();
+            (void)hipEventRecord(r.e0, st);
         }
-        ConvArgs m = a, t = a;
-        const int nb = a.B - tail_probes;
-        m.B = nb;
-        t.B = tail_probes; t.nsplit = tail_split;
-        t.in += (long)nb * a.in_bs; t.out += (long)nb * a.out_bs;
-        if (t.prim) t.prim += (long)nb * a.prim_bs;
-        if (t.bias2) t.bias2 += (long)nb * a.bias2_bs;
-        if (t.res) t.res += (long)nb * a.res_bs;
-        if (t.sc) { t.sc += (long)nb * a.scsh_bs; t.sh += (long)nb * a.scsh_bs; }
-        if (t.mr) t.mr += (long)nb * a.mr_bs;
-        if (t.tst) t.tst += (long)nb * a.tst_bs;
-        if (t.tc) t.tc += (long)nb * a.tc_bs;
-        launch_conv_bf16x3(m, taps, st);
-        launch_conv_bf16x3(t, taps, st);      // includes the split-K reduce of the tail probes
+        if (c->prec == 1) launch_conv_bf16x3(x, taps, st); else launch_conv(x, taps, st);
+        if (c->prof_on) { (void)hipEventRecord(r.e1, st); c->prof.push_back(r); }
+        if (x.nsplit > 1) {
+            if (c->prof_on) {
+                rr = r; rr.name = "conv_splitk_reduce"; rr.flops = 0.0;
+                rr.e0 = c->next_event(); rr.e1 = c->next_event();
+                (void)hipEventRecord(rr.e0, st);
+            }
+            launch_conv_splitk_reduce(x, st);
+            if (c->prof_on) { (void)hipEventRecord(rr.e1, st); c->prof.push_back(rr); }
+        }
     };
-    if (c->prof_on) {
-        loco_ctx::ProfRec r;
-        r.name = conv_variant_name(a, taps, c->prec);
-        r.flops = 2.0 * a.Cin * a.Cout * taps * (double)a.Hout * a.Wout * a.B;
-        if (a.zins) r.flops *= 0.25;     // algorithmic work of the stride-2 data gradient
-        r.cin = a.Cin; r.cout = a.Cout; r.h = a.Hout; r.b = a.B; r.ns = a.nsplit; r.mode = a.mode; r.taps = taps;
-        r.e0 = c->next_event(); r.e1 = c->next_event();
-        (void)hipEventRecord(r.e0, st);
-        launch();
-        (void)hipEventRecord(r.e1, st);
-        c->prof.push_back(r);
-        return;
-    }
-    launch();
+    if (!tail_probes) { one(a); return; }
+    ConvArgs m = a, t = a;
+    const int nb = a.B - tail_probes;
+    m.B = nb;
+    t.B = tail_probes; t.nsplit = tail_split;
+    t.in += (long)nb * a.in_bs; t.out += (long)nb * a.out_bs;
+    if (t.prim) t.prim += (long)nb * a.prim_bs;
+    if (t.bias2) t.bias2 += (long)nb * a.bias2_bs;
+    if (t.res) t.res += (long)nb * a.res_bs;
+    if (t.sc) { t.sc += (long)nb * a.scsh_bs; t.sh += (long)nb * a.scsh_bs; }
+    if (t.mr) t.mr += (long)nb * a.mr_bs;
+    if (t.tst) t.tst += (long)nb * a.tst_bs;
+    if (t.tc) t.tc += (long)nb * a.tc_bs;
+    one(m);
+    one(t);
 }
 
 inline void setw(ConvArgs& a, const ConvP& p, bool dgrad) {
@@ -1717,7 +1722,10 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     a.nsplit = 1; a.partial = c->partial;
     int saved = g_bf16_tile_override;
     g_bf16_tile_override = tile;
-    auto run = [&]() { if (c->prec == 1) launch_conv_bf16x3(a, taps, st); else launch_conv(a, taps, st); };
+    auto run = [&]() {
+        if (c->prec == 1) launch_conv_bf16x3(a, taps, st); else launch_conv(a, taps, st);
+        launch_conv_splitk_reduce(a, st);
+    };
     run();
     HIPCHK(c, hipEventRecord(c->ev0, st));
     for (int i = 0; i < iters; ++i) run();

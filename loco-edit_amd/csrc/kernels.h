@@ -53,6 +53,7 @@ struct ConvArgs {
     int B;
 };
 
+// the conv kernel only; when a.nsplit > 1 the caller follows with launch_conv_splitk_reduce (run_conv does)
 void launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st);
 void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st);
