@@ -634,7 +634,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
                     float v = acc[i][j][r] + rv[r];
                     if (a.bias) v += a.bias[co];
                     if (b2) v += b2[co];
-                    ob[(long)co * out_plane + pix] = v;
+                    __builtin_nontemporal_store(v, &ob[(long)co * out_plane + pix]);   // streamed once: keep L2 for the shared primal cache / weights (2 ms per step)
                     const int q = i * 4 + (r >> 2);
                     const float z = a.fs_kind == 1 ? v * sxv[r].x * irs[q] : v;
                     s1[q] += z;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
                         float v = acc[i][j][r] + rv[r];
                         if (a.bias) v += a.bias[co];
                         if (b2) v += b2[co];
-                        ob[(long)co * out_plane + pix] = v;
+                        __builtin_nontemporal_store(v, &ob[(long)co * out_plane + pix]);   // streamed once: keep L2 for the shared primal cache / weights (2 ms per step)
                     }
                 } else {
 #pragma unroll
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
                         float v = acc[i][j][r];
                         if (a.bias) v += a.bias[co];
                         if (b2) v += b2[co];
-                        ob[(long)co * out_plane + pix] = v;
+                        __builtin_nontemporal_store(v, &ob[(long)co * out_plane + pix]);   // streamed once: keep L2 for the shared primal cache / weights (2 ms per step)
                     }
                 }
             }
