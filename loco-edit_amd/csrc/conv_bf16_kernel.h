@@ -43,7 +43,9 @@ constexpr int NDUMMY = 0;   // (timing experiment only: invalid lanes clobber re
 constexpr int NDUMMY = 8;   // spare halo records per buffer: lanes without a halo item store there instead of branching
 #endif
 
-__device__ __forceinline__ float sigmoidf2_(float y) { return 1.0f / (1.0f + __expf(-y)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~10 VALU instructions fewer per element of the halo
+// conversion of the forward (GroupNorm + SiLU) convs, 2.6 % per denoiser evaluation
+__device__ __forceinline__ float sigmoidf2_(float y) { return __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
 
 // byte offset of logical 16-byte chunk q (0..3) inside the 64-byte record of index p
 __device__ __forceinline__ int rec_off(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
