@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(double* Gio, int k, dou
     __shared__ double cs[32], sn[32];
     __shared__ int pp[32], qq[32];
     __shared__ int order[64];
+    __shared__ double red_off[256], red_dia[256];
     const int tid = threadIdx.x;
     const int kp = (k + 1) & ~1;
     for (int e = tid; e < 64 * 64; e += 256) {
@@ -145,6 +146,25 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(double* Gio, int k, dou
             }
             __syncthreads();
         }
+        // converged?  max |off-diagonal| against max |diagonal| (cyclic Jacobi converges quadratically: 5-8 sweeps)
+        double off = 0.0, dia = 0.0;
+        for (int e = tid; e < k * k; e += 256) {
+            int i = e / k, j = e % k;
+            double v = fabs(G[i][j]);
+            if (i == j) dia = v > dia ? v : dia; else off = v > off ? v : off;
+        }
+        red_off[tid] = off; red_dia[tid] = dia;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                if (red_off[tid + st] > red_off[tid]) red_off[tid] = red_off[tid + st];
+                if (red_dia[tid + st] > red_dia[tid]) red_dia[tid] = red_dia[tid + st];
+            }
+            __syncthreads();
+        }
+        const bool done = red_off[0] <= 1e-15 * red_dia[0];
+        __syncthreads();
+        if (done) break;
     }
     if (tid == 0) {
         for (int i = 0; i < k; ++i) order[i] = i;
