@@ -385,3 +385,27 @@ def test_edge_cases_empty_mask_single_probe_full_mask(engines):
     assert vT.shape == (1, cfg.n) and u.shape == (cfg.n, 1) and torch.isfinite(vT).all()
     assert abs(float(vT.norm()) - 1.0) < 1e-4
     assert float((vT * vT2).sum().abs()) > 0.99999 and abs(float(sv[0] - sv2[0])) < 1e-4 * float(sv2[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [5, 6])
+def test_probe_batching_is_invariant_full_size(k, engines):
+    """J V and J^T U of a probe do not depend on how the probes are batched (5 and 6 probes exercise the tail-probe
+    split with one and two probes in the split-K tail; single-probe launches take neither path)."""
+    cfg = CELEBA_DDPM
+    eng = engines(cfg, "bf16x3")
+    s = _sched()
+    t = float(s.timesteps[40]); at = float(s.alpha_at(t))
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=g).to(DEV)
+    mask = torch.zeros(3, cfg.resolution, cfg.resolution, dtype=torch.bool)
+    mask[:, 110:130, 70:110] = True
+    eng.pmp_primal(x, t, at, mask.to(DEV))
+    V = torch.randn(k, cfg.n, generator=g).to(DEV)
+    U = eng.pmp_jvp(V)
+    A = eng.pmp_vjp(U)
+    for i in (0, k - 1):
+        Ui = eng.pmp_jvp(V[i:i + 1].contiguous())
+        Ai = eng.pmp_vjp(U[i:i + 1].contiguous())
+        assert float((U[i] - Ui[0]).norm() / Ui[0].norm()) < 1e-5     # split-K factors differ with the batch: rounding only
+        assert float((A[i] - Ai[0]).norm() / Ai[0].norm()) < 1e-5
