@@ -2,47 +2,88 @@
 """Benchmark of the LOCO-Edit hot path on MI355X.
 
 Metric (BASELINE.json): edit-directions/sec for a top-5 PMP-Jacobian basis at
-256x256, t = 0.6T.  One *step* = one complete subspace solve on synthetic input
-(BASELINE.md section 4): denoiser = CelebA-HQ DDPM architecture with the
-deterministic synthetic checkpoint (seed 0), x_t = randn (seed 1),
-t = timesteps[40] = 595.36, mask = rows 110:130 x cols 70:110 on 3 channels
-(L = 2400), V0 = randn (seed 7), 12 power iterations (the reference's minimum,
-edit.py:2492 with min_iter=10), i.e. per step: thin QR of V0, 1 primal pass,
-12 x (k tangent passes + k cotangent passes + Gram/eig re-orthonormalisation).
+256x256, t = 0.6T, + vT cosine similarity against the reference.  One *step* =
+one complete subspace solve on synthetic input:
+denoiser = CelebA-HQ DDPM architecture with the deterministic synthetic
+checkpoint (seed 0), x_t = randn (seed 1), t = timesteps[40] = 595.36, mask =
+rows 110:130 x cols 70:110 on 3 channels (L = 2400), V0 = randn (seed 7), 12
+power iterations (the reference's minimum, edit.py:2492 with min_iter=10), i.e.
+per step: thin QR of V0, 1 primal pass, 12 x (k tangent passes + k cotangent
+passes + Gram/eig re-orthonormalisation).
 
-N GPUs: weak scaling -- every rank keeps 5 probes (k = 5 N probes of ONE image
-sharded over ranks, one RCCL all-gather of the A shards per iteration, the
-k x k algebra replicated); value = 5 N directions / step time.
+Workloads (--workload):
+  celeba_top5 (default, the headline): N GPUs = weak scaling -- every rank keeps 5
+      probes (k = 5 N probes of ONE image sharded over ranks, one RCCL all-gather
+      of the A shards per iteration, the k x k algebra replicated); value = 5 N
+      directions / step time.
+  p2_k64 (BASELINE config 3): FFHQ-P2 architecture, 64 probes sharded over the N
+      ranks (strong scaling, 64/N per rank), keep the leading 20 rows; value = 20 /
+      step time.  The default run also times one step of it and reports it under
+      "extra_workloads" next to the headline line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--precision P]
+                    [--no-cpu-baseline] [--no-e2e] [--no-extra]
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (python -m torch.distributed.run, one process per GPU) before anything
+touches the GPU and relays rank 0's JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import loco_edit_amd  # noqa: E402
-from loco_edit_amd.config import CELEBA_DDPM, synth_params  # noqa: E402
-from loco_edit_amd.dist import ProbeSharder  # noqa: E402
-from loco_edit_amd.hip import LocoEngine  # noqa: E402
-from loco_edit_amd.scheduler import YHCustomScheduler  # noqa: E402
-from loco_edit_amd import solver  # noqa: E402
 
 K_PER_GPU = 5
 N_ITER = 12
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (Chip-level parameters)
 PEAK_F32_MFMA_TF = 157.3      # v_mfma_f32_32x32x2_f32 (exact fp32)
-PEAK_BF16_MFMA_TF = 2500.0    # v_mfma_f32_32x32x16_bf16; the split-bf16 path issues 3 MFMA flops per algorithmic flop
+PEAK_BF16_MFMA_TF = 2500.0    # v_mfma_f32_32x32x16_bf16 / _f16; the split-bf16 path issues 3 MFMA flops per algorithmic flop
+DTYPE_NOTE = {
+    "bf16x3": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate + fp32 storage)",
+    "f32": "f32",
+    "f16": "f16 (single f16 MFMA per product, fp32 accumulate + fp32 storage)",
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["celeba_top5", "p2_k64"], default="celeba_top5")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end phase timing (inversion ... decode)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra workload (p2_k64) and extra precision lines")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16"], default=os.environ.get("LOCO_PRECISION", "bf16x3"),
+                    help="conv arithmetic: exact fp32 MFMA, split-bf16 (3 bf16 MFMAs per product, fp32-faithful), or "
+                         "one f16 MFMA per product")
+    return ap.parse_args()
+
+
+def launch_ranks(n):
+    """Parent of a multi-GPU run: start n fresh rank processes (this process never touches the GPU), relay their
+    output, exit with their code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def synthetic_inputs(cfg, k, device):
+    import torch
     x = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=torch.Generator().manual_seed(1)).to(device)
     mask = torch.zeros(3, cfg.resolution, cfg.resolution, dtype=torch.bool)
     r = cfg.resolution
@@ -73,6 +114,7 @@ def usable_cores():
 def cpu_baseline(cfg, params, t, budget_s=30.0):
     """Reference algorithm (oracle = pinned restatement: jacfwd + autograd.functional.jacobian
     + svd) timed on the host cores on a BOUNDED sample of the same workload (<= ~30 s)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import loco_oracle as orc
     cores = usable_cores()
@@ -96,29 +138,106 @@ def cpu_baseline(cfg, params, t, budget_s=30.0):
         t0 = time.time()
         oed.pullback(x, tt, 1, v0, min_iter=1, max_iter=1, mask=mask)
         t_iter1 = time.time() - t0
-        t_iter5 = t_iter1 * (3 * 5 + 1) / (3 * 1 + 1)   # reference cost model (3k+1)F, BASELINE.md section 2
+        scale = (3 * 5 + 1) / (3 * 1 + 1)              # reference cost model (3k+1)F, BASELINE.md section 2
+        t_iter5 = t_iter1 * scale
         sample = (f"1 power iteration (jacfwd JVP + autograd VJP + svd) at k=1, 256x256, fp32: {t_iter1:.1f} s; "
-                  f"U-Net forward {t_fwd:.2f} s; scaled to k=5 x {N_ITER} iterations by the (3k+1)F cost model")
+                  f"U-Net forward {t_fwd:.2f} s; EXTRAPOLATED to k=5 x {N_ITER} iterations by the (3k+1)F cost model")
+        measured, factor = t_iter1, scale * N_ITER
     else:
         t_iter5 = t_fwd * (3 * 5 + 1)
         sample = (f"U-Net forward 256x256 fp32: {t_fwd:.2f} s (a full power iteration would exceed the {budget_s:.0f} s "
-                  f"sample budget); scaled by the reference's (3k+1) forward-equivalents per iteration, k=5 x {N_ITER}")
+                  f"sample budget); EXTRAPOLATED by the reference's (3k+1) forward-equivalents per iteration, k=5 x {N_ITER}")
+        measured, factor = t_fwd, (3 * 5 + 1) * N_ITER
     val = K_PER_GPU / (N_ITER * t_iter5)
-    return {"value": val, "unit": "edit-directions/s", "cores": cores, "kind": "port", "sample": sample}
+    return {"value": val, "unit": "edit-directions/s", "cores": cores, "kind": "port", "extrapolated": True,
+            "measured_sample_s": round(measured, 3), "scale_factor_to_full_solve": round(factor, 2), "sample": sample}
+
+
+def parity_vs_fixture(s, vT, name):
+    """|cos| of every row of vT and the relative error of s against the fixture the REFERENCE produced on the same
+    inputs (tests/golden/<name>.pt, written by oracle/make_golden.py from /root/reference; edit.py:2406-2504)."""
+    import torch
+    path = os.path.join(ROOT, "tests", "golden", name + ".pt")
+    if not os.path.exists(path):
+        return None
+    g = torch.load(path)
+    k = g["s_modify"].shape[0]
+    ref = g["vT_modify_f16"].float()
+    ref = ref / ref.norm(dim=1, keepdim=True)
+    v = vT[:k].detach().cpu().float()
+    cos = (v * ref).sum(dim=1).abs()
+    ov = torch.linalg.svdvals(v.double() @ ref.double().T)          # principal-angle cosines of the two spans
+    srel = ((s[:k].detach().cpu() - g["s_modify"]).abs() / g["s_modify"]).max()
+    return {"fixture": f"tests/golden/{name}.pt (reference output, {g['n_iter']} iterations, same x/t/mask/V0)",
+            "n_iter": int(g["n_iter"]), "cos_min": round(float(cos.min()), 6), "cos": [round(float(c), 6) for c in cos],
+            "span_cos_min": round(float(ov.min()), 6), "s_relerr": float(f"{float(srel):.3e}"),
+            "bar": "|cos| >= 0.99 (north_star)"}
+
+
+def e2e_phases(eng, cfg, sched_cls, solver, device):
+    """The reference flow a5 -> a11 on one synthetic image, seconds per phase (edit.py:2216-2366 with
+    --pca_rank 5 --pca_rank_null 5, 12 power iterations per solve, scale 0.5 x 16 steps, vis_num 2)."""
+    import torch
+    sync = torch.cuda.synchronize
+    out = {}
+    inv = sched_cls(); inv.set_timesteps(100, is_inversion=True)
+    fwd = sched_cls(); fwd.set_timesteps(100)
+    x0 = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=torch.Generator().manual_seed(0)).clamp(-1, 1).to(device)
+
+    def chain(x, sched, i0, i1):
+        for i in range(i0, i1):
+            t = sched.timesteps[i]
+            x = eng.ddim_step(x, float(t), sched.alpha_at(t), sched.alpha_at(sched.timesteps_next[i]), 0.0, None)
+        return x
+    sync(); t0 = time.perf_counter()
+    xT = chain(x0, inv, 0, len(inv.timesteps) - 1)                       # 98 evaluations, B = 1 (edit.py:2147-2148)
+    sync(); out["inversion_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    xt = chain(xT, fwd, 0, 40)                                           # 40 evaluations to t = 0.6T
+    sync(); out["to_t_s"] = time.perf_counter() - t0
+    t = float(fwd.timesteps[40]); at = fwd.alpha_at(t)
+    mask = torch.zeros(3, cfg.resolution, cfg.resolution, dtype=torch.bool, device=device)
+    mask[:, 110:130, 70:110] = True
+    g = torch.Generator().manual_seed(7)
+    v0m, v0n = torch.randn(cfg.n, 5, generator=g).to(device), torch.randn(cfg.n, 5, generator=g).to(device)
+    sync(); t0 = time.perf_counter()
+    _, _, vTm, _ = solver.local_basis(eng, xt, t, at, 5, mask=mask, min_iter=N_ITER, max_iter=N_ITER, v0=v0m, verbose=False)
+    _, _, vTn, _ = solver.local_basis(eng, xt, t, at, 5, mask=~mask, min_iter=N_ITER, max_iter=N_ITER, v0=v0n, verbose=False)
+    sync(); out["two_solves_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    vT = eng.null_project(vTm, vTn)
+    xb = eng.edit_axpy(xt, vT[0].contiguous(), [-8.0, -4.0, 0.0, 4.0, 8.0])
+    sync(); out["projection_edit_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dec = chain(xb, fwd, 40, 99)                                         # 59 steps x 5 frames of ONE direction (eta = 0)
+    sync(); out["decode_one_direction_s"] = time.perf_counter() - t0
+    out = {k: round(v, 4) for k, v in out.items()}
+    out["basis_plus_edit_s"] = round(out["two_solves_s"] + out["projection_edit_s"], 4)
+    out["image_total_one_direction_s"] = round(sum(out[k] for k in ("inversion_s", "to_t_s", "two_solves_s",
+                                                                     "projection_edit_s", "decode_one_direction_s")), 4)
+    out["note"] = ("synthetic weights; decode = 59 DDIM steps of the 5-frame +/- walk of one direction (the reference "
+                   "decodes every direction: x5 for a top-5 basis); finite output: " + str(bool(torch.isfinite(dec).all())))
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default=os.environ.get("LOCO_PRECISION", "bf16x3"),
-                    help="conv arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product, fp32-faithful)")
-    a = ap.parse_args()
+    a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        launch_ranks(a.gpus)            # never returns
+    world = int(env_world or "1")
+    if world != a.gpus and not (env_world is None and a.gpus == 1):
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    import loco_edit_amd  # noqa: F401
+    from loco_edit_amd.config import CELEBA_DDPM, FFHQ_P2, synth_params
+    from loco_edit_amd.dist import ProbeSharder
+    from loco_edit_amd.hip import LocoEngine
+    from loco_edit_amd.scheduler import YHCustomScheduler
+    from loco_edit_amd import solver
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # LOCO_BENCH_BACKEND=gloo lets several ranks share one GPU (a smoke test of the sharded path on a 1-GPU box);
@@ -136,44 +255,54 @@ def main():
             dist.init_process_group(backend=backend)
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-
-    cfg = CELEBA_DDPM
-    params = synth_params(cfg, seed=0)
-    eng = LocoEngine(cfg, max_batch=8, device=device)
-    eng.load_state_dict(params)
-    eng.set_precision(a.precision)
     sched = YHCustomScheduler()
     sched.set_timesteps(100)
     t = float(sched.timesteps[40])
     at = sched.alpha_at(t)
-    k = K_PER_GPU * world
-    x, mask, v0 = synthetic_inputs(cfg, k, device)
     sharder = ProbeSharder("world")
-
-    def step():
-        return solver.local_basis(eng, x, t, at, k, mask=mask, min_iter=N_ITER, max_iter=N_ITER,
-                                  convergence_threshold=1e-4, v0=v0, sharder=sharder, verbose=False)
-
-    for _ in range(a.warmup):
-        step()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        u, s, vT, n_iter = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, res
+
+    def make_workload(name, prec):
+        if name == "celeba_top5":
+            cfg, k, keep = CELEBA_DDPM, K_PER_GPU * world, K_PER_GPU * world
+        else:
+            cfg, k, keep = FFHQ_P2, 64, 20
+        params = synth_params(cfg, seed=0)
+        eng = LocoEngine(cfg, max_batch=8, device=device)
+        eng.load_state_dict(params)
+        eng.set_precision(prec)
+        x, mask, v0 = synthetic_inputs(cfg, k, device)
+
+        def step():
+            return solver.local_basis(eng, x, t, at, k, mask=mask, min_iter=N_ITER, max_iter=N_ITER,
+                                      convergence_threshold=1e-4, v0=v0, sharder=sharder, verbose=False)
+        return dict(cfg=cfg, k=k, keep=keep, eng=eng, params=params, step=step, x=x, mask=mask, v0=v0)
+
+    w = make_workload(a.workload, a.precision)
+    eng, cfg, k, keep = w["eng"], w["cfg"], w["k"], w["keep"]
+    elapsed, (u, s, vT, n_iter) = timed(w["step"], a.steps, a.warmup)
     ms_per_step = elapsed / a.steps * 1e3
-    value = k / (elapsed / a.steps)
+    value = keep / (elapsed / a.steps)
+    k_local = sharder.rows(k)[1] - sharder.rows(k)[0]
 
     # ---- roofline leg: per-kernel HIP-event profile of one more identical step
     roofline = None
@@ -184,7 +313,7 @@ def main():
             eng.profile_enable(True)
         torch.cuda.synchronize()
         tp0 = time.perf_counter()
-        step()
+        w["step"]()
         torch.cuda.synchronize()
         t_prof = time.perf_counter() - tp0
     if rank == 0 and not a.no_profile:
@@ -195,53 +324,116 @@ def main():
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
         if a.precision == "bf16x3":
             peak, issued = PEAK_BF16_MFMA_TF, 3.0 * achieved
+        elif a.precision == "f16":
+            peak, issued = PEAK_BF16_MFMA_TF, achieved
         else:
             peak, issued = PEAK_F32_MFMA_TF, achieved
         tot_ms = sum(v["ms"] for v in rep.values())
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and a.workload == "celeba_top5":
             try:
-                traffic = json.load(open(tpath)).get(name)
+                tj = json.load(open(tpath))
+                traffic = tj.get(name)
+                traffic_src = tj.get("_source", "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                                "command, stored (not re-measured by this run)")
             except Exception:
                 traffic = None
+        executed = (1 + 2 * k_local * N_ITER) * F      # the primal runs once per solve
         roofline = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "mfma_flops_issued_TFLOPs": round(issued, 2), "mfma_issue_frac": round(issued / peak, 4),
             "note": ("achieved = algorithmic 2*MAC / time, frac = achieved / dense bf16 MFMA peak; split-bf16 issues 3 "
                      "MFMA flops per algorithmic flop, so the matrix pipe itself runs at mfma_issue_frac of peak "
                      "(the exact-fp32 MFMA peak is 157.3 TF/s)" if a.precision == "bf16x3" else
-                     "achieved = algorithmic 2*MAC / time on the exact-fp32 MFMA"),
+                     "achieved = algorithmic 2*MAC / time on " + ("the exact-fp32 MFMA" if a.precision == "f32"
+                                                                  else "one f16 MFMA per product")),
             "launches": r["launches"], "avg_launch_ms": round(r["ms"] / r["launches"], 4),
             "flops_per_launch": r["flops"] / r["launches"],
             "conv_share_of_step": round(tot_ms / (t_prof * 1e3), 3),
-            "whole_step_TFLOPs": round((1 + 2 * K_PER_GPU) * F * N_ITER / (ms_per_step * 1e-3) / 1e12, 2),
+            "whole_step_TFLOPs_executed_per_gpu": round(executed / (ms_per_step * 1e-3) / 1e12, 2),
             "all_conv_kernels": {n: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                      "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                  for n, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])},
         }
+
+    # ---- parity leg (outside the timed region): the metric's second half, vT cosine vs the reference
+    parity = None
+    if a.workload == "celeba_top5":
+        if world == 1:
+            ps, pvT = s, vT
+        else:   # the k = 5 solve of the fixture, replicated on every rank (no collective), reported by rank 0
+            x5, m5, v05 = synthetic_inputs(cfg, K_PER_GPU, device)
+            _, ps, pvT, _ = solver.local_basis(eng, x5, t, at, K_PER_GPU, mask=m5, min_iter=N_ITER, max_iter=N_ITER,
+                                               v0=v05, sharder=ProbeSharder(None), verbose=False)
+        if rank == 0:
+            parity = parity_vs_fixture(ps, pvT, "celeba256")
+
+    extra = {}
+    e2e = None
+    if rank == 0 and world == 1 and a.workload == "celeba_top5" and not a.no_e2e:
+        e2e = e2e_phases(eng, cfg, YHCustomScheduler, solver, device)
+    if a.workload == "celeba_top5" and not a.no_extra:
+        # other conv arithmetic modes on the same workload, one timed step each, with their measured cosine
+        if world == 1:
+            for prec in ("f16", "f32"):
+                if prec == a.precision:
+                    continue
+                try:
+                    eng.set_precision(prec)
+                except Exception:
+                    continue
+                el, (_, s2, vT2, _) = timed(w["step"], 1, 1)
+                extra[f"celeba_top5_{prec}"] = {"value": round(keep / el, 4), "unit": "edit-directions/s",
+                                                "ms_per_step": round(el * 1e3, 3), "dtype": DTYPE_NOTE[prec],
+                                                "parity": parity_vs_fixture(s2, vT2, "celeba256")}
+            eng.set_precision(a.precision)
+        # BASELINE config 3 next to the headline: FFHQ-P2, 64 probes over the ranks, keep 20
+        w2 = make_workload("p2_k64", a.precision)
+        el, (_, s3, vT3, _) = timed(w2["step"], 1, 1)
+        if rank == 0:
+            F2 = w2["eng"].unet_flops()
+            kl = sharder.rows(64)[1] - sharder.rows(64)[0]
+            extra["p2_k64"] = {
+                "value": round(20 / el, 4), "unit": "edit-directions/s (20 kept of 64 probes)", "ms_per_step": round(el * 1e3, 3),
+                "scaling": "strong", "n_gpus": world, "probes_per_gpu": kl, "n_iter": N_ITER,
+                "whole_step_TFLOPs_executed_per_gpu": round((1 + 2 * kl * N_ITER) * F2 / el / 1e12, 2),
+                "singular_values_head": [round(float(v), 4) for v in s3.tolist()[:5]],
+                "orthonormality_err": float(f"{float((vT3[:20] @ vT3[:20].T - torch.eye(20, device=device)).abs().max()):.2e}"),
+            }
+
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, params, t)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "celeba_top5":
+        cpu = cpu_baseline(cfg, w["params"], t)
 
     if rank == 0:
+        if a.workload == "celeba_top5":
+            metric = "edit-directions/sec (top-5 PMP-Jacobian SVD @256^2) + vT cos-sim vs ref"
+            wl = ("CelebA-HQ DDPM 256x256 top-5 local basis (l_eye-sized mask, L=2400), t=0.6T, 12 power iterations, "
+                  "probes sharded 5 per GPU")
+            scaling = "weak"
+        else:
+            metric = "edit-directions/sec (rank-20 of 64 probes, FFHQ-P2 @256^2)"
+            wl = ("FFHQ-P2 256x256 rank-20 basis from 64 probes (l_eye-sized mask, L=2400), t=0.6T, 12 power iterations, "
+                  "64 probes sharded over the GPUs")
+            scaling = "strong"
         out = {
-            "metric": "edit-directions/sec (top-5 PMP-Jacobian SVD @256^2)",
+            "metric": metric,
             "value": round(value, 4), "unit": "edit-directions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16x3 (split-bf16 MFMA operands, fp32 accumulate + fp32 storage)" if a.precision == "bf16x3"
-                      else "f32"), "data": "synthetic",
-            "config": {"workload": "CelebA-HQ DDPM 256x256 top-5 local basis (l_eye-sized mask, L=2400), "
-                                   "t=0.6T, 12 power iterations, probes sharded 5 per GPU",
-                       "probes_total": k, "n_iter": int(n_iter), "mask_L": int(mask.sum().item()),
-                       "weights": "synthetic seed 0"},
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": DTYPE_NOTE[a.precision], "data": "synthetic",
+            "config": {"workload": wl, "probes_total": k, "probes_per_gpu": k_local, "kept": keep, "n_iter": int(n_iter),
+                       "mask_L": int(w["mask"].sum().item()), "weights": "synthetic seed 0",
+                       "convergence_check": "not executed inside the timed region (min_iter == max_iter == 12; the "
+                                            "reference flow with min_iter=10 adds one 2-float readback per iteration after the 11th)"},
             "singular_values": [round(float(v), 4) for v in s.tolist()[:5]],
-            "roofline": roofline, "cpu_baseline": cpu,
+            "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "extra_workloads": extra or None,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -28,6 +28,8 @@ typedef struct loco_ctx loco_ctx;
 /* Architecture of the denoiser: reference src/configs/custom_celeba_ddpm.yml
  * `model:` block + DDPM.__init__ (src/models/ddpm/diffusion.py:22-126). */
 typedef struct loco_unet_cfg {
+    int32_t struct_size;       /* = sizeof(loco_unet_cfg) of the header the caller was built against; loco_create
+                                  refuses a mismatch instead of reading past an older binding's struct */
     int32_t resolution;        /* data.image_size */
     int32_t in_channels;       /* model.in_channels */
     int32_t out_ch;            /* model.out_ch */
@@ -124,6 +126,8 @@ int  loco_edit_axpy(loco_ctx* ctx, const float* x, const float* v, const float* 
                     int32_t B, int64_t n, float* out, void* stream);
 /* Compact the masked entries: out[k, L] = U[k, mask] (P_xt[:, mask], edit.py:2390). */
 int  loco_mask_gather(loco_ctx* ctx, const float* U, int32_t k, float* out, void* stream);
+/* L = number of selected mask elements of the last loco_pmp_primal (C*H*W without a mask).  The gather list is built
+ * on the device; the first call after a primal reads L back (one 4-byte copy + stream sync). */
 int64_t loco_mask_count(loco_ctx* ctx);
 
 /* Work model helpers for bench.py: 2*MAC of one denoiser evaluation (B=1). */
@@ -139,7 +143,10 @@ int  loco_timer_stop(loco_ctx* ctx, void* stream, float* ms);
 
 /* Arithmetic of the convolutions: 0 = exact fp32 (v_mfma_f32_32x32x2_f32, the parity
  * anchor), 1 = split-bf16 "bf16x3" (3 x v_mfma_f32_32x32x16_bf16 per product, fp32
- * accumulate, fp32-faithful to ~2^-16; the default).  Env LOCO_PRECISION=f32|bf16x3 overrides.
+ * accumulate, fp32-faithful to ~2^-16; the default), 2 = "f16" (one v_mfma_f32_32x32x16_f16
+ * per product: operands rounded to 11 significant bits -- the precision class of the TF32
+ * convolutions the reference's CUDA path runs by PyTorch default --, fp32 accumulate and
+ * fp32 tensors in HBM).  Env LOCO_PRECISION=f32|bf16x3|f16 sets the initial mode.
  * Invalidates the cached primal. */
 int  loco_set_precision(loco_ctx* ctx, int32_t mode);
 int  loco_get_precision(loco_ctx* ctx);
@@ -148,9 +155,6 @@ int  loco_get_precision(loco_ctx* ctx);
  * mode: 0 raw, 1 GN+SiLU, 2 GN, 3 tangent, 4 cotangent; tile: -1 auto or a variant id. */
 int  loco_bench_conv(loco_ctx* ctx, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t B, int32_t mode,
                      int32_t taps, int32_t tile, int32_t iters, float* ms_avg, void* stream);
-
-/* Diagnostic builds only (-DLOCO_STAMP): copy the first n floats of the split-K workspace to the host. */
-int  loco_debug_read_scratch(loco_ctx* ctx, float* dst_host, int32_t n);
 
 /* Per-kernel HIP-event profile of the convolution launches (bench.py roofline
  * leg).  While enabled every conv launch is bracketed by two events on the

@@ -351,16 +351,18 @@ int conv_bf16_pick_tile(int Cout, int HW, int Bsplit);   // conv_bf16.hip
 
 const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
     static const char* tiles[6] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1", "2,2,2,4", "2,4,2,2"};
-    static char names[2][2][6][5][56];
+    static char names[3][2][6][5][56];
     int t = prec ? conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B * a.nsplit) : pick_tile(a.Cout, a.Hout * a.Wout);
-    if (prec && a.stride == 2 && (t == 5 || t == 4)) t = 0;
+    if (prec && t == 4) t = 5;
+    if (prec && a.stride == 2 && t == 5) t = 0;
     if (t < 0 || t > 5) t = 0;
     int ti = taps == 9 ? 0 : 1;
     int m = a.mode;
     if (taps != 9 && m != CM_NONE) m = CM_GN;
     if (m < 0 || m > 4) m = 2;
-    char* n = names[prec ? 1 : 0][ti][t][m];
-    if (!n[0]) snprintf(n, 56, "%s<%d,%s,%d>", prec ? "conv_mfma_bf16x3" : "conv_mfma_f32", taps, tiles[t], m);
+    char* n = names[prec][ti][t][m];
+    static const char* kn[3] = {"conv_mfma_f32", "conv_mfma_bf16x3", "conv_mfma_f16"};
+    if (!n[0]) snprintf(n, 56, "%s<%d,%s,%d>", kn[prec], taps, tiles[t], m);
     return n;
 }
 

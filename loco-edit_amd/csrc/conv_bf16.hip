@@ -7,7 +7,8 @@ namespace loco {
 
 constexpr int BKC = 16;
 int conv_pick_tile(int Cout, int HW);   // conv.hip
-template <int TAPS, int MODE> void launch_tile_b(const ConvArgs& a, hipStream_t st);   // conv_bf16_inst_*.hip
+template <int PR, int TAPS, int MODE> void launch_tile_b(const ConvArgs& a, hipStream_t st);   // conv_bf16_inst_*.hip
+enum : int { PR_BF16X3 = 0, PR_F16 = 1 };
 
 int g_bf16_tile_override = -1;   // debug / tuning: force a tile variant for the big-image case
 
@@ -39,7 +40,8 @@ int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B) {
 
 int bf16_tile_of(const ConvArgs& a) {
     int tile = conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B * a.nsplit);
-    if (a.stride == 2 && (tile == 5 || tile == 4)) tile = 0;   // the double-buffered stride-2 halo of a 256-pixel tile exceeds LDS
+    if (tile == 4) tile = 5;
+    if (a.stride == 2 && tile == 5) tile = 0;   // the double-buffered stride-2 halo of a 256-pixel tile exceeds LDS
     return tile;
 }
 int conv_bf16_tile_pixels(const ConvArgs& a) {
@@ -47,21 +49,24 @@ int conv_bf16_tile_pixels(const ConvArgs& a) {
     return NTs[bf16_tile_of(a)];
 }
 
-void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st) {
+template <int PR>
+static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
     if (taps == 9) {
         switch (a.mode) {
-            case CM_NONE: launch_tile_b<9, CM_NONE>(a, st); break;
-            case CM_GN_SILU: launch_tile_b<9, CM_GN_SILU>(a, st); break;
-            case CM_TAN_SILU: launch_tile_b<9, CM_TAN_SILU>(a, st); break;
-            case CM_COT_SILU: launch_tile_b<9, CM_COT_SILU>(a, st); break;
-            default: launch_tile_b<9, CM_GN>(a, st); break;
+            case CM_NONE: launch_tile_b<PR, 9, CM_NONE>(a, st); break;
+            case CM_GN_SILU: launch_tile_b<PR, 9, CM_GN_SILU>(a, st); break;
+            case CM_TAN_SILU: launch_tile_b<PR, 9, CM_TAN_SILU>(a, st); break;
+            case CM_COT_SILU: launch_tile_b<PR, 9, CM_COT_SILU>(a, st); break;
+            default: launch_tile_b<PR, 9, CM_GN>(a, st); break;
         }
     } else {
         switch (a.mode) {
-            case CM_NONE: launch_tile_b<1, CM_NONE>(a, st); break;
-            default: launch_tile_b<1, CM_GN>(a, st); break;
+            case CM_NONE: launch_tile_b<PR, 1, CM_NONE>(a, st); break;
+            default: launch_tile_b<PR, 1, CM_GN>(a, st); break;
         }
     }
 }
+void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st) { launch_lowp<PR_BF16X3>(a, taps, st); }
+void launch_conv_f16(const ConvArgs& a, int taps, hipStream_t st) { launch_lowp<PR_F16>(a, taps, st); }
 
 }  // namespace loco

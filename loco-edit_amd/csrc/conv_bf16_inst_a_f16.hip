@@ -2,5 +2,5 @@
 #include "conv_bf16_kernel.h"
 
 namespace loco {
-template void launch_tile_b<PR_BF16X3, 9, CM_TAN_SILU>(const ConvArgs&, hipStream_t);
+template void launch_tile_b<PR_F16, 9, CM_NONE>(const ConvArgs&, hipStream_t);
 }  // namespace loco

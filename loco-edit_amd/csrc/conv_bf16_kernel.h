@@ -17,10 +17,6 @@
 // scheduling regions so LDS reads, halo conversion and re-loads sit under the MFMAs
 // (see the pipeline comment in the kernel and profiles/r01_conv_whatif.md).
 //
-// Development switches (never set in the shipped build): LOCO_EXP=<bitmask> drops one
-// ingredient of the stage for what-if timing (results are wrong by construction),
-// LOCO_DEV_ONE / LOCO_DEV_TILE0 / LOCO_DEV_TILE4 instantiate a single variant for
-// fast ISA inspection, LOCO_STAMP records per-phase cycle counters.
 // This header holds the kernel template and its per-(TAPS, MODE) launcher; conv_bf16_inst_*.hip instantiate
 // disjoint subsets so the variants compile in parallel, conv_bf16.hip holds the tile heuristics and the dispatch.
 #pragma once
@@ -32,41 +28,61 @@ namespace loco {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));      // 16-byte operand fragment, reinterpreted per arithmetic
 
-#ifndef LOCO_EXP
-#define LOCO_EXP 0     // development: what-if variants that drop one ingredient of the stage (timing only, wrong results)
-#endif
+// Operand arithmetic (template parameter PR):
+//   PR_BF16X3: every fp32 operand as hi + lo bf16, 3 MFMAs per product (fp32-faithful, 64-byte records
+//              [hi k0-7|hi k8-15|lo k0-7|lo k8-15]);
+//   PR_F16:    operands rounded to f16 (11 significant bits), ONE v_mfma_f32_32x32x16_f16 per product, 32-byte
+//              records [k0-7|k8-15]: a third of the matrix work, half the LDS and weight traffic.
+enum : int { PR_BF16X3 = 0, PR_F16 = 1 };
+
 constexpr int BKC = 16;
-#ifdef LOCO_DEV_TILE0
-constexpr int NDUMMY = 0;   // (timing experiment only: invalid lanes clobber record 0)
-#else
 constexpr int NDUMMY = 8;   // spare halo records per buffer: lanes without a halo item store there instead of branching
-#endif
 
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~10 VALU instructions fewer per element of the halo
 // conversion of the forward (GroupNorm + SiLU) convs, 2.6 % per denoiser evaluation
 __device__ __forceinline__ float sigmoidf2_(float y) { return __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
 
-// byte offset of logical 16-byte chunk q (0..3) inside the 64-byte record of index p
-__device__ __forceinline__ int rec_off(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
-// Halo records use a PADDED pitch instead of the XOR swizzle: 80 bytes = 20 dwords, so 16 consecutive records hit 16
-// disjoint 4-dword bank groups (ds_read_b128 conflict-free) AND the offset stays affine in the record index -- a tap
-// shift is then a wave-uniform addend, where the swizzle needed one precomputed VGPR offset per (tap, operand).
-constexpr int HP = 80;
-__device__ __forceinline__ int hrec_off(int p, int q) { return p * HP + (q << 4); }
+// byte offset of logical 16-byte chunk q inside the weight record of index p: 64-byte records (bf16x3) XOR the chunk
+// with (p>>2)&3, 32-byte records (f16) with (p>>3)&1 -- either way the 16 lanes of a ds_read_b128 service group hit 16
+// disjoint 4-dword bank groups
+template <int PR>
+__device__ __forceinline__ int rec_off(int p, int q) {
+    if constexpr (PR == PR_F16) return p * 32 + ((q ^ ((p >> 3) & 1)) << 4);
+    else return p * 64 + ((q ^ ((p >> 2) & 3)) << 4);
+}
+// Halo records use a PADDED pitch instead of the XOR swizzle: 80 bytes = 20 dwords (48 bytes = 12 dwords for the
+// 32-byte f16 records), so 16 consecutive records hit 16 disjoint 4-dword bank groups (ds_read_b128 conflict-free) AND
+// the offset stays affine in the record index -- a tap shift is then a wave-uniform addend, where the swizzle needed one
+// precomputed VGPR offset per (tap, operand).
+template <int PR> constexpr int halo_pitch() { return PR == PR_F16 ? 48 : 80; }
+template <int PR> constexpr int rec_bytes() { return PR == PR_F16 ? 32 : 64; }
+template <int PR>
+__device__ __forceinline__ int hrec_off(int p, int q) { return p * halo_pitch<PR>() + (q << 4); }
 
-__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
-    unsigned h[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 hb = (__bf16)v[j];
-        float r = v[j] - (float)hb;
-        __bf16 lb = (__bf16)r;
-        h[j] = __builtin_bit_cast(unsigned short, hb);
-        l[j] = __builtin_bit_cast(unsigned short, lb);
+// two fp32 values -> one dword of packed 16-bit operands (hi part) and, for bf16x3, the dword of their residuals
+template <int PR>
+__device__ __forceinline__ void cvt2(float a, float b, unsigned& hi, unsigned& lo) {
+    if constexpr (PR == PR_F16) {
+        _Float16 ha = (_Float16)a, hb = (_Float16)b;
+        hi = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+        lo = 0;
+    } else {
+        __bf16 ha = (__bf16)a, hb = (__bf16)b;
+        __bf16 la = (__bf16)(a - (float)ha), lb = (__bf16)(b - (float)hb);
+        hi = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+        lo = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
     }
-    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+template <int PR>
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+    cvt2<PR>(v[0], v[1], hi.x, lo.x);
+    cvt2<PR>(v[2], v[3], hi.y, lo.y);
+    cvt2<PR>(v[4], v[5], hi.z, lo.z);
+    cvt2<PR>(v[6], v[7], hi.w, lo.w);
 }
 
 constexpr int max_halo(int NT, int taps, bool s2) {
@@ -79,13 +95,12 @@ constexpr int max_halo(int NT, int taps, bool s2) {
     return s2 ? 17 * 17 : 10 * 10;   // NT = 64 : 8x8 output tile
 }
 
-template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
-#ifdef LOCO_DEV_TILE0
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_bf16x3(ConvArgs a) {
-#else
-__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
-#endif
+template <int PR, int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
+__device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
     constexpr int NTHR = WM * WN * 64;
+    constexpr int HP = halo_pitch<PR>();
+    constexpr int RB = rec_bytes<PR>();               // bytes of one operand record (16 k-values of one pixel / cout)
+    constexpr int NPC = RB / 16;                      // 16-byte pieces per record
     constexpr int MT = WM * TM * 32;
     constexpr int NT = WN * TN * 32;
     constexpr int KS = (TAPS == 9) ? 3 : 1;
@@ -98,12 +113,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     // caller-owned tensors); 2: per-pixel staging sized for the stride-2 halo
     constexpr bool GEN = STG != 0;
     constexpr int NITEM = GEN ? (2 * max_halo(NT, TAPS, STG == 2) + NTHR - 1) / NTHR : 1;
-    constexpr int WTOT = NTS * MT * 4;               // 16-byte pieces of one weight stage
+    constexpr int WTOT = NTS * MT * NPC;             // 16-byte pieces of one weight stage
     constexpr int NWV = (WTOT + NTHR - 1) / NTHR;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     // double-buffered: weight stage s lives in W buffer s&1, the halo of chunk c in H buffer c&1
-    constexpr int WBYTES = NTS * MT * 64;
+    constexpr int WBYTES = NTS * MT * RB;
     unsigned char* const Wsb = smem_b;               // 2 x [NTS][MT] records
     unsigned char* Hsb;                              // 2 x [halo_sz] records (set below, needs halo_sz)
     unsigned char* Ws = smem_b;                      // W / H buffer the operand reads and the halo conversion address
@@ -226,14 +241,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     }
     int hbyte[TN];                           // byte offset of the lane's hi operand chunk inside a halo buffer
 #pragma unroll
-    for (int j = 0; j < TN; ++j) hbyte[j] = hrec_off(hoff[j], khalf);
+    for (int j = 0; j < TN; ++j) hbyte[j] = hrec_off<PR>(hoff[j], khalf);
     // A-operand (weight) record offsets inside one tap block: cout-local index fixed per lane
     int aoff_hi[TM], aoff_lo[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         int p = (wm * TM + i) * 32 + l31;
-        aoff_hi[i] = rec_off(p, khalf);
-        aoff_lo[i] = rec_off(p, 2 + khalf);
+        aoff_hi[i] = rec_off<PR>(p, khalf);
+        aoff_lo[i] = PR == PR_F16 ? 0 : rec_off<PR>(p, 2 + khalf);
     }
 
     f32x16 acc[TM][TN];
@@ -321,21 +336,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
                 }
                 r[kk] = ((v_pm >> pxi) & 1u) ? v : 0.0f;
             }
-            unsigned h[KP], l[KP];
-#pragma unroll
-            for (int kk = 0; kk < KP; ++kk) {
-                __bf16 hb = (__bf16)r[kk];
-                __bf16 lb = (__bf16)(r[kk] - (float)hb);
-                h[kk] = __builtin_bit_cast(unsigned short, hb);
-                l[kk] = __builtin_bit_cast(unsigned short, lb);
-            }
-            unsigned char* dst = Hs + hrec_off(v_rec[pxi], oct) + half * 8 + part * (KP * 2);
+            unsigned char* dst = Hs + hrec_off<PR>(v_rec[pxi], oct) + half * 8 + part * (KP * 2);
             if constexpr (KP == 4) {
-                *reinterpret_cast<uint2*>(dst) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                uint2 h, l;
+                cvt2<PR>(r[0], r[1], h.x, l.x);
+                cvt2<PR>(r[2], r[3], h.y, l.y);
+                *reinterpret_cast<uint2*>(dst) = h;
+                if constexpr (PR == PR_BF16X3) *reinterpret_cast<uint2*>(dst + 32) = l;
             } else {
-                *reinterpret_cast<unsigned*>(dst) = h[0] | (h[1] << 16);
-                *reinterpret_cast<unsigned*>(dst + 32) = l[0] | (l[1] << 16);
+                unsigned h, l;
+                cvt2<PR>(r[0], r[1], h, l);
+                *reinterpret_cast<unsigned*>(dst) = h;
+                if constexpr (PR == PR_BF16X3) *reinterpret_cast<unsigned*>(dst + 32) = l;
             }
         }
     };
@@ -390,16 +402,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     for (int i = 0; i < NWV; ++i) {
         int e = tid + i * NTHR;
         if (e >= WTOT) e = WTOT - 1;
-        int tap = e / (MT * 4), rem = e - tap * (MT * 4);
-        int rec = co0 + (rem >> 2);
+        int tap = e / (MT * NPC), rem = e - tap * (MT * NPC);
+        int rec = co0 + rem / NPC;
         if (rec >= wpitch) rec = wpitch - 1;
-        wrel[i] = (unsigned)((tap * wpitch + rec) * 4 + (rem & 3)) * 16u;
+        wrel[i] = (unsigned)((tap * wpitch + rec) * NPC + (rem % NPC)) * 16u;
     }
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     typedef const __attribute__((address_space(1))) unsigned char glb_u8;
     auto dma_w = [&](int chunk, int row, unsigned char* Wdst) {
         const unsigned char* wbase = reinterpret_cast<const unsigned char*>(wg) +
-                                     (unsigned)(chunk * TAPS + row * NTS) * ((unsigned)wpitch * 64u);
+                                     (unsigned)(chunk * TAPS + row * NTS) * ((unsigned)wpitch * (unsigned)RB);
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             const int e0 = (wave * 64 + i * NTHR);                 // first piece of this wave's 1 KiB slab
@@ -440,27 +452,28 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
                 v[k] = r;
             }
             uint4 hi, lo;
-            split8(v, hi, lo);
-            *reinterpret_cast<uint4*>(Hs + hrec_off(ipos[i], ioct[i])) = hi;
-            *reinterpret_cast<uint4*>(Hs + hrec_off(ipos[i], 2 + ioct[i])) = lo;
+            split8<PR>(v, hi, lo);
+            *reinterpret_cast<uint4*>(Hs + hrec_off<PR>(ipos[i], ioct[i])) = hi;
+            if constexpr (PR == PR_BF16X3) *reinterpret_cast<uint4*>(Hs + hrec_off<PR>(ipos[i], 2 + ioct[i])) = lo;
         }
     };
 
     // MFMA operand fragments of one tap; two sets alternate so the ds_reads of tap t+1 are in flight under the
     // MFMAs of tap t (one exposed LDS latency per stage instead of one per operand)
-    struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+    constexpr int NLO = PR == PR_BF16X3 ? 1 : 0;     // lo halves exist only in the split arithmetic
+    struct Frag { s16x8 ah[TM], al[NLO ? TM : 1], bh[TN], bl[NLO ? TN : 1]; };
     auto load_frag = [&](Frag& f, int row, int tp) {
         const int tapoff = (TAPS == 9) ? row * halo_w + tp : 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            f.ah[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_hi[i]);
-            f.al[i] = *reinterpret_cast<const bf16x8*>(Ws + tp * MT * 64 + aoff_lo[i]);
+            f.ah[i] = *reinterpret_cast<const s16x8*>(Ws + tp * MT * RB + aoff_hi[i]);
+            if constexpr (NLO) f.al[i] = *reinterpret_cast<const s16x8*>(Ws + tp * MT * RB + aoff_lo[i]);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const unsigned char* hp = Hs + tapoff * HP + hbyte[j];     // uniform tap shift + per-lane record base
-            f.bh[j] = *reinterpret_cast<const bf16x8*>(hp);
-            f.bl[j] = *reinterpret_cast<const bf16x8*>(hp + 32);
+            f.bh[j] = *reinterpret_cast<const s16x8*>(hp);
+            if constexpr (NLO) f.bl[j] = *reinterpret_cast<const s16x8*>(hp + 32);
         }
     };
     auto mma_frag = [&](const Frag& f) {
@@ -468,9 +481,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                if constexpr (PR == PR_F16) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.ah[i]),
+                                                                       __builtin_bit_cast(f16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+                } else {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, f.ah[i]), al = __builtin_bit_cast(bf16x8, f.al[i]);
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, f.bh[j]), bl = __builtin_bit_cast(bf16x8, f.bl[j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+                }
             }
     };
 
@@ -486,13 +506,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
     //   halo schedule, 3x3 vector path (2 parts A,B):  row0: store A | load B   row1: store B   row2: load A'
     //   3x3 per-pixel path (1 part):                   row0: load           row2: store
     //   1x1:                                           every stage: store | load
-#ifdef LOCO_STAMP
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = __builtin_readcyclecounter();
-#define STAMP(i) { unsigned long long tn = __builtin_readcyclecounter(); tacc[i] += tn - tprev; tprev = tn; }
-#else
-#define STAMP(i)
-#endif
     const int nch = cend - cbeg;
     const int clast = cend - 1;
     auto cclamp = [&](int c) { return __builtin_amdgcn_readfirstlane(c < clast ? c : clast); };   // keep it scalar
@@ -508,17 +521,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
         if constexpr (!GEN && NPART == 2) {
             // both parts of the first chunk are loaded together (a second register set that only lives here) so the
             // workgroup pays one memory latency, not two, before its first stage
-            if (!(LOCO_EXP & 128)) {
-                HaloRegs hr2;
-                prefetch_hv(hr, cbeg, 0);
-                prefetch_hv(hr2, cbeg, 1);
-                stage_hv(hr, 0);
-                stage_hv(hr2, 1);
-            }
+            HaloRegs hr2;
+            prefetch_hv(hr, cbeg, 0);
+            prefetch_hv(hr2, cbeg, 1);
+            stage_hv(hr, 0);
+            stage_hv(hr2, 1);
         } else {
 #pragma unroll
             for (int part = 0; part < NPART; ++part) {
-                if (LOCO_EXP & 128) continue;                     // what-if: no prologue halo
                 prefetch_h(cbeg, part);
                 stage_h(cbeg, part);
             }
@@ -546,147 +556,42 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
             constexpr bool MIDLOAD = !GEN;          // issue the loads inside the stage, behind the conversion
             // vector-memory instructions of one part's loads (for the counted wait that leaves them in flight)
             constexpr int NLD = KP + (NEEDP ? 2 * KP + 1 : (MODE != CM_NONE ? 2 : 0));
-            STAMP(0)
             // Regions fenced by sched_barrier(0): the machine scheduler would otherwise sink every ds_read to just
             // before its first use and expose one LDS latency per operand.
             {
                 const int r1 = (row + 1) % NROW, dc = (row + 1) / NROW;
-                if (!(LOCO_EXP & 8)) dma_w(cclamp(chunk + dc), r1, Wnxt);
+                dma_w(cclamp(chunk + dc), r1, Wnxt);
             }
             Ws = Wcur; Hs = Hcur;
             Frag f0, f1;
-#define X_MMA(f) do { if (!(LOCO_EXP & 1)) mma_frag(f); } while (0)
-#define X_LOAD(f, r, t) do { if (!(LOCO_EXP & 4) || (ci == 0 && r == 0)) load_frag(f, r, t); } while (0)
-            X_LOAD(f0, row, 0);
-            if (NTS > 1) X_LOAD(f1, row, 1);
+            load_frag(f0, row, 0);
+            if (NTS > 1) load_frag(f1, row, 1);
             __builtin_amdgcn_sched_barrier(0);
-            X_MMA(f0);
-            STAMP(1)
+            mma_frag(f0);
             __builtin_amdgcn_sched_barrier(0);
-            if (NTS > 2) X_LOAD(f0, row, 2);
+            if (NTS > 2) load_frag(f0, row, 2);
             __builtin_amdgcn_sched_barrier(0);
-            if (NTS > 1) X_MMA(f1);
+            if (NTS > 1) mma_frag(f1);
             // halo conversion, then the re-load of its registers, share one scheduling region with the MFMAs of taps
             // 1 and 2 (a fence between them measured 2.7 ms/step slower; conversion under tap 0 13 ms slower)
-            if (!(LOCO_EXP & 2) && st_part >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), st_part); Hs = Hcur; }
-            STAMP(2)
-            if (MIDLOAD && !(LOCO_EXP & 18) && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
-            STAMP(3)
-            if (NTS > 2) X_MMA(f0);
-            STAMP(4)
+            if (st_part >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), st_part); Hs = Hcur; }
+            if (MIDLOAD && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+            if (NTS > 2) mma_frag(f0);
             __builtin_amdgcn_sched_barrier(0);
             // the LDS-DMA of this stage (older than the part loads just issued) must have landed before the barrier
-            if (MIDLOAD && ld_part >= 0 && !(LOCO_EXP & 18)) {
+            if (MIDLOAD && ld_part >= 0) {
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!MIDLOAD && !(LOCO_EXP & 18) && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+                if (!MIDLOAD && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
             }
-            if (!(LOCO_EXP & 32)) stage_end();
+            stage_end();
         }
     }
-#ifdef LOCO_STAMP
-    if (blockIdx.x == 0 && (tid & 63) == 0) {
-        for (int i = 0; i < 6; ++i) a.partial[wave * 8 + i] = (float)tacc[i];
-    }
-    unsigned long long tep0 = __builtin_readcyclecounter();
-#endif
 
     // epilogue.  D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const long out_plane = (long)a.Hout * a.Wout;
     const bool full_co = (co0 + MT <= a.Cout);
-    if ((LOCO_EXP & 64) && acc[0][0][0] != 12345.f) return;      // what-if: no epilogue
-    if (a.fs_out) {
-        // ---- epilogue with FUSED GroupNorm tangent / cotangent statistics of the consumer norm ----
-        // (needs nsplit == 1, a full cout tile, no accumulate, cpg in {4,8,16,32}: guaranteed by the engine).
-        // Per lane: accumulator pair index ai = i*4 + (r>>2) collects z and xhat*z over the lane's pixels for
-        // the 4 consecutive channels (r&3) of that quad; quads are merged into groups after the lane reduction.
-        float s1[TM * 4], s2[TM * 4], irs[TM * 4];
-#pragma unroll
-        for (int q = 0; q < TM * 4; ++q) { s1[q] = 0.f; s2[q] = 0.f; irs[q] = 1.f; }
-        if (a.fs_kind == 1) {
-#pragma unroll
-            for (int q = 0; q < TM * 4; ++q) {
-                int co = co0 + (wm * TM + (q >> 2)) * 32 + 8 * (q & 3) + 4 * khalf;
-                irs[q] = 1.0f / a.fs_mr[2 * (co / a.fs_cpg) + 1];
-            }
-        }
-        float* ob = a.out + (long)b * a.out_bs;
-        const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
-        const float* b2 = a.bias2 ? a.bias2 + (long)b * a.bias2_bs : nullptr;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int p = (wn * TN + j) * 32 + l31;
-            int ty = p / TW, tx = p - ty * TW;
-            const unsigned pix = (unsigned)((oy0 + ty) * a.Wout + ox0 + tx);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int cob = co0 + (wm * TM + i) * 32 + 4 * khalf;
-                float rv[16];
-                float2 sxv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long off = (long)(cob + (r & 3) + 8 * (r >> 2)) * out_plane + pix;
-                    rv[r] = rb ? rb[off] : 0.f;
-                    sxv[r] = a.fs_sx[off];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cob + (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r] + rv[r];
-                    if (a.bias) v += a.bias[co];
-                    if (b2) v += b2[co];
-                    __builtin_nontemporal_store(v, &ob[(long)co * out_plane + pix]);   // streamed once: keep L2 for the shared primal cache / weights (2 ms per step)
-                    const int q = i * 4 + (r >> 2);
-                    const float z = a.fs_kind == 1 ? v * sxv[r].x * irs[q] : v;
-                    s1[q] += z;
-                    s2[q] += sxv[r].y * z;
-                }
-            }
-        }
-        // reduce over the 32 pixel lanes of each half wave
-#pragma unroll
-        for (int q = 0; q < TM * 4; ++q) {
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                s1[q] += __shfl_xor(s1[q], o, 64);
-                s2[q] += __shfl_xor(s2[q], o, 64);
-            }
-        }
-        // all waves are past their last LDS read of the stage loop once they pass this barrier
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem_b);        // [wave][khalf][TM*4][2]
-        if (l31 == 0) {
-#pragma unroll
-            for (int q = 0; q < TM * 4; ++q) {
-                red[((wave * 2 + khalf) * TM * 4 + q) * 2] = s1[q];
-                red[((wave * 2 + khalf) * TM * 4 + q) * 2 + 1] = s2[q];
-            }
-        }
-        __syncthreads();
-        // one thread per channel group of the workgroup's MT couts: sum the quads of the group over the WN waves
-        const int cpg = a.fs_cpg, ngrp = MT / cpg;
-        if (tid < ngrp) {
-            float t1 = 0.f, t2 = 0.f;
-            const int c_lo = tid * cpg;                           // first local cout of the group
-            for (int cl = c_lo; cl < c_lo + cpg; cl += 4) {       // quads of 4 consecutive couts
-                int blk = cl >> 5, rowin = cl & 31;               // 32-cout block, row inside it
-                int wmq = blk / TM, iq = blk - wmq * TM;
-                int kh = (rowin >> 2) & 1, qq = rowin >> 3;       // row = (r&3) + 8*(r>>2) + 4*khalf
-                for (int w2 = 0; w2 < WN; ++w2) {
-                    int wv = wmq * WN + w2;
-                    t1 += red[((wv * 2 + kh) * TM * 4 + iq * 4 + qq) * 2];
-                    t2 += red[((wv * 2 + kh) * TM * 4 + iq * 4 + qq) * 2 + 1];
-                }
-            }
-            const int g = (co0 + c_lo) / cpg;
-            const int npt = (a.Hout * a.Wout) / NT;
-            float* o = a.fs_out + (((long)b * a.fs_G + g) * npt + tile_id) * 2;
-            o[0] = t1;
-            o[1] = t2;
-        }
-        return;
-    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         int p = (wn * TN + j) * 32 + l31;
@@ -745,75 +650,71 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
             }
         }
     }
-#ifdef LOCO_STAMP
-    if (blockIdx.x == 0 && (tid & 63) == 0) a.partial[wave * 8 + 6] = (float)(__builtin_readcyclecounter() - tep0);
-#endif
 }
 
 // ---------------------------------------------------------------------------
-
+// Kernel entry points: one name per arithmetic so profiles tell them apart.
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
+__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
+    conv_lowp_body<PR_BF16X3, TAPS, WM, WN, TM, TN, MODE, STG>(a);
+}
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
+__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f16(ConvArgs a) {
+    conv_lowp_body<PR_F16, TAPS, WM, WN, TM, TN, MODE, STG>(a);
+}
+
+template <int PR, int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
 static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     constexpr int MT = WM * TM * 32, NT = WN * TN * 32;
     constexpr int KS = (TAPS == 9) ? 3 : 1;
     int TW = a.Wout < 32 ? a.Wout : 32;
     int TH = NT / TW;
     int halo_w = (TW - 1) * a.stride + KS, halo_h = (TH - 1) * a.stride + KS;
-    size_t lds = 2 * ((size_t)KS * MT * 64 + ((size_t)halo_w * halo_h + NDUMMY) * HP);
+    size_t lds = 2 * ((size_t)KS * MT * rec_bytes<PR>() + ((size_t)halo_w * halo_h + NDUMMY) * halo_pitch<PR>());
     dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
+    auto kern = PR == PR_F16 ? &conv_mfma_f16<TAPS, WM, WN, TM, TN, MODE, STG>
+                             : &conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
             done = true;
         }
     }
-    hipLaunchKernelGGL((conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>), grid, dim3(WM * WN * 64), lds, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, a);
 }
 
-template <int TAPS, int WM, int WN, int TM, int TN, int MODE>
+template <int PR, int TAPS, int WM, int WN, int TM, int TN, int MODE>
 static void launch_one_b(const ConvArgs& a, hipStream_t st) {
     const bool general = a.stride != 1 || a.upsample || a.zins || (a.Cin % BKC) != 0 || !a.in_padded;
     if constexpr (MODE == CM_NONE) {
         // raw inputs: 3x3 convs take the vector path when the layout allows (measured 66.1 -> 62.8 ms/step);
         // 1x1 convs stay on the per-pixel path (38.1 vs 39.2 ms/step)
-        if (a.stride == 2) launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 2>(a, st);
-        else if (TAPS == 9 && !general) launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
-        else launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 1>(a, st);
+        if (a.stride == 2) launch_one_b2<PR, TAPS, WM, WN, TM, TN, MODE, 2>(a, st);
+        else if (TAPS == 9 && !general) launch_one_b2<PR, TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
+        else launch_one_b2<PR, TAPS, WM, WN, TM, TN, MODE, 1>(a, st);
         return;
     }
     if constexpr (MODE == CM_GN_SILU || MODE == CM_TAN_SILU) {
-        if (general) { launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 1>(a, st); return; }
+        if (general) { launch_one_b2<PR, TAPS, WM, WN, TM, TN, MODE, 1>(a, st); return; }
     }
-    launch_one_b2<TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
+    launch_one_b2<PR, TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
 }
 
 
 int bf16_tile_of(const ConvArgs& a);     // conv_bf16.hip
 
-template <int TAPS, int MODE>
+template <int PR, int TAPS, int MODE>
 void launch_tile_b(const ConvArgs& a, hipStream_t st) {
-#ifdef LOCO_DEV_ONE   // development aid: instantiate only one tile variant (fast recompiles for ISA inspection)
-#ifdef LOCO_DEV_TILE0
-    launch_one_b2<TAPS, 2, 2, 2, 2, MODE, 0>(a, st);
-#elif defined(LOCO_DEV_TILE4)
-    launch_one_b2<TAPS, 2, 2, 2, 4, MODE, 0>(a, st);
-#else
-    launch_one_b2<TAPS, 2, 4, 2, 2, MODE, 0>(a, st);
-#endif
-    return;
-#else
     const int tile = bf16_tile_of(a);
     switch (tile) {
-        case 4: launch_one_b<TAPS, 2, 2, 2, 4, MODE>(a, st); break;   // 128 x 256, 4 waves (64 x 128 each)
-        case 5: launch_one_b<TAPS, 2, 4, 2, 2, MODE>(a, st); break;   // 128 x 256, 8 waves (64 x 64 each)
-        case 0: launch_one_b<TAPS, 2, 2, 2, 2, MODE>(a, st); break;
-        case 1: launch_one_b<TAPS, 4, 1, 1, 2, MODE>(a, st); break;
-        case 2: launch_one_b<TAPS, 1, 4, 1, 1, MODE>(a, st); break;
-        default: launch_one_b<TAPS, 2, 2, 1, 1, MODE>(a, st); break;
+        case 5: launch_one_b<PR, TAPS, 2, 4, 2, 2, MODE>(a, st); break;   // 128 x 256, 8 waves (64 x 64 each)
+        case 0: launch_one_b<PR, TAPS, 2, 2, 2, 2, MODE>(a, st); break;
+        case 1: launch_one_b<PR, TAPS, 4, 1, 1, 2, MODE>(a, st); break;
+        case 2: launch_one_b<PR, TAPS, 1, 4, 1, 1, MODE>(a, st); break;
+        default: launch_one_b<PR, TAPS, 2, 2, 1, 1, MODE>(a, st); break;
     }
-#endif
 }
 
 

@@ -43,6 +43,8 @@ struct ConvP {       // one convolution's parameters in kernel layouts
     float* wd = nullptr;    // dgrad    [Cout][taps][CinP]  (flipped taps)
     float* wbf = nullptr;   // split-bf16 forward records [Cin/16][taps][CoutP][32 x u16]
     float* wbd = nullptr;   // split-bf16 dgrad records   [Cout/16][taps][CinP][32 x u16]
+    float* whf = nullptr;   // f16 forward records        [Cin/16][taps][CoutP][16 x f16]
+    float* whd = nullptr;   // f16 dgrad records          [Cout/16][taps][CinP][16 x f16]
     float* bias = nullptr;
     int cin = 0, cout = 0, taps = 0;
 };
@@ -67,7 +69,6 @@ struct Op {
     int heads = 1;                // ATTN
     bool in_is_skip = false;
     bool has_nin = false;
-    bool n1_ready = false;        // per pass: the producer's conv epilogue already delivered norm1's tangent statistics
     // parameter name stems in the reference state_dict
     std::string pn_n1, pn_c1, pn_emb, pn_n2, pn_c2, pn_skip, pn_qkv, pn_proj, pn_conv;
     ConvP c1, c2, nin, qkvc, proj, conv;     // conv: CONV_IN / DOWN / UP / OUT
@@ -110,7 +111,7 @@ struct loco_ctx {
     float* alphas = nullptr;
     float2* sxcache = nullptr;     // primal {S, xhat} per GroupNorm+SiLU input (bf16x3 path)
     long sx_total = 0;
-    int prec = 0;                  // 0: exact fp32 MFMA, 1: split-bf16 (bf16x3) MFMA
+    int prec = 0;                  // 0: exact fp32 MFMA, 1: split-bf16 (bf16x3) MFMA, 2: single f16 MFMA
     std::vector<float*> owned;     // everything to hipFree
     size_t bytes = 0;
 
@@ -119,8 +120,10 @@ struct loco_ctx {
     float p_cv = 0.f, p_ce = 0.f;
     uint8_t* mask = nullptr;       // device, [n] (owned copy)
     bool has_mask = false;
-    int* mask_idx = nullptr;
-    long mask_L = 0;
+    int* mask_idx = nullptr;       // device: indices of the selected elements, ascending
+    int* mask_L_dev = nullptr;     // device: their count
+    long mask_L = 0;               // host copy, -1 = not read back yet
+    hipStream_t mask_stream = nullptr;
     int primal_B = 0;
     double flops = 0.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -608,6 +611,28 @@ static std::vector<float> build_records(int nin, int nout, int taps, F get) {
     return out;
 }
 
+// f16 records: W(o, i, t) -> [ceil(nin/16)][taps][noutP][16 x f16], 32-byte record per (chunk, tap, o): logical 16-byte
+// pieces {k0-7, k8-15} stored at piece ^ ((o>>3)&1)
+template <typename F>
+static std::vector<float> build_records_f16(int nin, int nout, int taps, F get) {
+    int nch = (nin + 15) / 16, noutP = (nout + 31) & ~31;
+    std::vector<_Float16> rec((size_t)nch * taps * noutP * 16, (_Float16)0.f);
+    for (int ck = 0; ck < nch; ++ck)
+        for (int t = 0; t < taps; ++t)
+            for (int o = 0; o < nout; ++o) {
+                _Float16* r = rec.data() + (((size_t)ck * taps + t) * noutP + o) * 16;
+                int sw = (o >> 3) & 1;
+                for (int k = 0; k < 16; ++k) {
+                    int i = ck * 16 + k;
+                    float v = (i < nin) ? get(o, i, t) : 0.f;
+                    r[((k >> 3) ^ sw) * 8 + (k & 7)] = (_Float16)v;     // round to nearest even
+                }
+            }
+    std::vector<float> out(rec.size() / 2);
+    std::memcpy(out.data(), rec.data(), rec.size() * 2);
+    return out;
+}
+
 // weights [cout][cin][k][k] -> forward [cin][taps][coutP], dgrad [cout][taps][cinP] with flipped taps
 int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::vector<const HostParam*>& bs,
               ConvP* out, int row_limit = -1) {
@@ -641,6 +666,9 @@ int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::v
     std::vector<float> rf = build_records(cin, cout, taps, fwd);
     std::vector<float> rd = build_records(cout, cin, taps, dgr);
     if (upload(c, &out->wbf, rf) || upload(c, &out->wbd, rd)) return -1;
+    std::vector<float> hf = build_records_f16(cin, cout, taps, fwd);
+    std::vector<float> hd = build_records_f16(cout, cin, taps, dgr);
+    if (upload(c, &out->whf, hf) || upload(c, &out->whd, hd)) return -1;
     return 0;
 }
 int make_conv1(loco_ctx* c, const std::string& name, ConvP* out, int row_limit = -1) {
@@ -757,11 +785,11 @@ void conv_defaults(ConvArgs& a) {
 
 // run a conv with automatic split-K selection
 void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
-    a.nsplit = c->prec == 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B)
+    if (c->prec == 2) a.wb = a.wh;
+    a.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B)
                             : conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
     if (a.nsplit < 1) a.nsplit = 1;
-    if (a.nsplit > 1 || c->prec != 1 || a.accumulate) a.fs_out = nullptr;   // fused statistics need the final value in-kernel
     a.partial = c->partial;
     {
         const size_t span = (size_t)c->cfg.max_batch * c->per_sample;
@@ -772,7 +800,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
     // with split-K so the tail round is as wide as the chip: 1 + 1/s rounds + a one-sample reduce instead of 2
     // (measured 331.0 vs 334.1 ms per step).
     int tail_probes = 0, tail_split = 1;
-    if (c->prec == 1 && a.nsplit == 1 && a.B >= 2 && !a.fs_out) {
+    if (c->prec >= 1 && a.nsplit == 1 && a.B >= 2) {
         const long per_probe = (long)((a.Hout * a.Wout) / conv_bf16_tile_pixels(a)) * ((a.Cout + 127) / 128);
         const long total = per_probe * a.B, r = total % 256;
         const int nchunks = (a.Cin + 15) / 16;
@@ -797,7 +825,9 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
             r.e0 = c->next_event(); r.e1 = c->next_event();
             (void)hipEventRecord(r.e0, st);
         }
-        if (c->prec == 1) launch_conv_bf16x3(x, taps, st); else launch_conv(x, taps, st);
+        if (c->prec == 1) launch_conv_bf16x3(x, taps, st);
+        else if (c->prec == 2) launch_conv_f16(x, taps, st);
+        else launch_conv(x, taps, st);
         if (c->prof_on) { (void)hipEventRecord(r.e1, st); c->prof.push_back(r); }
         if (x.nsplit > 1) {
             if (c->prof_on) {
@@ -829,6 +859,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
 inline void setw(ConvArgs& a, const ConvP& p, bool dgrad) {
     a.w = dgrad ? p.wd : p.wf;
     a.wb = dgrad ? (const void*)p.wbd : (const void*)p.wbf;
+    a.wh = dgrad ? (const void*)p.whd : (const void*)p.whf;
 }
 
 // sc / sh / mr / tst pointers of a norm inside a stats arena
@@ -996,39 +1027,11 @@ void set_tan(loco_ctx* c, ConvArgs& a, const NormP& n, const float* prim) {
     a.sx = (n.sx_off >= 0 && c->sxcache) ? c->sxcache + n.sx_off : nullptr;
 }
 
-constexpr size_t RED_BYTES = (size_t)4 << 20;   // reduction scratch (GN partial sums, fused-statistics partials)
-// Fused consumer-norm statistics in a conv epilogue (bf16x3 path): request before run_conv, finalise after.
-bool fuse_request(loco_ctx* c, ConvArgs& a, const NormP& n, int kind) {
-    const int G = c->cfg.gn_groups, cpg = n.C / G;
-    if (c->prec != 1 || n.sx_off < 0 || !c->sxcache) return false;
-    if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) || (a.Cout % 128) != 0 || a.Cout != n.C) return false;
-    // Opt-in (LOCO_FUSED_STATS=1): measured on MI355X the fused epilogue costs more than the separate statistics
-    // kernels save (378.8 vs 349.8 ms/step) -- the {S, xhat} cache read is exposed at one workgroup per CU, while
-    // the stand-alone reduction streams it at full HBM rate.  Kept for conv variants with an overlapped epilogue.
-    static const bool enabled = getenv("LOCO_FUSED_STATS") != nullptr;
-    if (!enabled) return false;
-    const int HW = a.Hout * a.Wout, NT = conv_bf16_tile_pixels(a);
-    if (HW % NT != 0 || (size_t)a.B * G * (HW / NT) * 2 * sizeof(float) > RED_BYTES) return false;
-    NS sp = nstats(c, c->statsP, n);
-    a.fs_out = reinterpret_cast<float*>(c->red);
-    a.fs_sx = c->sxcache + n.sx_off;
-    a.fs_mr = sp.mr; a.fs_cpg = cpg; a.fs_kind = kind; a.fs_G = G;
-    return true;
-}
-void fuse_finalize(loco_ctx* c, const ConvArgs& a, const NormP& n, int kind, hipStream_t st) {
-    const int G = c->cfg.gn_groups, cpg = n.C / G;
-    const int HW = a.Hout * a.Wout;
-    const int NT = conv_bf16_tile_pixels(a);
-    NS sp = nstats(c, c->statsP, n);
-    NS stt = nstats(c, c->statsT, n);
-    launch_fs_finalize(a.fs_out, HW / NT, a.B, G, cpg, 1.0 / ((double)cpg * HW), sp.mr, kind, stt.tst, stt.tc,
-                       c->stats_per_sample, st);
-}
+constexpr size_t RED_BYTES = (size_t)4 << 20;   // reduction scratch (GN partial sums)
 
 int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
     const loco_unet_cfg& cfg = c->cfg;
     const long PS = c->per_sample;
-    for (auto& op : c->ops) op.n1_ready = false;
     auto TP = [&](int id) { return c->arenaP + c->tens[id].off; };   // primal
     auto TT = [&](int id) { return c->arenaT + c->tens[id].off; };   // tangent
     for (auto& op : c->ops) {
@@ -1046,7 +1049,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
             case OP_RES: {
                 const Tens& ti = c->tens[op.in];
                 const int HWi = ti.H * ti.W;
-                if (!op.n1_ready) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HWi, B, st);
+                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HWi, B, st);
                 ConvArgs a; conv_defaults(a);
                 a.Cin = ti.C;
                 setw(a, op.c1, false);
@@ -1067,10 +1070,8 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                     }
                 }
                 a.out = TT(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
-                fuse_request(c, a, op.n2, 0);
                 run_conv(c, a, 9, st);
-                if (a.fs_out) fuse_finalize(c, a, op.n2, 0, st);
-                else tangent_stats(c, op.n2, TT(op.h1), PS, TP(op.h1), HW, B, st);
+                tangent_stats(c, op.n2, TT(op.h1), PS, TP(op.h1), HW, B, st);
                 const float* xin = op.updown ? TT(op.xu) : TT(op.in);
                 const float* res = xin;
                 if (op.has_nin) {
@@ -1086,14 +1087,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 setw(b, op.c2, false); b.res = res; b.res_bs = PS;
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.out = TT(op.out); b.out_bs = PS; b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
-                {
-                    // the block output feeds the next op's norm1 when that op reads exactly this tensor (no concat)
-                    Op* nxt = (&op - &c->ops[0] + 1 < (long)c->ops.size()) ? &op + 1 : nullptr;
-                    bool want = nxt && nxt->in == op.out && (nxt->kind == OP_RES || nxt->kind == OP_OUT);
-                    if (want) want = fuse_request(c, b, nxt->n1, 0);
-                    run_conv(c, b, 9, st);
-                    if (want && b.fs_out) { fuse_finalize(c, b, nxt->n1, 0, st); nxt->n1_ready = true; }
-                }
+                run_conv(c, b, 9, st);
                 break;
             }
             case OP_ATTN: {
@@ -1147,7 +1141,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
             }
             case OP_OUT: {
                 const Tens& ti = c->tens[op.in];
-                if (!op.n1_ready) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), ti.H * ti.W, B, st);
+                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), ti.H * ti.W, B, st);
                 ConvArgs a; conv_defaults(a);
                 a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false);
@@ -1188,10 +1182,8 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 a.in = ge; a.in_bs = c->n_in; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
                 setw(a, op.conv, true);
                 a.out = TG(op.a1); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
-                fuse_request(c, a, op.n1, 1);
                 run_conv(c, a, 9, st);
-                if (a.fs_out) fuse_finalize(c, a, op.n1, 1, st);
-                else cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), ti.H * ti.W, B, 1, st);
+                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), ti.H * ti.W, B, 1, st);
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 0, B, ti.C, ti.H * ti.W, G,
@@ -1225,10 +1217,8 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
                 setw(a, op.c2, true);
                 a.out = TG(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
-                fuse_request(c, a, op.n2, 1);
                 run_conv(c, a, 9, st);
-                if (a.fs_out) fuse_finalize(c, a, op.n2, 1, st);
-                else cot_stats(c, op.n2, TG(op.h1), PS, TP(op.h1), HW, B, 1, st);
+                cot_stats(c, op.n2, TG(op.h1), PS, TP(op.h1), HW, B, 1, st);
                 // dgrad conv1 of the norm2/silu cotangent of g_a2 (fused in the staging), at conv1's resolution
                 ConvArgs b; conv_defaults(b);
                 b.in = TG(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
@@ -1236,12 +1226,9 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.mode = CM_COT_SILU;
                 b.out_bs = PS; b.Cout = ti.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
-                bool n1_fused = false;
                 if (op.updown == 0) {
                     b.out = TG(op.a1);
-                    fuse_request(c, b, op.n1, 1);
                     run_conv(c, b, 9, st);
-                    if (b.fs_out) { fuse_finalize(c, b, op.n1, 1, st); n1_fused = true; }
                 } else if (op.updown == 1) {
                     b.out = TG(op.ap);                                     // cotangent of the pooled activation
                     run_conv(c, b, 9, st);
@@ -1251,7 +1238,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                     run_conv(c, b, 9, st);
                     launch_pool2x2_sum(TG(op.xu), PS, TG(op.a1), PS, 0, B, ti.C, ti.H, ti.W, st);           // nearest^T
                 }
-                if (!n1_fused) cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), HWi, B, 1, st);
+                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), HWi, B, 1, st);
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 int acc = op.in_is_skip ? 1 : 0;
@@ -1350,7 +1337,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
 // =============================== C ABI =======================================
 extern "C" {
 
-const char* loco_version(void) { return "loco_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* loco_version(void) { return "loco_hip 0.2 (gfx950; conv arithmetic: f32 MFMA | bf16x3 split-bf16 MFMA | f16 MFMA)"; }
 
 int loco_device_count(void) {
     int n = 0;
@@ -1361,8 +1348,14 @@ int loco_device_count(void) {
 int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
     if (!cfg || !out) return -2;
     loco_ctx* c = new loco_ctx();
-    c->cfg = *cfg;
     *out = c;
+    if (cfg->struct_size != (int32_t)sizeof(loco_unet_cfg)) {
+        // a binding built against another revision of include/loco_hip.h: refuse before reading past its struct
+        c->err = "loco_unet_cfg.struct_size = " + std::to_string(cfg->struct_size) + ", this library expects " +
+                 std::to_string(sizeof(loco_unet_cfg)) + " (binding and library built from different headers)";
+        return -2;
+    }
+    c->cfg = *cfg;
     if (cfg->max_batch < 1 || cfg->num_levels < 1 || cfg->num_levels > 8) { c->err = "bad config"; return -2; }
     {
         int r = cfg->resolution;
@@ -1403,11 +1396,12 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
     }
     {
         const char* e = getenv("LOCO_PRECISION");
-        c->prec = (e && std::string(e) == "f32") ? 0 : 1;   // default: split-bf16 (fp32-faithful to ~2^-16)
+        c->prec = (e && std::string(e) == "f32") ? 0 : (e && std::string(e) == "f16") ? 2 : 1;   // default: split-bf16
         const char* t = getenv("LOCO_BF16_TILE");
         if (t) g_bf16_tile_override = atoi(t);
     }
-    if (dalloc(c, &c->mask, (size_t)c->n_in) || dalloc(c, &c->mask_idx, (size_t)c->n_in)) return -1;
+    if (dalloc(c, &c->mask, (size_t)c->n_in) || dalloc(c, &c->mask_idx, (size_t)c->n_in) ||
+        dalloc(c, &c->mask_L_dev, 4)) return -1;
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
     return 0;
@@ -1507,7 +1501,7 @@ int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_
     hipStream_t st = (hipStream_t)stream;
     if (forward_pass(c, x, t, 1, c->arenaP, c->statsP, st)) return -1;
     c->primal_B = 1;
-    if (c->prec == 1) {
+    if (c->prec >= 1) {
         // {S, xhat} cache for the tangent / cotangent staging of the split-bf16 convs
         for (auto& op : c->ops) {
             if (op.kind != OP_RES && op.kind != OP_OUT) continue;
@@ -1529,18 +1523,12 @@ int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_
     c->has_mask = (mask != nullptr);
     c->mask_L = c->n_in;
     if (mask) {
+        // masked-latent gather list built on the device (ordered prefix-sum compaction, one launch, no host sync);
+        // L is read back lazily by loco_mask_count / loco_mask_gather
         HIPCHK(c, hipMemcpyAsync(c->mask, mask, (size_t)c->n_in, hipMemcpyDeviceToDevice, st));
-        std::vector<uint8_t> hm((size_t)c->n_in);
-        HIPCHK(c, hipMemcpyAsync(hm.data(), mask, (size_t)c->n_in, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        std::vector<int> idx;
-        idx.reserve(c->n_in);
-        for (int i = 0; i < c->n_in; ++i)
-            if (hm[i]) idx.push_back(i);
-        c->mask_L = (long)idx.size();
-        if (!idx.empty())
-            HIPCHK(c, hipMemcpyAsync(c->mask_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        launch_mask_compact(c->mask, c->n_in, c->mask_idx, c->mask_L_dev, st);
+        c->mask_L = -1;
+        c->mask_stream = st;
     }
     HIPCHK(c, hipGetLastError());
     c->primal_ok = true;
@@ -1643,7 +1631,16 @@ int loco_edit_axpy(loco_ctx* c, const float* x, const float* v, const float* alp
     return 0;
 }
 
-int64_t loco_mask_count(loco_ctx* c) { return c ? c->mask_L : -1; }
+static long mask_count_lazy(loco_ctx* c) {
+    if (c->mask_L < 0) {
+        int L = 0;
+        if (hipMemcpyAsync(&L, c->mask_L_dev, sizeof(int), hipMemcpyDeviceToHost, c->mask_stream) != hipSuccess ||
+            hipStreamSynchronize(c->mask_stream) != hipSuccess) return -1;
+        c->mask_L = L;
+    }
+    return c->mask_L;
+}
+int64_t loco_mask_count(loco_ctx* c) { return c ? mask_count_lazy(c) : -1; }
 
 int loco_mask_gather(loco_ctx* c, const float* U, int32_t k, float* out, void* stream) {
     if (!c) return -2;
@@ -1653,7 +1650,9 @@ int loco_mask_gather(loco_ctx* c, const float* U, int32_t k, float* out, void* s
         HIPCHK(c, hipMemcpyAsync(out, U, (size_t)k * c->n_in * sizeof(float), hipMemcpyDeviceToDevice, st));
         return 0;
     }
-    launch_mask_gather(U, c->mask_idx, c->mask_L, c->n_in, k, out, st);
+    const long L = mask_count_lazy(c);
+    if (L < 0) { c->err = "mask count readback failed"; return -1; }
+    if (L > 0) launch_mask_gather(U, c->mask_idx, L, c->n_in, k, out, st);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1680,7 +1679,7 @@ int loco_timer_stop(loco_ctx* c, void* stream, float* ms) {
 
 int loco_set_precision(loco_ctx* c, int32_t mode) {
     if (!c) return -2;
-    if (mode != 0 && mode != 1) { c->err = "precision mode must be 0 (f32) or 1 (bf16x3)"; return -2; }
+    if (mode < 0 || mode > 2) { c->err = "precision mode must be 0 (f32), 1 (bf16x3) or 2 (f16)"; return -2; }
     c->prec = mode;
     c->primal_ok = false;   // the {S, xhat} cache belongs to the mode it was built in
     return 0;
@@ -1712,7 +1711,7 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     ConvArgs a; conv_defaults(a);
     a.in = in; a.in_bs = in_e; a.Cin = cin; a.Hin = H; a.Win = W;
     a.prim = c->arenaP; a.prim_bs = 0; a.sx = c->sxcache;
-    a.w = wf; a.wb = wf;
+    a.w = wf; a.wb = wf; a.wh = wf;
     a.out = out; a.out_bs = out_e; a.Cout = cout; a.Hout = H; a.Wout = W; a.B = B;
     a.mode = mode; a.pad = taps == 9 ? 1 : 0; a.in_padded = 1;
     a.sc = c->statsP; a.sh = c->statsP + cin; a.scsh_bs = 0; a.mr = c->statsP + 2 * cin; a.mr_bs = 0;
@@ -1723,7 +1722,9 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     int saved = g_bf16_tile_override;
     g_bf16_tile_override = tile;
     auto run = [&]() {
-        if (c->prec == 1) launch_conv_bf16x3(a, taps, st); else launch_conv(a, taps, st);
+        if (c->prec == 1) launch_conv_bf16x3(a, taps, st);
+        else if (c->prec == 2) launch_conv_f16(a, taps, st);
+        else launch_conv(a, taps, st);
         launch_conv_splitk_reduce(a, st);
     };
     run();
@@ -1736,13 +1737,6 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *ms_avg = ms / iters;
     HIPCHK(c, hipGetLastError());
-    return 0;
-}
-
-int loco_debug_read_scratch(loco_ctx* c, float* dst_host, int32_t n) {
-    if (!c) return -2;
-    HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(dst_host, c->partial, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -23,8 +23,10 @@ struct ConvArgs {
     const float* prim; long prim_bs;
     // weights, layout [Cin][TAPS][Cout]
     const float* w;
-    // split-bf16 weights, layout [Cin/16][TAPS][Cout^32][hi0-7|hi8-15|lo0-7|lo8-15] (swizzled 64-byte records)
+    // low-precision weights: bf16x3 [Cin/16][TAPS][Cout^32][hi0-7|hi8-15|lo0-7|lo8-15] (swizzled 64-byte records),
+    // f16 [Cin/16][TAPS][Cout^32][k0-7|k8-15] (swizzled 32-byte records)
     const void* wb;
+    const void* wh;     // f16 records of the same operator (the engine points wb at them in f16 mode)
     // primal cache {S = sc*silu'(y), xhat} per element of `in`'s primal (bf16x3 path, modes TAN/COT)
     const float2* sx;
     float* out; long out_bs; int Cout, Hout, Wout;
@@ -43,9 +45,6 @@ struct ConvArgs {
     int pad;         // top/left zero padding in input coords (1: 3x3 s1, 0: 3x3 s2 / 1x1, 2: zero-insert dgrad)
     int upsample;    // input is read through a nearest x2 upsample
     int zins;        // input is read through stride-2 zero insertion (dgrad of the stride-2 conv)
-    // fused statistics of the consumer GroupNorm in the epilogue (bf16x3 path): partial sums of z and xhat*z per
-    // (b, group, pixel tile) -> fs_out[((b*fs_G + g)*ntile + tile)*2]; z = out (fs_kind 0) or out*S/rstd (fs_kind 1)
-    float* fs_out; const float2* fs_sx; const float* fs_mr; int fs_cpg, fs_kind, fs_G;
     int in_padded;   // `in` (and `sx`) live in a padded engine arena: 16-byte loads may start 1 float before / end 3 after a plane
     int accumulate;  // out += result
     int nsplit;      // split-K factor (>1: raw partials go to `partial`, epilogue by conv_splitk_reduce)
@@ -56,6 +55,7 @@ struct ConvArgs {
 // the conv kernel only; when a.nsplit > 1 the caller follows with launch_conv_splitk_reduce (run_conv does)
 void launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st);
+void launch_conv_f16(const ConvArgs& a, int taps, hipStream_t st);     // a.wb = the f16 weight records
 void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st);
 int conv_pick_tile(int Cout, int HW);
 extern int g_bf16_tile_override;
@@ -108,9 +108,6 @@ void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int 
 //   kind 3: out (+)= base + rstd*(gamma*d - m1 - xh*m2)           (attention norm cotangent)
 //   kind 4: out = silu(sc*x + sh)                                  (activation ahead of an avg-pool, ADM down block)
 //   kind 5: out = silu'(y)*sc*(d - m1 - xh*m2)                     (its tangent)
-// finalise fused conv-epilogue statistics: sums the per-tile partials, writes tst {m1,m2} and the per-channel tc
-void launch_fs_finalize(const float* part, int ntile, int B, int G, int cpg, double inv_n, const float* mr, int kind,
-                        float* tst, float* tc, long tbs, hipStream_t st);
 void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x_bs,
                      const float* base, long base_bs, float* out, long out_bs, int accumulate,
                      int B, int C, int HW, int G, const float* sc, const float* sh, const float* mr,
@@ -175,5 +172,7 @@ void launch_normalize_rows(float* A, int k, long n, double* scratch, hipStream_t
 void launch_edit_axpy(const float* x, const float* v, const float* alphas_dev, int B, long n, float* out,
                       hipStream_t st);
 void launch_mask_gather(const float* U, const int* idx, long L, long n, int k, float* out, hipStream_t st);
+// idx[0..L) = ascending positions of the non-zero bytes of mask[0..n), *count = L  (one workgroup, ordered scan)
+void launch_mask_compact(const uint8_t* mask, long n, int* idx, int* count, hipStream_t st);
 
 }  // namespace loco

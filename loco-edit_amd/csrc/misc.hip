@@ -244,30 +244,6 @@ void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int 
                        G, 1.0 / (double)len, tst, tc, tst_bs, cpg, mr, pbs_g, kind);
 }
 
-__global__ void fs_finalize_kernel(const float* part, int ntile, long BG, int G, int cpg, double inv_n, const float* mr,
-                                   int kind, float* tst, float* tc, long tbs) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BG) return;
-    double a = 0.0, c = 0.0;
-    const float* p = part + i * ntile * 2;
-    for (int t = 0; t < ntile; ++t) { a += (double)p[2 * t]; c += (double)p[2 * t + 1]; }
-    const int g = (int)(i % G);
-    const long b = i / G;
-    float m1 = (float)(a * inv_n), m2 = (float)(c * inv_n);
-    float* o = tst + b * tbs + 2 * g;
-    o[0] = m1;
-    o[1] = m2;
-    float f = kind == 0 ? 1.0f : mr[2 * g + 1];
-    float* t = tc + b * tbs + 2 * (long)g * cpg;
-    for (int k = 0; k < cpg; ++k) { t[2 * k] = f * m1; t[2 * k + 1] = f * m2; }
-}
-void launch_fs_finalize(const float* part, int ntile, int B, int G, int cpg, double inv_n, const float* mr, int kind,
-                        float* tst, float* tc, long tbs, hipStream_t st) {
-    long BG = (long)B * G;
-    hipLaunchKernelGGL(fs_finalize_kernel, dim3((unsigned)((BG + 63) / 64)), dim3(64), 0, st, part, ntile, BG, G, cpg,
-                       inv_n, mr, kind, tst, tc, tbs);
-}
-
 // ---------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* d, long d_bs, const float* x, long x_bs,

@@ -429,4 +429,33 @@ void launch_mask_gather(const float* U, const int* idx, long L, long n, int k, f
     hipLaunchKernelGGL(mask_gather_kernel, dim3(blocks, k), dim3(256), 0, st, U, idx, L, n, out);
 }
 
+// Ordered stream compaction of the mask (north_star: coalesced masked-latent gather): one workgroup of 1024 threads;
+// thread t owns the contiguous slice [t*per, (t+1)*per) so the output order is ascending; counts are combined with a
+// wave-shuffle inclusive scan + one LDS pass over the 16 wave totals.
+__global__ __launch_bounds__(1024) void mask_compact_kernel(const uint8_t* mask, long n, int* idx, int* count) {
+    __shared__ int wtot[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long per = (n + 1023) / 1024;
+    const long lo = (long)t * per, hi = lo + per < n ? lo + per : n;
+    int cnt = 0;
+    for (long i = lo; i < hi; ++i) cnt += mask[i] != 0;
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wtot[w];
+    int pos = base + inc - cnt;
+    for (long i = lo; i < hi; ++i)
+        if (mask[i]) idx[pos++] = (int)i;
+    if (t == 1023) *count = base + inc;
+}
+void launch_mask_compact(const uint8_t* mask, long n, int* idx, int* count, hipStream_t st) {
+    hipLaunchKernelGGL(mask_compact_kernel, dim3(1), dim3(1024), 0, st, mask, n, idx, count);
+}
+
 }  // namespace loco

@@ -1,7 +1,8 @@
 """Flags and derived settings of the unconditional LOCO-Edit path: the subset of
-reference ``src/utils/define_argparser.py:14-258`` the hot path reads (SURVEY.md
-section 5, row "Config / flags"), same names / types / defaults, plus three
-deployment flags (``--ckpt_path``, ``--synthetic_weights``, ``--max_batch``).
+reference ``src/utils/define_argparser.py:14-258``: the complete flag schema (same
+names / types / defaults, so every shipped ``scripts/main_*.sh`` argument list
+parses), the derived fields of ``preset`` for the unconditional branch, plus the
+deployment flags ``--ckpt_path``, ``--synthetic_weights``, ``--max_batch``, ``--precision``.
 """
 import argparse
 import os
@@ -24,65 +25,91 @@ def str2bool(v):
         raise argparse.ArgumentTypeError('Boolean value expected.')
 
 
+# Flag schema = reference define_argparser.py:18-124 (every flag the twelve shipped scripts pass parses here with
+# the reference's name, type and default); rows: (name, type, default).  Flags that only steer subsystems outside
+# the unconditional hot path (prompts, guidance scales, SAM model name, ablations) are accepted and carried on the
+# Namespace so the shipped scripts run unmodified; `preset` rejects the text-to-image model names.
+_S, _I, _F = str, int, float
+_FLAGS = [
+    # default setting
+    ('sh_file_name', _S, ''), ('device', _S, 'cuda:0'), ('dtype', _S, 'fp32'), ('seed', _I, 0),
+    ('result_folder', _S, './runs/'), ('cache_folder', _S, ''), ('dataset_root', _S, ''),
+    # model, dataset
+    ('model_name', _S, 'CelebA_HQ_HF'), ('dataset_name', _S, 'Synthetic'), ('num_imgs', _I, 100),
+    ('image_size', _I, 256), ('c_in', _I, 3), ('sample_idx', _I, 0),
+    # prompts (text-to-image only)
+    ('for_prompt', _S, ''), ('inv_prompt', _S, ''), ('neg_prompt', _S, ''),
+    # diffusion schedule
+    ('for_steps', _I, 100), ('inv_steps', _I, 100), ('performance_boosting_t', _F, 0.0),
+    ('use_yh_custom_scheduler', 'bool', 'True'),
+    # guidance (text-to-image only)
+    ('guidance_scale', _F, 0), ('guidance_scale_edit', _F, 4.0),
+    # edit
+    ('edit_prompt', _S, ''), ('original_prompt', _S, ''), ('edit_xt', _S, 'default'),
+    ('use_x_space_guidance', 'bool', 'False'), ('x_space_guidance_direct', 'bool', 'False'),
+    ('x_space_guidance_edit_step', _F, 1), ('x_space_guidance_scale', _F, 0), ('x_space_guidance_num_step', _I, 0),
+    ('x_space_guidance_use_edit_prompt', 'bool', 'True'), ('pca_rank_null', _I, 5), ('pca_rank', _I, 5),
+    ('h_t', _F, 0.8), ('edit_t', _F, 1.0), ('no_edit_t', _F, 0.5), ('h_edit_step_size', _F, 0),
+    ('x_edit_step_size', _F, 0),
+    # memory (accepted for script compatibility; batches stay in HBM)
+    ('pca_device', _S, 'cpu'), ('buffer_device', _S, 'cpu'), ('save_result_as', _S, 'image'),
+    # experiments
+    ('note', _S, None),
+    ('run_cfg_forward', 'bool', 'False'), ('run_mcg_forward', 'bool', 'False'), ('run_pfg_forward', 'bool', 'False'),
+    ('run_ddim_forward', 'bool', 'False'), ('run_ddim_inversion', 'bool', 'False'),
+    ('run_edit_local_encoder_pullback_zt', 'bool', 'False'), ('run_edit_local_decoder_pullback_zt', 'bool', 'False'),
+    ('run_edit_local_encoder_decoder_pullback_zt', 'bool', 'False'), ('encoder_decoder_by_et', 'bool', 'False'),
+    ('use_mask', 'bool', 'True'), ('run_edit_local_x0_decoder_pullback_zt', 'bool', 'False'),
+    ('run_edit_local_pca_zt', 'bool', 'False'), ('run_edit_null_space_projection', 'bool', 'False'),
+    ('run_edit_null_space_projection_zt', 'bool', 'False'),
+    ('run_edit_null_space_projection_zt_semantic', 'bool', 'False'),
+    ('run_edit_null_space_projection_xt', 'bool', 'False'),
+    ('run_edit_null_space_projection_xt_semantic', 'bool', 'False'),
+    ('group_edit_null_space_projection', 'bool', 'False'),
+    ('vis_num', _I, 4), ('choose_sem', _S, 'hair'), ('null_space_projection', 'bool', 'False'),
+    # mode
+    ('debug_mode', 'bool', 'False'), ('sampling_mode', 'bool', 'False'), ('non_semantic', 'bool', 'False'),
+    # mask segmentation
+    ('mask_model_name', _S, 'facebook/sam-vit-large'), ('filter_mask', _I, 100), ('mask_index', _I, 0),
+    ('vT_path', _S, ''), ('vT1_path', _S, ''), ('jacobian', 'bool', 'False'), ('use_sega', 'bool', 'False'),
+    ('edit_t_idx', _I, 1), ('num_inference_steps', _I, 3), ('random_edit', 'bool', 'False'),
+]
+_UNET_PRESETS = {'celeba_ddpm': 'CELEBA_DDPM', 'ffhq_p2': 'FFHQ_P2', 'tiny_ddpm': 'TINY_DDPM', 'mid_ddpm': 'MID_DDPM',
+                 'tiny_adm': 'TINY_ADM'}
+_TILDA_V = ["proj_null[for-null](edit-null)-direct", "(for-edit)-direct", "(edit-null)-direct",
+            "null+(for-null)+(edit-null)", "null+(for-null)", "null+(edit-null)", "(for-edit)",
+            "edit-proj[for](edit)", "null+for+edit-proj[for](edit)"]
+
+
 def build_parser():
     p = argparse.ArgumentParser()
-    # default setting
-    p.add_argument('--sh_file_name', type=str, default='', help="for logging")
-    p.add_argument('--device', type=str, default='cuda:0')
-    p.add_argument('--dtype', type=str, default='fp32', help="'fp32' (the uncond scripts' setting)")
-    p.add_argument('--seed', type=int, default=0, help='Random seed (0 = draw one)')
-    p.add_argument('--result_folder', type=str, default='./runs/')
-    p.add_argument('--dataset_root', type=str, default='')
-    # model, dataset
-    p.add_argument('--model_name', type=str, default='CelebA_HQ_HF')
-    p.add_argument('--dataset_name', type=str, default='Synthetic')
-    p.add_argument('--image_size', type=int, default=256)
-    p.add_argument('--c_in', type=int, default=3)
-    p.add_argument('--sample_idx', type=int, default=0)
-    p.add_argument('--ckpt_path', type=str, default='', help='state_dict in the vendored Ho-DDPM key layout')
+    for name, typ, default in _FLAGS:
+        p.add_argument('--' + name, type=str2bool if typ == 'bool' else typ, default=default)
+    p.add_argument('--mask_type', type=str, default="SAM", choices=["SAM", "diffedit"])
+    p.add_argument('--ablation_method', type=str, choices=["null-space-proj", "sega", "diffedit"])
+    p.add_argument('--tilda_v_score_type', type=str, choices=_TILDA_V)
+    # deployment flags of this build (not in the reference)
+    p.add_argument('--ckpt_path', type=str, default='', help='state_dict in the vendored Ho-DDPM / ADM / diffusers key layout')
     p.add_argument('--synthetic_weights', type=int, default=None, help='seed of the deterministic weight synthesiser')
     p.add_argument('--max_batch', type=int, default=8, help='largest image/probe batch resident on the GPU')
-    # diffusion schedule
-    p.add_argument('--for_steps', type=int, default=100)
-    p.add_argument('--inv_steps', type=int, default=100)
-    p.add_argument('--performance_boosting_t', type=float, default=0.0)
-    p.add_argument('--use_yh_custom_scheduler', type=str2bool, default='True')
-    # edit
-    p.add_argument('--edit_prompt', type=str, default='')
-    p.add_argument('--use_x_space_guidance', type=str2bool, default='False')
-    p.add_argument('--x_space_guidance_direct', type=str2bool, default='False')
-    p.add_argument('--x_space_guidance_edit_step', type=float, default=1)
-    p.add_argument('--x_space_guidance_scale', type=float, default=0)
-    p.add_argument('--x_space_guidance_num_step', type=int, default=0)
-    p.add_argument('--pca_rank_null', type=int, default=5)
-    p.add_argument('--pca_rank', type=int, default=5)
-    p.add_argument('--edit_t', type=float, default=1.0)
-    # memory (accepted for script compatibility; batches stay in HBM)
-    p.add_argument('--pca_device', type=str, default='cpu')
-    p.add_argument('--buffer_device', type=str, default='cpu')
-    p.add_argument('--save_result_as', type=str, default='image')
-    # experiments
-    p.add_argument('--note', type=str)
-    p.add_argument('--run_ddim_forward', type=str2bool, default='False')
-    p.add_argument('--run_ddim_inversion', type=str2bool, default='False')
-    p.add_argument('--encoder_decoder_by_et', type=str2bool, default='False')
-    p.add_argument('--use_mask', type=str2bool, default='True')
-    p.add_argument('--run_edit_null_space_projection', type=str2bool, default='False')
-    p.add_argument('--group_edit_null_space_projection', type=str2bool, default='False')
-    p.add_argument('--vis_num', type=int, default=4)
-    p.add_argument('--choose_sem', type=str, default='hair')
-    p.add_argument('--null_space_projection', type=str2bool, default='False')
-    p.add_argument('--sampling_mode', type=str2bool, default='False')
-    p.add_argument('--mask_index', type=int, default=0)
-    p.add_argument('--mask_type', type=str, default="SAM", choices=["SAM", "diffedit"])
-    p.add_argument('--vT_path', type=str, default="")
-    p.add_argument('--vT1_path', type=str, default="")
-    p.add_argument('--random_edit', type=str2bool, default='False')
+    p.add_argument('--unet_preset', type=str, default=None, choices=sorted(_UNET_PRESETS),
+                   help='override the architecture --model_name implies (small parity-test sizes)')
+    p.add_argument('--precision', type=str, default=None, choices=['f32', 'bf16x3', 'f16'],
+                   help="conv arithmetic of the HIP engine: 'f32' exact fp32 MFMA (parity anchor), 'bf16x3' split-bf16 "
+                        "(fp32-faithful to ~2^-16, default), 'f16' single f16 MFMA with fp32 accumulate (2^-11 operands)")
     return p
 
 
 def parse_args(argv=None):
-    return build_parser().parse_args(argv)
+    args = build_parser().parse_args(argv)
+    if args.unet_preset:
+        from . import config
+        args.unet_config = getattr(config, _UNET_PRESETS[args.unet_preset])
+    return args
+
+
+UNCOND_MODELS_HF = ('CelebA_HQ_HF', 'LSUN_church_HF', 'LSUN_bedroom_HF', 'FFHQ_HF')
+UNCOND_MODELS_P2 = ('FFHQ_P2', 'AFHQ_P2', 'Flower_P2', 'Cub_P2', 'Metface_P2')
 
 
 def preset(args):
@@ -93,6 +120,14 @@ def preset(args):
     if any(s in args.model_name for s in ('stable-diffusion', 'DeepFloyd', 'LCM')):
         raise NotImplementedError('text-to-image T-LOCO (SD / DeepFloyd-IF / LCM) is outside this build (SURVEY.md 8f.2)')
     args.is_stable_diffusion = args.is_DeepFloyd_IF_diffusion = args.is_LCM = False
+    # model-name gate of define_argparser.py:166-176 (`unet_config` = an explicit architecture, tests / tiny configs)
+    if getattr(args, 'unet_config', None) is None:
+        if args.model_name == 'CelebA_HQ':
+            raise NotImplementedError('Model weight deprecated...')
+        if args.model_name in ('LSUN_bedroom', 'LSUN_cat', 'LSUN_horse'):
+            raise NotImplementedError('Please download P2 weight from https://github.com/jychoi118/P2-weighting')
+        if args.model_name not in UNCOND_MODELS_HF + UNCOND_MODELS_P2:
+            raise ValueError('model_name choice: [CelebA_HQ_HF, LSUN_church_HF, FFHQ_HF]')
     args.exp = f'{args.model_name}-{args.dataset_name}'
     args.exp_folder = os.path.join(args.result_folder, args.exp)
     os.makedirs(args.exp_folder, exist_ok=True)
@@ -108,6 +143,7 @@ def preset(args):
     args.dtype = torch.float32 if args.dtype == 'fp32' else torch.float16
     print(f'device : {args.device}, dtype : {args.dtype}')
     args.c_in = 3
+    args.image_size = 256 if getattr(args, 'unet_config', None) is None else args.unet_config.resolution
     args.memory_bound = 50
     args.noise_schedule = 'linear'
     # asserts of define_argparser.py:245-247

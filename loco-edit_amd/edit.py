@@ -29,11 +29,13 @@ class EditUncondDiffusion(object):
         self.dtype = args.dtype
         self.seed = args.seed
         if self.dtype != torch.float32:
-            raise ValueError("the unconditional hot path runs fp32 (scripts/main_celeba_hf_null_space_projection.sh:7)")
+            raise ValueError("the unconditional hot path keeps fp32 tensors (scripts/main_celeba_hf_null_space_projection.sh:7); "
+                             "the conv arithmetic is chosen with --precision")
 
         # get model (edit.py:2046-2052)
         self.unet = get_custom_diffusion_model(args)
         self.engine = self.unet.engine
+        print(f'engine : {self.engine.version()}, conv arithmetic : {self.engine.get_precision()}')
         self.scheduler = get_custom_diffusion_scheduler(args, engine=self.engine)
         self.model_name = args.model_name
 
@@ -74,6 +76,27 @@ class EditUncondDiffusion(object):
         self.EXP_NAME = "exp"
         self.args = args
 
+    # ------------------------------------------------------------------ multi-rank file discipline
+    # Under torchrun every rank runs the same flow; rank 0 alone writes, and branch decisions that depend on the
+    # file system are rank 0's (ranks taking different branches would hang in the solver's all-gather).
+    def _save_image(self, *a, **k):
+        if self.sharder.is_main:
+            _save_image(*a, **k)
+
+    def _save(self, obj, path):
+        if self.sharder.is_main:
+            torch.save(obj, path)
+
+    def _exists(self, path):
+        return self.sharder.agree(bool(path) and os.path.exists(path))
+
+    def _load(self, path, **kw):
+        """torch.load on rank 0, broadcast to the others (they may not see rank 0's freshly written file yet)."""
+        if not self.sharder.active:
+            return torch.load(path, **kw)
+        obj = torch.load(path, **kw) if self.sharder.is_main else None
+        return self.sharder.agree(obj if obj is None else obj.cpu())
+
     # ------------------------------------------------------------------ helpers
     def _step(self, xt, t, eta, noise=None):
         """unet + scheduler.step fused on the device (edit.py:2151-2160 / 2572-2581)."""
@@ -111,13 +134,13 @@ class EditUncondDiffusion(object):
         timesteps = self.scheduler.timesteps
         if x0 is None:
             x0 = self.dataset[idx]
-        _save_image((x0 / 2 + 0.5).clamp(0, 1), os.path.join(self.result_folder, 'original.png'))
+        self._save_image((x0 / 2 + 0.5).clamp(0, 1), os.path.join(self.result_folder, 'original.png'))
         xt = x0.to(self.device, dtype=self.dtype).contiguous()
         for i, t in enumerate(timesteps):
             if i == len(timesteps) - 1:
                 break
             xt = self._step(xt, t, eta=0)
-        _save_image((xt / 2 + 0.5).clamp(0, 1), os.path.join(self.result_folder, f'xT-{EXP_NAME}.png'))
+        self._save_image((xt / 2 + 0.5).clamp(0, 1), os.path.join(self.result_folder, f'xT-{EXP_NAME}.png'))
         return xt
 
     @torch.no_grad()
@@ -147,7 +170,7 @@ class EditUncondDiffusion(object):
             xt = self._step(xt, t, eta=eta, noise=nz)
         if save_image:
             image = (xt / 2 + 0.5).clamp(0, 1)
-            _save_image(image, os.path.join(self.result_folder, f'{self.EXP_NAME}.png'), nrow=image.size(0))
+            self._save_image(image, os.path.join(self.result_folder, f'{self.EXP_NAME}.png'), nrow=image.size(0))
         if return_xt:
             return xt
         return
@@ -193,7 +216,7 @@ class EditUncondDiffusion(object):
         xt, t, t_idx = self.DDIMforwardsteps(xT, t_start_idx=0, t_end_idx=self.edit_t_idx)
         assert t_idx == self.edit_t_idx
         print('!!!LOAD VT FROM VT_PATH!!!')
-        vT_list = [torch.load(self.vT_path), torch.load(self.vT1_path)]
+        vT_list = [self._load(self.vT_path), self._load(self.vT1_path)]
         BASIS_NAME = "load-basis-2"
         xt_temp = xt.detach().clone()
         xt_vis_list = [xt_temp]
@@ -253,7 +276,7 @@ class EditUncondDiffusion(object):
         xt, t, t_idx = self.DDIMforwardsteps(xT, t_start_idx=0, t_end_idx=self.edit_t_idx)
         assert t_idx == self.edit_t_idx
 
-        if not os.path.exists(self.vT_path):
+        if not self._exists(self.vT_path):
             print('!!!CALCULATING VT!!!')
             tag = self.args.choose_sem if self.dataset_name in ("CelebA_HQ_mask", "Synthetic") else self.args.mask_index
             save_dir = os.path.join(self.result_folder, "basis", f'local_basis-{self.edit_t}T-select-mask-{tag}')
@@ -261,27 +284,27 @@ class EditUncondDiffusion(object):
             vT_modify_path = os.path.join(save_dir, f'vT-modify-pca-rank-{pca_rank}.pt')
             vT_null_path = os.path.join(save_dir, f'vT-null-{pca_rank_null}.pt')
 
-            if os.path.exists(vT_modify_path):
-                vT_modify = torch.load(vT_modify_path, map_location=self.device).type(self.dtype)
+            if self._exists(vT_modify_path):
+                vT_modify = self._load(vT_modify_path, map_location=self.device).to(self.device).type(self.dtype)
             else:
                 print('!!!RUN LOCAL PULLBACK FOR EDIR SPACE!!!')
                 u_modify, s_modify, vT_modify = self.local_encoder_decoder_pullback_xt(
                     x=xt, t=t, op=op, block_idx=block_idx, pca_rank=pca_rank,
                     min_iter=10, max_iter=50, convergence_threshold=1e-4, mask=mask, noise=encoder_decoder_by_et)
-                torch.save(vT_modify, vT_modify_path)
+                self._save(vT_modify, vT_modify_path)
 
             vT_null = None
-            if null_space_projection and os.path.exists(vT_null_path):
-                vT_null = torch.load(vT_null_path, map_location=self.device).type(self.dtype)
+            if null_space_projection and self._exists(vT_null_path):
+                vT_null = self._load(vT_null_path, map_location=self.device).to(self.device).type(self.dtype)
             elif null_space_projection:
                 print('!!!RUN LOCAL PULLBACK FOR NULL SPACE!!!')
                 u_null, s_null, vT_null = self.local_encoder_decoder_pullback_xt(
                     x=xt, t=t, op=op, block_idx=block_idx, pca_rank=pca_rank_null,
                     min_iter=10, max_iter=50, convergence_threshold=1e-4, mask=~mask, noise=encoder_decoder_by_et)
-                torch.save(vT_null, vT_null_path)
+                self._save(vT_null, vT_null_path)
 
             if random_edit:
-                vT_modify = torch.randn_like(vT_modify)
+                vT_modify = torch.randn_like(vT_modify)       # same generator state on every rank (seed broadcast in main)
 
             # normalize vT (edit.py:2316-2323)
             if not null_space_projection:
@@ -294,10 +317,10 @@ class EditUncondDiffusion(object):
             # IndexError for vis_num_pc > rank; main.py always passes vis_num_pc == pca_rank
             for pc_idx in range(min(max(vis_num_pc, vT.shape[0]), vT.shape[0])):
                 self.EXP_NAME = f'{idx}-Edit_xt-noise-{BASIS_NAME}-pc_{pc_idx:0=3d}'
-                torch.save(vT[[pc_idx], :], os.path.join(save_dir, f'{self.EXP_NAME}-vT.pt'))
+                self._save(vT[[pc_idx], :], os.path.join(save_dir, f'{self.EXP_NAME}-vT.pt'))
         else:
             print('!!!LOAD VT FROM VT_PATH!!!')
-            vT = torch.load(self.vT_path).to(self.device, torch.float32)
+            vT = self._load(self.vT_path).to(self.device, torch.float32)
             BASIS_NAME = f"edit_{self.edit_t}T-load-basis-'{os.path.basename(self.vT_path)}'"
 
         # edit (edit.py:2339-2364)

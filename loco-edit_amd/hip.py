@@ -27,13 +27,13 @@ SYMBOLS = [
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop", "loco_debug_tensor",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision",
-    "loco_bench_conv", "loco_debug_read_scratch",
+    "loco_bench_conv",
 ]
 
 
 class LocoCfg(C.Structure):
     _fields_ = [
-        ("resolution", C.c_int32), ("in_channels", C.c_int32), ("out_ch", C.c_int32), ("ch", C.c_int32),
+        ("struct_size", C.c_int32), ("resolution", C.c_int32), ("in_channels", C.c_int32), ("out_ch", C.c_int32), ("ch", C.c_int32),
         ("num_levels", C.c_int32), ("ch_mult", C.c_int32 * 8), ("num_res_blocks", C.c_int32),
         ("num_attn_res", C.c_int32), ("attn_resolutions", C.c_int32 * 8), ("gn_groups", C.c_int32),
         ("gn_eps", C.c_float), ("max_batch", C.c_int32),
@@ -88,7 +88,6 @@ def load_library():
     lib.loco_set_precision.argtypes = [vp, i32]
     lib.loco_get_precision.argtypes = [vp]
     lib.loco_bench_conv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32), vp]
-    lib.loco_debug_read_scratch.argtypes = [vp, C.POINTER(f32), i32]
     lib.loco_profile_enable.argtypes = [vp, i32]
     lib.loco_profile_report.argtypes = [vp, C.c_char_p, i64]
     lib.loco_debug_tensor.argtypes = [vp, C.c_char_p, vp, i64, vp]
@@ -126,6 +125,7 @@ class LocoEngine:
         self.cfg = cfg
         self.max_batch = int(max_batch)
         c = LocoCfg()
+        c.struct_size = C.sizeof(LocoCfg)
         c.resolution, c.in_channels, c.out_ch, c.ch = cfg.resolution, cfg.in_channels, cfg.out_ch, cfg.ch
         c.num_levels = len(cfg.ch_mult)
         for i, m in enumerate(cfg.ch_mult):
@@ -280,6 +280,9 @@ class LocoEngine:
         return int(self.lib.loco_mask_count(self._ctx))
 
     # ---- introspection
+    def version(self) -> str:
+        return self.lib.loco_version().decode()
+
     def unet_flops(self) -> float:
         return float(self.lib.loco_unet_flops(self._ctx))
 
@@ -294,10 +297,11 @@ class LocoEngine:
         self._check(self.lib.loco_timer_stop(self._ctx, _stream(), C.byref(ms)), "loco_timer_stop")
         return float(ms.value)
 
-    PRECISIONS = {"f32": 0, "bf16x3": 1}
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "f16": 2}
 
     def set_precision(self, mode: str):
-        """'f32' = exact fp32 MFMA (parity anchor); 'bf16x3' = split-bf16 MFMA (fp32-faithful to ~2^-16)."""
+        """'f32' = exact fp32 MFMA (parity anchor); 'bf16x3' = split-bf16 MFMA (fp32-faithful to ~2^-16);
+        'f16' = one f16 MFMA per product (11-bit operands, fp32 accumulate)."""
         self._check(self.lib.loco_set_precision(self._ctx, self.PRECISIONS[mode]), "loco_set_precision")
 
     def get_precision(self) -> str:
@@ -309,11 +313,6 @@ class LocoEngine:
         self._check(self.lib.loco_bench_conv(self._ctx, cin, cout, H, W, B, mode, taps, tile, iters, C.byref(ms),
                                              _stream()), "loco_bench_conv")
         return float(ms.value)
-
-    def debug_read_scratch(self, n: int):
-        buf = (C.c_float * n)()
-        self._check(self.lib.loco_debug_read_scratch(self._ctx, buf, n), "loco_debug_read_scratch")
-        return list(buf)
 
     def profile_enable(self, on):
         """True/1: per kernel variant; 2: per layer shape; False: off."""

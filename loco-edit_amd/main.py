@@ -1,11 +1,28 @@
 """CLI entry: ``python -m loco_edit_amd.main <flags>`` -- dispatch of reference
-``src/main.py:12-103`` for the unconditional (DDPM) models."""
+``src/main.py:12-103`` for the unconditional (DDPM) models.
+
+Multi-GPU: ``torchrun --nproc-per-node N -m loco_edit_amd.main <flags>`` runs one
+process per GPU; the Jacobian probes of each subspace solve are sharded over the
+ranks (``dist.ProbeSharder``), everything else is replicated, rank 0 writes the files.
+"""
+from . import dist as ldist
 from .define_argparser import parse_args, preset
-from .edit import EditUncondDiffusion
 
 
 def main(argv=None):
-    args = preset(parse_args(argv))
+    args = parse_args(argv)
+    # one process per GPU: bind the device and create the process group before anything touches the GPU
+    rank, world, device = ldist.init_from_env(args.device)
+    args.device = device
+    if world > 1:
+        # `--seed 0` draws a seed (define_argparser.py:140-141): every rank must use rank 0's draw, or x_T and V0
+        # differ across ranks
+        import torch
+        sh = ldist.ProbeSharder("world")
+        if args.seed == 0:
+            args.seed = sh.agree(int(torch.randint(1, 2**32, ())))
+    args = preset(args)
+    from .edit import EditUncondDiffusion
     print('is custmized diffusion model')
     edit = EditUncondDiffusion(args)
     out = None
@@ -24,6 +41,8 @@ def main(argv=None):
         edit.run_DDIMforward(num_samples=5)
     if args.run_ddim_inversion:                  # main.py:102-103
         edit.run_DDIMinversion(idx=args.sample_idx)
+    if world > 1:
+        ldist.shutdown()
     return out
 
 

@@ -28,8 +28,13 @@ class JacobianOperator:
     def __init__(self, engine, x: torch.Tensor, t, at: float, mask: Optional[torch.Tensor], noise: bool = False):
         self.engine = engine
         self.n = engine.n
+        self.masked = mask is not None
         engine.pmp_primal(x.contiguous(), float(t), at, mask, use_et=noise)
-        if mask is not None and hasattr(engine, "mask_count") and engine.mask_count() == 0:
+
+    def check_mask(self):
+        """The gather list is built on the device and its length L is read back lazily (no host sync at the start
+        of a solve): the empty-mask error is raised when L is first needed, at the end of the solve."""
+        if self.masked and self.engine.mask_count() == 0:
             # the reference would run the power iteration on a 0-row Jacobian and return NaN directions
             raise ValueError("empty mask: J = d x0_hat[mask] / d x_t has no rows")
 
@@ -63,8 +68,11 @@ def subspace_iteration(op, algebra, V0: torch.Tensor, min_iter: int = 10, max_it
     for i in range(max_iter):
         V_prev = V
         lo, hi = sharder.rows(k)
-        U_loc = op.jvp(V[lo:hi].contiguous())          # u_i = J v_i            (edit.py:2451-2455)
-        A_loc = op.vjp(U_loc)                           # a_i = J^T u_i          (edit.py:2460-2480)
+        if hi > lo:
+            U_loc = op.jvp(V[lo:hi].contiguous())      # u_i = J v_i            (edit.py:2451-2455)
+            A_loc = op.vjp(U_loc)                       # a_i = J^T u_i          (edit.py:2460-2480)
+        else:                                           # more ranks than probes: this rank only joins the gather
+            U_loc = A_loc = V[0:0].contiguous()
         A = sharder.all_gather_rows(A_loc, k)           # the one collective per iteration
         U = U_loc
         V = A
@@ -103,6 +111,7 @@ def local_basis(engine, x, t, at, pca_rank: int, mask=None, noise=False, min_ite
     op = JacobianOperator(engine, x, t, at, mask, noise)
     U, s, V, n_iter = subspace_iteration(op, engine, V, min_iter, max_iter, convergence_threshold,
                                          sharder=sharder, verbose=verbose)
+    op.check_mask()
     u = op.gather(U).T.contiguous()                                          # [L, k]  (edit.py:2500-2502)
     if verbose:
         torch.cuda.synchronize()

@@ -51,6 +51,9 @@ def get_custom_diffusion_model(args) -> HipUNet:
     if cfg is None:
         raise ValueError('model_name choice: ' + ", ".join(MODEL_CONFIGS))
     engine = LocoEngine(cfg, max_batch=getattr(args, "max_batch", 8), device=args.device)
+    prec = getattr(args, "precision", None) or os.environ.get("LOCO_PRECISION")
+    if prec:
+        engine.set_precision(prec)
     ckpt = getattr(args, "ckpt_path", "")
     if ckpt:
         sd = torch.load(ckpt, map_location="cpu")

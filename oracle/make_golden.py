@@ -132,7 +132,7 @@ def abs_cos_rows(a, b):
 
 
 def gen_for_config(tag, cfg, redit, YHS, PullBackDDPM, k, k_null, n_iter, mrect, tmpdir,
-                   full_tensors=True, pipeline=True):
+                   full_tensors=True, pipeline=True, oracle_solver=True):
     import loco_oracle as orc
     from loco_edit_amd.config import synth_params
     torch.manual_seed(0)
@@ -215,12 +215,13 @@ def gen_for_config(tag, cfg, redit, YHS, PullBackDDPM, k, k_null, n_iter, mrect,
                     convergence_threshold=1e-4, mask=~mask)
         finally:
             torch.randn = real_randn
-        ou, os_, ovT, _ = oed.pullback(x, t, k, v0[:, :k], min_iter=n_iter, max_iter=n_iter,
-                                       convergence_threshold=1e-4, mask=mask)
-        check(f"{tag}/solver s", os_, s_m, rtol=1e-3)
-        c = abs_cos_rows(ovT, vT_m)
-        print(f"  oracle vs reference [{tag}/solver vT] |cos| min {c.min().item():.6f}")
-        assert c.min() > 0.999
+        if oracle_solver:
+            ou, os_, ovT, _ = oed.pullback(x, t, k, v0[:, :k], min_iter=n_iter, max_iter=n_iter,
+                                           convergence_threshold=1e-4, mask=mask)
+            check(f"{tag}/solver s", os_, s_m, rtol=1e-3)
+            c = abs_cos_rows(ovT, vT_m)
+            print(f"  oracle vs reference [{tag}/solver vT] |cos| min {c.min().item():.6f}")
+            assert c.min() > 0.999
         out["n_iter"] = n_iter
         out["s_modify"] = s_m
         out["u_modify"] = u_m
@@ -278,6 +279,44 @@ def gen_for_config(tag, cfg, redit, YHS, PullBackDDPM, k, k_null, n_iter, mrect,
         check(f"{tag}/to_t", oxt, xt_e, rtol=1e-3, atol=1e-4)
         out["pipe_x0"], out["pipe_xT"], out["pipe_xt"], out["pipe_dec"] = x0, xT, xt_e, xdec
     return out
+
+
+def gen_eta1_decode(redit, YHS, PullBackDDPM, tmpdir):
+    """Fixture family 6, stochastic half: the reference's DDIMforwardsteps from the edit step to x0 with
+    performance_boosting=True (eta switches 0 -> 1 at index 79, edit.py:2556-2559) on a batch of 2, with the
+    `torch.randn_like` draws of YHCustomScheduler.step (utils.py:374) replaced by a recorded sequence."""
+    import loco_oracle as orc
+    from loco_edit_amd.config import TINY_DDPM as cfg, synth_params
+    params = synth_params(cfg, seed=0)
+    model = ref_model(PullBackDDPM, cfg, params)
+    ed = ref_edit(redit, YHS, model, tmpdir)
+    base = torch.load(os.path.join(GOLD, "tiny.pt"))
+    xt = torch.cat([base["pipe_xt"], base["pipe_xt"] + 0.25 * base["x"]], dim=0)
+    gn = torch.Generator().manual_seed(23)
+    noises = []
+    real = torch.randn_like
+
+    def fake_randn_like(x, **kw):
+        nz = torch.randn(x.shape, generator=gn)
+        noises.append(nz)
+        return nz
+
+    torch.randn_like = fake_randn_like
+    try:
+        with torch.no_grad():
+            dec = ed.DDIMforwardsteps(xt, t_start_idx=ed.edit_t_idx, t_end_idx=-1, performance_boosting=True,
+                                      save_image=False)
+    finally:
+        torch.randn_like = real
+    pbi = int(ed.performance_boosting_t_idx)
+    assert len(noises) == 99 - pbi, (len(noises), pbi)
+    # the oracle on the same draws
+    oed = orc.OracleEdit(orc.to_torch(params), cfg)
+    oed.performance_boosting_t_idx = pbi
+    odec = oed.ddim_forwardsteps(xt, int(ed.edit_t_idx), -1, performance_boosting=True,
+                                 noises={pbi + j: nz for j, nz in enumerate(noises)})
+    check("tiny/eta1 decode", odec, dec, rtol=1e-3, atol=1e-4)
+    return {"xt": xt, "pbt_idx": pbi, "first_noise_step": pbi, "noises": torch.stack(noises), "dec": dec}
 
 
 def gen_scheduler(YHS, extract):
@@ -354,6 +393,17 @@ def main():
                            mrect=(110, 130, 70, 110), tmpdir=tmpdir, full_tensors=False, pipeline=False)
         o = {k: v for k, v in o.items() if v is not None}
         torch.save(o, os.path.join(GOLD, "p2_256.pt"))
+    if a.only == "p2_solver":
+        print("FFHQ-P2 256x256 solver fixture: 16 probes, 3 iterations")
+        o = gen_for_config("p2_solver", FFHQ_P2, redit, YHS, PullBackDDPM, k=16, k_null=0, n_iter=3,
+                           mrect=(110, 130, 70, 110), tmpdir=tmpdir, full_tensors=False, pipeline=False,
+                           oracle_solver=False)
+        keep = ("cfg", "weights_seed", "x", "t", "mask", "v0_seed", "n_iter", "s_modify", "vT_modify_f16",
+                "vT_proj_seed", "vT_modify_proj")
+        torch.save({k: o[k] for k in keep}, os.path.join(GOLD, "p2_solver.pt"))
+    if a.only == "eta1":
+        print("tiny eta=1 decode with injected noise")
+        torch.save(gen_eta1_decode(redit, YHS, PullBackDDPM, tmpdir), os.path.join(GOLD, "tiny_eta1.pt"))
     if a.full:
         print("full config (256x256 CelebA-HQ DDPM arch)")
         o = gen_for_config("celeba256", CELEBA_DDPM, redit, YHS, PullBackDDPM, k=5, k_null=0,

@@ -89,3 +89,62 @@ def test_sharded_equals_single():
     assert torch.allclose(s1, s2, rtol=1e-5)
     assert (V1 * V2).sum(dim=1).abs().min() > 0.99999
     assert torch.allclose(U1, U2, rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# the CLI under torchrun: process group from the environment, rank 0's seed everywhere, rank 0 alone
+# writes, file-existence branches agreed, uneven probe shards
+def _run_cli(rank, world, port, tmp, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LOCO_DIST_BACKEND="gloo")
+    os.chdir(tmp)
+    import loco_edit_amd  # noqa: F401
+    import loco_edit_amd.edit as ledit
+    from loco_edit_amd import main as lmain
+    from loco_edit_amd.dist import ProbeSharder
+
+    class StubEdit(ledit.EditUncondDiffusion):
+        def __init__(self, args):
+            self.args, self.sharder = args, ProbeSharder("world")
+            self.result_folder = args.result_folder
+
+        def run_edit_null_space_projection(self, idx, **kw):
+            p = os.path.join(self.result_folder, "vT-test.pt")
+            e1 = self._exists(p)
+            self._save(torch.full((1, 4), float(self.sharder.rank)), p)
+            self.sharder.barrier()
+            e2 = self._exists(p)
+            v = self._load(p)
+            # 5 probes on 2 ranks: shards of 3 and 2 rows, gathered in probe order
+            lo, hi = self.sharder.rows(5)
+            rows = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
+            g = self.sharder.all_gather_rows(rows, 5)
+            return dict(rank=self.sharder.rank, seed=self.args.seed, device=str(self.args.device), e1=e1, e2=e2,
+                        loaded=float(v[0, 0]), rows=(lo, hi), gathered=g[:, 0].tolist(),
+                        draw=float(torch.rand(())))
+
+    ledit.EditUncondDiffusion = StubEdit
+    out = lmain.main(["--device", "cpu", "--seed", "0", "--performance_boosting_t", "0.2", "--result_folder", tmp,
+                      "--run_edit_null_space_projection", "True", "--pca_rank", "5"])
+    q.put(out)
+
+
+def test_cli_two_ranks_gloo(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run_cli, args=(r, 2, 29583, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120), q.get(timeout=120)], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res
+    assert a["seed"] == b["seed"] != 0 and a["draw"] == b["draw"]          # rank 0's drawn seed on both ranks
+    assert (a["e1"], b["e1"], a["e2"], b["e2"]) == (False, False, True, True)
+    assert a["loaded"] == b["loaded"] == 0.0                                 # only rank 0 wrote; both hold its tensor
+    assert a["rows"] == (0, 3) and b["rows"] == (3, 5)
+    assert a["gathered"] == b["gathered"] == [0.0, 1.0, 2.0, 3.0, 4.0]
+    pts = [f for _, _, fs in os.walk(tmp_path) for f in fs if f.endswith(".pt")]
+    assert pts == ["vT-test.pt"]
