@@ -22,11 +22,16 @@
 #pragma once
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace loco {
 
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));             // 16-byte global load from a 4-byte aligned address
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 f32x2_u __attribute__((aligned(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));      // 16-byte operand fragment, reinterpreted per arithmetic
@@ -115,6 +120,10 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
     constexpr int NITEM = GEN ? (2 * max_halo(NT, TAPS, STG == 2) + NTHR - 1) / NTHR : 1;
     constexpr int WTOT = NTS * MT * NPC;             // 16-byte pieces of one weight stage
     constexpr int NWV = (WTOT + NTHR - 1) / NTHR;
+    // cross-stage operand prefetch (see the stage loop): 3x3 stride-1 variants; the stride-2 halo leaves no LDS for a
+    // third weight buffer, and the 1x1 convs are HBM-bound
+    constexpr bool XPF = (TAPS == 9 && STG != 2);
+    constexpr int NWB = XPF ? 3 : 2;                 // weight stage buffers
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     // double-buffered: weight stage s lives in W buffer s&1, the halo of chunk c in H buffer c&1
@@ -171,7 +180,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
     const int halo_h = (TH - 1) * S + KS;
     const int halo_sz = halo_h * halo_w;
     const int HBYTES = (halo_sz + NDUMMY) * HP;     // + dump records for the lanes without a halo item
-    Hsb = smem_b + 2 * WBYTES;
+    Hsb = smem_b + NWB * WBYTES;
 
     const int LH = (a.upsample || a.zins) ? a.Hin * 2 : a.Hin;
     const int LW = (a.upsample || a.zins) ? a.Win * 2 : a.Win;
@@ -282,10 +291,23 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
     // split the CHANNELS, not the pixels: every load stays a full 16-byte run of 4 pixels.
     constexpr int NPART = (!GEN && NROW == 3) ? 2 : 1;
     constexpr int KP = 4 / NPART;
+    // The staged values stay whole 16-byte vectors from the load to their last use (components are sub-register
+    // reads): split into scalars, the register allocator parks the load results in freed fragment registers and copies
+    // single dwords out behind a vmcnt wait, which exposes the memory latency in every stage.
     struct HaloRegs {
-        float dq[GEN ? 1 : KP][4];                    // !GEN: [channel of the part][pixel]
-        float2 sq[(!GEN && NEEDP) ? KP : 1][4];       // {S, xhat} of those pixels
-        float cqa[(!GEN && MODE != CM_NONE) ? KP : 1], cqb[(!GEN && MODE != CM_NONE) ? KP : 1];   // per-channel constants
+        f32x4 dq[GEN ? 1 : KP];                       // !GEN: [channel of the part] x 4 pixels
+        f32x4 sq[(!GEN && NEEDP) ? KP : 1][2];        // {S, xhat} of those pixels: {S0,x0,S1,x1}, {S2,x2,S3,x3}
+        f32x4 cq[(!GEN && MODE != CM_NONE) ? (KP == 4 ? 2 : 1) : 1];   // per-channel constants, see cq_a / cq_b
+    };
+    // constants of channel kk of the part: tangent / cotangent modes load interleaved {a, b} pairs; the forward modes load
+    // the a's (scale) and the b's (shift) as two runs -- KP == 2: one vector {a0,a1,b0,b1}; KP == 4: {a0..a3}, {b0..b3}
+    auto cq_a = [&](const HaloRegs& R, int kk) -> float {
+        if constexpr (NEEDP) return KP == 4 ? R.cq[kk >> 1][(kk & 1) * 2] : R.cq[0][kk * 2];
+        else return KP == 4 ? R.cq[0][kk] : R.cq[0][kk];
+    };
+    auto cq_b = [&](const HaloRegs& R, int kk) -> float {
+        if constexpr (NEEDP) return KP == 4 ? R.cq[kk >> 1][(kk & 1) * 2 + 1] : R.cq[0][kk * 2 + 1];
+        else return KP == 4 ? R.cq[1][kk] : R.cq[0][2 + kk];
     };
     HaloRegs hr;                                      // the part in flight inside the stage loop
     auto prefetch_hv = [&](HaloRegs& R, int chunk, int part) {
@@ -299,19 +321,23 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
         for (int kk = 0; kk < KP; ++kk) {
             const unsigned po = v_goff + (unsigned)(part * KP + kk) * pl;
             // 4-byte aligned 16-byte loads (global memory tolerates dword alignment)
-            __builtin_memcpy(&R.dq[kk][0], pk + po, 16);
-            if constexpr (NEEDP) __builtin_memcpy(&R.sq[kk][0], sk + 2u * po, 32);
+            R.dq[kk] = *reinterpret_cast<const f32x4_u*>(pk + po);
+            if constexpr (NEEDP) {
+                R.sq[kk][0] = *reinterpret_cast<const f32x4_u*>(sk + 2u * po);
+                R.sq[kk][1] = *reinterpret_cast<const f32x4_u*>(sk + 2u * po + 16);
+            }
         }
         const int c0 = chunk * BKC + v_q4 * 4 + part * KP;    // first channel of this part
         if constexpr (MODE != CM_NONE) {
             if constexpr (NEEDP) {      // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent) per channel
-                float t[2 * KP];
-                __builtin_memcpy(t, tcb + 2 * c0, sizeof(t));
-#pragma unroll
-                for (int kk = 0; kk < KP; ++kk) { R.cqa[kk] = t[2 * kk]; R.cqb[kk] = t[2 * kk + 1]; }
+                R.cq[0] = *reinterpret_cast<const f32x4_u*>(tcb + 2 * c0);
+                if constexpr (KP == 4) R.cq[1] = *reinterpret_cast<const f32x4_u*>(tcb + 2 * c0 + 4);
+            } else if constexpr (KP == 4) {
+                R.cq[0] = *reinterpret_cast<const f32x4_u*>(scb + c0);
+                R.cq[1] = *reinterpret_cast<const f32x4_u*>(shb + c0);
             } else {
-                __builtin_memcpy(R.cqa, scb + c0, sizeof(float) * KP);
-                __builtin_memcpy(R.cqb, shb + c0, sizeof(float) * KP);
+                const f32x2 sa = *reinterpret_cast<const f32x2_u*>(scb + c0), sb = *reinterpret_cast<const f32x2_u*>(shb + c0);
+                R.cq[0] = f32x4{sa[0], sa[1], sb[0], sb[1]};
             }
         }
     };
@@ -325,14 +351,14 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 float d = R.dq[kk][pxi];
                 float v = d;
                 if constexpr (MODE == CM_GN_SILU) {
-                    float y = fmaf(R.cqa[kk], d, R.cqb[kk]);
+                    float y = fmaf(cq_a(R, kk), d, cq_b(R, kk));
                     v = y * sigmoidf2_(y);
                 } else if constexpr (MODE == CM_GN) {
-                    v = fmaf(R.cqa[kk], d, R.cqb[kk]);
+                    v = fmaf(cq_a(R, kk), d, cq_b(R, kk));
                 } else if constexpr (NEEDP) {
-                    const float Sv = R.sq[kk][pxi].x, xh = R.sq[kk][pxi].y;
-                    if constexpr (MODE == CM_TAN_SILU) v = Sv * (d - R.cqa[kk] - xh * R.cqb[kk]);
-                    else v = Sv * d - R.cqa[kk] - xh * R.cqb[kk];
+                    const float Sv = R.sq[kk][pxi >> 1][(pxi & 1) * 2], xh = R.sq[kk][pxi >> 1][(pxi & 1) * 2 + 1];
+                    if constexpr (MODE == CM_TAN_SILU) v = Sv * (d - cq_a(R, kk) - xh * cq_b(R, kk));
+                    else v = Sv * d - cq_a(R, kk) - xh * cq_b(R, kk);
                 }
                 r[kk] = ((v_pm >> pxi) & 1u) ? v : 0.0f;
             }
@@ -494,6 +520,28 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
             }
     };
 
+    // the same products split in two: head = the (0,0) sub-tile, tail = the rest (cross-stage prefetch pipeline)
+    auto mma_one = [&](const Frag& f, int i, int j) {
+        if constexpr (PR == PR_F16) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.ah[i]),
+                                                               __builtin_bit_cast(f16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+        } else {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, f.ah[i]), al = __builtin_bit_cast(bf16x8, f.al[i]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, f.bh[j]), bl = __builtin_bit_cast(bf16x8, f.bl[j]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+        }
+    };
+    auto mma_frag_head = [&](const Frag& f) { mma_one(f, 0, 0); };
+    auto mma_frag_tail = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (i + j > 0) mma_one(f, i, j);
+    };
+
     // Software pipeline with ONE barrier per stage (s = NROW*chunk + row).  Stage s multiplies out of W[s&1] /
     // H[chunk&1].  It opens by launching the LDS-DMA of stage s+1's weights into W[(s+1)&1]; between its taps it
     // converts one part of the NEXT chunk's halo (loaded into registers at the end of an earlier stage) into
@@ -515,6 +563,113 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    if constexpr (XPF) {
+        // ---- 3x3, stride 1: CROSS-STAGE operand prefetch ------------------------------------------------------------
+        // The operand fragments of a tap are read from LDS one whole tap ahead, ACROSS the stage barrier: while the
+        // MFMAs of tap t run, the ds_reads of tap t+1 are in flight -- also when tap t+1 opens the next stage -- so no
+        // stage starts with an exposed LDS burst (8 waves x 16 ds_read_b128 right behind the barrier, ~600 cycles of
+        // idle matrix pipe per stage before).  Two fragment sets alternate per tap; a chunk has 9 taps, so the roles
+        // flip every chunk and the loop is unrolled over two chunks (compile-time parity P).  Reading stage s+1's
+        // weights inside stage s needs them complete one barrier earlier: THREE weight buffers, the LDS-DMA runs two
+        // stages ahead (buffer index = kernel row: 3 rows, 3 buffers).  The halo of chunk c+1 is complete before row 2
+        // of chunk c starts (vector path: parts in rows 0 and 1; per-pixel path: converted in row 1).
+        Frag fr[2];
+        auto stage_of = [&](int ci_, int row_, int& c_out, int& r_out) {   // (chunk, row) of the stage `row_` may overflow into
+            c_out = cclamp(cbeg + ci_ + row_ / NROW);
+            r_out = row_ % NROW;
+        };
+        if (nch > 0) {
+            int c1, r1;
+            dma_w(cbeg, 0, Wsb);
+            stage_of(0, 1, c1, r1);
+            dma_w(c1, r1, Wsb + WBYTES);
+            Hs = Hsb;
+            if constexpr (!GEN && NPART == 2) {
+                // both parts of the first chunk are loaded together (a second register set that only lives here) so
+                // the workgroup pays one memory latency, not two, before its first stage
+                HaloRegs hr2;
+                prefetch_hv(hr, cbeg, 0);
+                prefetch_hv(hr2, cbeg, 1);
+                stage_hv(hr, 0);
+                stage_hv(hr2, 1);
+            } else {
+                prefetch_h(cbeg, 0);
+                stage_h(cbeg, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prefetch_h(cclamp(cbeg + 1), 0);          // pending part / chunk expected by the first chunk's conversion
+            stage_end();
+            Ws = Wsb; Hs = Hsb;
+            load_frag(fr[0], 0, 0);                   // the only exposed operand read of the tile
+        }
+        auto chunk_body = [&](auto ptag, const int ci) {
+            constexpr int P = decltype(ptag)::value;
+            const int chunk = cbeg + ci;
+            unsigned char* const Hcur = Hsb + P * HBYTES;
+            unsigned char* const Hnxt = Hsb + (1 - P) * HBYTES;
+#pragma unroll
+            for (int row = 0; row < NROW; ++row) {
+                unsigned char* const Wcur = Wsb + row * WBYTES;
+                unsigned char* const Wnx1 = Wsb + ((row + 1) % 3) * WBYTES;
+                unsigned char* const Wnx2 = Wsb + ((row + 2) % 3) * WBYTES;
+                // which halo part of the next chunk this row converts (-1: none) and which it (re)loads
+                const int st_part = NPART == 2 ? (row == 0 ? 0 : row == 1 ? 1 : -1) : (row == 1 ? 0 : -1);
+                const int ld_part = NPART == 2 ? (row == 0 ? 1 : row == 1 ? 0 : -1) : (row == 2 ? 0 : -1);
+                const int ld_chunk = NPART == 2 ? (row == 1 ? chunk + 2 : chunk + 1) : chunk + 2;
+                constexpr bool MIDLOAD = !GEN;          // issue the loads inside the stage, behind the conversion
+                constexpr int NLD = KP + (NEEDP ? 2 * KP + 1 : (MODE != CM_NONE ? 2 : 0));
+                {
+                    int c2, r2;
+                    stage_of(ci, row + 2, c2, r2);
+                    dma_w(c2, r2, Wnx2);               // weights of the stage after next
+                }
+                Frag& fa = fr[(P + row) & 1];          // taps 0 and 2 of this stage
+                Frag& fb = fr[(P + row + 1) & 1];      // tap 1, then tap 0 of the next stage
+                // One tap = [first MFMAs of the tap | ds_reads of the NEXT tap | remaining MFMAs (+ staging work)]: the
+                // reads are issued once the matrix pipe has work queued and have the rest of the tap to land, and the
+                // wait in front of a tap's first MFMA only covers reads issued a whole tap earlier.
+                Ws = Wcur; Hs = Hcur;
+                mma_frag_head(fa);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frag(fb, row, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_frag_tail(fa);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_frag_head(fb);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frag(fa, row, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                // halo conversion of the next chunk under the remaining MFMAs of tap 1 ...
+                if (st_part >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), st_part); }
+                mma_frag_tail(fb);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_frag_head(fa);
+                __builtin_amdgcn_sched_barrier(0);
+                // operands of the NEXT stage's first tap (same chunk: next kernel row; last row: next chunk's halo)
+                Ws = Wnx1;
+                if (row + 1 < NROW) { Hs = Hcur; load_frag(fb, row + 1, 0); }
+                else { Hs = Hnxt; load_frag(fb, 0, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+                // ... and the re-load of the converted registers under those of tap 2, in a region of its own: the loads
+                // then land directly in the registers the conversion has finished reading (no copies behind a vmcnt wait)
+                if (MIDLOAD && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+                mma_frag_tail(fa);
+                __builtin_amdgcn_sched_barrier(0);
+                // the LDS-DMA of this stage (older than the part loads just issued) must have landed before the barrier
+                if (MIDLOAD && ld_part >= 0) {
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!MIDLOAD && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+                }
+                stage_end();
+            }
+        };
+        for (int ci = 0; ci < nch; ci += 2) {
+            chunk_body(std::integral_constant<int, 0>{}, ci);
+            if (ci + 1 < nch) chunk_body(std::integral_constant<int, 1>{}, ci + 1);
+        }
+    } else {
     if (nch > 0) {
         dma_w(cbeg, 0, Wsb);
         Hs = Hsb;
@@ -587,6 +742,8 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
             }
             stage_end();
         }
+    }
+
     }
 
     // epilogue.  D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -670,7 +827,8 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     int TW = a.Wout < 32 ? a.Wout : 32;
     int TH = NT / TW;
     int halo_w = (TW - 1) * a.stride + KS, halo_h = (TH - 1) * a.stride + KS;
-    size_t lds = 2 * ((size_t)KS * MT * rec_bytes<PR>() + ((size_t)halo_w * halo_h + NDUMMY) * halo_pitch<PR>());
+    const int nwb = (TAPS == 9 && STG != 2) ? 3 : 2;
+    size_t lds = (size_t)nwb * KS * MT * rec_bytes<PR>() + 2 * ((size_t)halo_w * halo_h + NDUMMY) * halo_pitch<PR>();
     dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
     auto kern = PR == PR_F16 ? &conv_mfma_f16<TAPS, WM, WN, TM, TN, MODE, STG>
                              : &conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;
