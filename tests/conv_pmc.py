@@ -7,7 +7,8 @@ import loco_edit_amd.hip as H
 from loco_edit_amd.config import CELEBA_DDPM, synth_params
 eng = H.LocoEngine(CELEBA_DDPM, max_batch=8)
 eng.load_state_dict(synth_params(CELEBA_DDPM, 0))
-eng.set_precision("bf16x3")
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
+eng.set_precision(prec)
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 ms = eng.bench_conv(128, 128, 256, 256, 5, mode, 9, 5, 3)
-print(f"mode {mode}: {ms*1e3:.1f} us")
+print(f"{prec} mode {mode}: {ms*1e3:.1f} us")
