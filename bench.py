@@ -162,11 +162,12 @@ def parity_vs_fixture(s, vT, name):
         return None
     g = torch.load(path)
     k = g["s_modify"].shape[0]
-    ref = g["vT_modify_f16"].float()
+    ref = g["vT_modify_f16"].double()                                # fp64 dot products: n = 196608 terms
     ref = ref / ref.norm(dim=1, keepdim=True)
-    v = vT[:k].detach().cpu().float()
+    v = vT[:k].detach().cpu().double()
+    v = v / v.norm(dim=1, keepdim=True)
     cos = (v * ref).sum(dim=1).abs()
-    ov = torch.linalg.svdvals(v.double() @ ref.double().T)          # principal-angle cosines of the two spans
+    ov = torch.linalg.svdvals(v @ ref.T)                             # principal-angle cosines of the two spans
     srel = ((s[:k].detach().cpu() - g["s_modify"]).abs() / g["s_modify"]).max()
     return {"fixture": f"tests/golden/{name}.pt (reference output, {g['n_iter']} iterations, same x/t/mask/V0)",
             "n_iter": int(g["n_iter"]), "cos_min": round(float(cos.min()), 6), "cos": [round(float(c), 6) for c in cos],

@@ -126,6 +126,7 @@ def check(name, a, b, rtol=1e-4, atol=1e-5):
 
 
 def abs_cos_rows(a, b):
+    a, b = a.double(), b.double()
     a = a / a.norm(dim=1, keepdim=True)
     b = b / b.norm(dim=1, keepdim=True)
     return (a * b).sum(dim=1).abs()
