@@ -401,7 +401,7 @@ def main():
                 "scaling": "strong", "n_gpus": world, "probes_per_gpu": kl, "n_iter": N_ITER,
                 "whole_step_TFLOPs_executed_per_gpu": round((1 + 2 * kl * N_ITER) * F2 / el / 1e12, 2),
                 "singular_values_head": [round(float(v), 4) for v in s3.tolist()[:5]],
-                "orthonormality_err": float(f"{float((vT3[:20] @ vT3[:20].T - torch.eye(20, device=device)).abs().max()):.2e}"),
+                "orthonormality_err": float(f"{float((vT3[:20].double() @ vT3[:20].double().T - torch.eye(20, device=device, dtype=torch.float64)).abs().max()):.2e}"),
             }
 
     cpu = None

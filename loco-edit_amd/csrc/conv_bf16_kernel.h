@@ -222,9 +222,14 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
     if constexpr (!GEN) {
         const int per_q = halo_h * nseg;
         if (tid < 4 * per_q) {
-            v_q4 = tid / per_q;
-            int rem = tid - v_q4 * per_q;
-            int hy = rem / nseg, sg = rem - hy * nseg;
+            // Lane order: channel quarter fastest, then halo ROW, then the 4-pixel segment.  The LDS stores of one pixel
+            // index (a dword or two per record) then spread over banks 8*row + 4*octet + 2*half: 16 distinct bank
+            // pairs per half-wave, a 2-way conflict at worst.  With segments fastest (records 4 apart = 320 bytes) all
+            // lanes of a half-wave fell on two bank groups -- a 16-way conflict that kept the LDS busy for ~2000
+            // cycles per halo part and stalled the operand reads of every wave (55 of 340 us on the 128->128 conv).
+            v_q4 = tid & 3;
+            const int it = tid >> 2;
+            const int sg = it / halo_h, hy = it - sg * halo_h;
             int Y = oy0 - a.pad + hy, X0 = ox0 - a.pad + 4 * sg;
             bool rowok = (Y >= 0 && Y < a.Hin);
             v_pos0 = hy * halo_w + 4 * sg;

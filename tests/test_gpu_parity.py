@@ -182,7 +182,8 @@ def test_headline_config_12_iterations_vs_reference(prec, engines, golden):
     sign = torch.sign((vT.cpu() * g["vT_modify_f16"].float()).sum(dim=1, keepdim=True))
     if prec == "f32":
         assert rel(sign * (vT.cpu() @ P), g["vT_modify_proj"]) < 5e-2
-    assert (vT @ vT.T - torch.eye(k, device=DEV)).abs().max().item() < 1e-5
+    vd = vT.double()      # fp64 Gram: an fp32 GEMM over n = 196608 terms has ~3e-5 of summation error on the diagonal
+    assert (vd @ vd.T - torch.eye(k, device=DEV, dtype=torch.float64)).abs().max().item() < 2e-6
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -233,7 +234,8 @@ def test_config3_p2_rank20_of_64_probes_at_size(engines, golden):
     _, s12, vT12, n_it = solver.local_basis(eng, x, t, at, 64, mask=mask, min_iter=12, max_iter=12, v0=v64, verbose=False)
     keep = vT12[:20]
     assert n_it == 12 and vT12.shape == (64, cfg.n)
-    assert (keep @ keep.T - torch.eye(20, device=DEV)).abs().max().item() < 2e-5
+    kd = keep.double()
+    assert (kd @ kd.T - torch.eye(20, device=DEV, dtype=torch.float64)).abs().max().item() < 2e-6
     assert bool((s12[:-1] >= s12[1:] * (1 - 1e-5)).all()) and bool(torch.isfinite(vT12).all())
     eng.pmp_primal(x, t, at, mask)
     JV = eng.pmp_jvp(keep[:8].contiguous())
