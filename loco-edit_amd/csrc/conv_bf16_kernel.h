@@ -221,15 +221,30 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
     unsigned v_goff = 0;                     // byte offset of the item's first pixel / channel from (chunk base - 16 floats)
     if constexpr (!GEN) {
         const int per_q = halo_h * nseg;
-        if (tid < 4 * per_q) {
-            // Lane order: channel quarter fastest, then halo ROW, then the 4-pixel segment.  The LDS stores of one pixel
-            // index (a dword or two per record) then spread over banks 8*row + 4*octet + 2*half: 16 distinct bank
-            // pairs per half-wave, a 2-way conflict at worst.  With segments fastest (records 4 apart = 320 bytes) all
-            // lanes of a half-wave fell on two bank groups -- a 16-way conflict that kept the LDS busy for ~2000
-            // cycles per halo part and stalled the operand reads of every wave (55 of 340 us on the 128->128 conv).
-            v_q4 = tid & 3;
-            const int it = tid >> 2;
-            const int sg = it / halo_h, hy = it - sg * halo_h;
+        // Lane order of the staging items.  The LDS stores of one pixel index put a dword or two into each record; the
+        // record pitch (80 / 48 bytes) sends them to bank 8*row + 16*seg + 4*octet + 2*half (mod 32), so only the low bits
+        // of (row, seg, octet, half) can spread a half-wave over banks.  Default order below: lane bits = {seg & 3, row & 1,
+        // half, octet}: 16 distinct bank pairs per half-wave (2-way conflict) while 4 consecutive segments (64 bytes of
+        // one image row) stay adjacent lanes for the global loads.  The plain order (segments fastest, then rows, then
+        // channel quarters) is 8-way conflicted; it remains the fallback when the padded index space does not fit the
+        // workgroup.
+        const int nsg4 = (nseg + 3) >> 2, nhy2 = (halo_h + 1) >> 1;
+        bool have = false;
+        int hy = 0, sg = 0;
+        if (32 * nsg4 * nhy2 <= NTHR) {
+            const int hi = tid >> 5;                       // (seg >> 2, row >> 1)
+            v_q4 = (tid >> 3) & 3;
+            sg = (hi % nsg4) * 4 + (tid & 3);
+            hy = (hi / nsg4) * 2 + ((tid >> 2) & 1);
+            have = hi < nsg4 * nhy2 && sg < nseg && hy < halo_h;
+            if (!have) v_q4 = 0;
+        } else if (tid < 4 * per_q) {
+            v_q4 = tid / per_q;
+            int rem = tid - v_q4 * per_q;
+            hy = rem / nseg; sg = rem - hy * nseg;
+            have = true;
+        }
+        if (have) {
             int Y = oy0 - a.pad + hy, X0 = ox0 - a.pad + 4 * sg;
             bool rowok = (Y >= 0 && Y < a.Hin);
             v_pos0 = hy * halo_w + 4 * sg;

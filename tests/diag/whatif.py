@@ -77,4 +77,6 @@ def run():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2:      # subset of variants: python tests/diag/whatif.py build v0_base,v1_noconv
+        VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[2].split(",")}
     {"build": build, "run": run}[sys.argv[1]]()
