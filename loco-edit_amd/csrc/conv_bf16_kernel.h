@@ -632,11 +632,15 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 unsigned char* const Wcur = Wsb + row * WBYTES;
                 unsigned char* const Wnx1 = Wsb + ((row + 1) % 3) * WBYTES;
                 unsigned char* const Wnx2 = Wsb + ((row + 2) % 3) * WBYTES;
-                // which halo part of the next chunk this row converts (-1: none) and which it (re)loads
-                const int st_part = NPART == 2 ? (row == 0 ? 0 : row == 1 ? 1 : -1) : (row == 1 ? 0 : -1);
-                const int ld_part = NPART == 2 ? (row == 0 ? 1 : row == 1 ? 0 : -1) : (row == 2 ? 0 : -1);
-                const int ld_chunk = NPART == 2 ? (row == 1 ? chunk + 2 : chunk + 1) : chunk + 2;
-                constexpr bool MIDLOAD = !GEN;          // issue the loads inside the stage, behind the conversion
+                // Halo schedule of a chunk (one register set hr; a part is loaded >= one whole stage before it is converted):
+                //   vector path, parts A, B:  row 0: tap 1 converts A(c+1), tap 2 loads B(c+1);  row 1: tap 2 converts B(c+1);
+                //                             row 2: tap 0 loads A(c+2)
+                //   per-pixel path, one part: row 1: tap 1 converts (c+1);  row 2: loads (c+2) at the end of the stage
+                const int cv1 = NPART == 2 ? (row == 0 ? 0 : -1) : (row == 1 ? 0 : -1);    // part converted under tap 1
+                const int cv2 = (NPART == 2 && row == 1) ? 1 : -1;                         // part converted under tap 2
+                const int ld0 = (NPART == 2 && row == 2) ? 0 : -1;                         // part loaded under tap 0
+                const int ld2 = (NPART == 2 && row == 0) ? 1 : -1;                         // part loaded under tap 2
+                const int lde = (NPART == 1 && row == 2) ? 0 : -1;                         // part loaded at the stage end
                 constexpr int NLD = KP + (NEEDP ? 2 * KP + 1 : (MODE != CM_NONE ? 2 : 0));
                 {
                     int c2, r2;
@@ -653,14 +657,14 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_frag(fb, row, 1);
                 __builtin_amdgcn_sched_barrier(0);
+                if (ld0 >= 0) prefetch_h(cclamp(chunk + 2), ld0);
                 mma_frag_tail(fa);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_frag_head(fb);
                 __builtin_amdgcn_sched_barrier(0);
                 load_frag(fa, row, 2);
                 __builtin_amdgcn_sched_barrier(0);
-                // halo conversion of the next chunk under the remaining MFMAs of tap 1 ...
-                if (st_part >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), st_part); }
+                if (cv1 >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), cv1); }
                 mma_frag_tail(fb);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_frag_head(fa);
@@ -670,17 +674,18 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 if (row + 1 < NROW) { Hs = Hcur; load_frag(fb, row + 1, 0); }
                 else { Hs = Hnxt; load_frag(fb, 0, 0); }
                 __builtin_amdgcn_sched_barrier(0);
-                // ... and the re-load of the converted registers under those of tap 2, in a region of its own: the loads
-                // then land directly in the registers the conversion has finished reading (no copies behind a vmcnt wait)
-                if (MIDLOAD && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+                // conversion and re-load never share a scheduling region: the loads then land directly in the registers
+                // the conversion has finished reading (no copies behind a vmcnt wait)
+                if (cv2 >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), cv2); }
+                if (ld2 >= 0) prefetch_h(cclamp(chunk + 1), ld2);
                 mma_frag_tail(fa);
                 __builtin_amdgcn_sched_barrier(0);
-                // the LDS-DMA of this stage (older than the part loads just issued) must have landed before the barrier
-                if (MIDLOAD && ld_part >= 0) {
+                // the LDS-DMA of this stage (older than the part loads issued in it) must have landed before the barrier
+                if (ld0 >= 0 || ld2 >= 0) {
                     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (!MIDLOAD && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+                    if (lde >= 0) prefetch_h(cclamp(chunk + 2), lde);
                 }
                 stage_end();
             }
