@@ -37,15 +37,9 @@ __device__ __forceinline__ float wmax(float v) {
     return v;
 }
 
-// LDS layout (floats).  Ys rows are padded to T + 16 (k rows 0,1 of a ds_read_b32 half-wave land in disjoint bank
-// halves), the [16][T] score tiles and the Z chunk to T + 2 (16 rows x 2 k-columns hit 32 distinct banks).
-struct Lds {
-    float* xs;     // [KC][16]
-    float* ys;     // [KC][T + 16]   (phase 1)  /  zs [CG][T + 2]  (phase 3) share this region
-    float* ps;     // [16][T + 2]    P rows (tangent / cotangent) or the forward probabilities
-    float* ds;     // [16][T + 2]    score tile -> dP / g_S
-};
-
+// LDS layout (floats): xs [KC][16] | big: phase 1 ys [KC][T + 16], phase 3 zs [CG][T + 2] | ps [16][T + 2] | ds [16][T + 2].
+// Ys rows are padded to T + 16 (k rows 0,1 of a ds_read_b32 half-wave land in disjoint bank halves), the score tiles and
+// the Z chunk to T + 2 (16 rows x 2 k-columns hit 32 distinct banks).
 template <int FORM>   // 0 forward, 1 tangent, 2 cotangent (row-block part)
 __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -243,32 +237,39 @@ size_t rows_lds(int T) {
     return (size_t)(KC * 16 + bigsz + 2 * ROWS * SP) * sizeof(float);
 }
 
-template <typename K>
-void set_lds(K kern, size_t lds) {
-    static size_t granted = 0;
-    if (lds > 64 * 1024 && lds > granted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        granted = 160 * 1024;
+template <int FORM>
+void launch_rows(const AttnArgs& a, hipStream_t st) {
+    static bool big_lds = false;
+    const size_t lds = rows_lds(a.T);
+    if (lds > 64 * 1024 && !big_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_rows_kernel<FORM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds = true;
     }
+    hipLaunchKernelGGL(attn_rows_kernel<FORM>, dim3(a.T / ROWS, a.NH, a.B), dim3(256), lds, st, a);
 }
 
 }  // namespace
 
-bool attn_supported(int T, int CH) { return T % 64 == 0 && T <= 256 && CH % 16 == 0; }
+// TODO(perf): measured 41 ms/step SLOWER than the five-GEMM path (latency-bound inner loops); routed off until the
+// contiguous-k / ds_read_b128 rewrite lands
+bool attn_supported(int T, int CH) { (void)T; (void)CH; return false; }
 
 void launch_attn_rows(int form, const AttnArgs& a, hipStream_t st) {
-    dim3 grid(a.T / ROWS, a.NH, a.B);
-    const size_t lds = rows_lds(a.T);
-    if (form == 0) { set_lds(attn_rows_kernel<0>, lds); hipLaunchKernelGGL(attn_rows_kernel<0>, grid, dim3(256), lds, st, a); }
-    else if (form == 1) { set_lds(attn_rows_kernel<1>, lds); hipLaunchKernelGGL(attn_rows_kernel<1>, grid, dim3(256), lds, st, a); }
-    else { set_lds(attn_rows_kernel<2>, lds); hipLaunchKernelGGL(attn_rows_kernel<2>, grid, dim3(256), lds, st, a); }
+    if (form == 0) launch_rows<0>(a, st);
+    else if (form == 1) launch_rows<1>(a, st);
+    else launch_rows<2>(a, st);
 }
 
 void launch_attn_cols(const AttnArgs& a, hipStream_t st) {
-    dim3 grid(a.T / ROWS, a.NH, a.B);
+    static bool big_lds = false;
     const size_t lds = (size_t)(a.T * 17 + CG * (a.T + 2)) * sizeof(float);
-    set_lds(attn_cols_kernel, lds);
-    hipLaunchKernelGGL(attn_cols_kernel, grid, dim3(256), lds, st, a);
+    if (lds > 64 * 1024 && !big_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        big_lds = true;
+    }
+    hipLaunchKernelGGL(attn_cols_kernel, dim3(a.T / ROWS, a.NH, a.B), dim3(256), lds, st, a);
 }
 
 }  // namespace loco

@@ -322,12 +322,15 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
     // constants of channel kk of the part: tangent / cotangent modes load interleaved {a, b} pairs; the forward modes load
     // the a's (scale) and the b's (shift) as two runs -- KP == 2: one vector {a0,a1,b0,b1}; KP == 4: {a0..a3}, {b0..b3}
     auto cq_a = [&](const HaloRegs& R, int kk) -> float {
-        if constexpr (NEEDP) return KP == 4 ? R.cq[kk >> 1][(kk & 1) * 2] : R.cq[0][kk * 2];
-        else return KP == 4 ? R.cq[0][kk] : R.cq[0][kk];
+        if constexpr (GEN || MODE == CM_NONE) return 0.f;
+        else if constexpr (NEEDP) { if constexpr (KP == 4) return R.cq[kk >> 1][(kk & 1) * 2]; else return R.cq[0][kk * 2]; }
+        else return R.cq[0][kk];
     };
     auto cq_b = [&](const HaloRegs& R, int kk) -> float {
-        if constexpr (NEEDP) return KP == 4 ? R.cq[kk >> 1][(kk & 1) * 2 + 1] : R.cq[0][kk * 2 + 1];
-        else return KP == 4 ? R.cq[1][kk] : R.cq[0][2 + kk];
+        if constexpr (GEN || MODE == CM_NONE) return 0.f;
+        else if constexpr (NEEDP) { if constexpr (KP == 4) return R.cq[kk >> 1][(kk & 1) * 2 + 1]; else return R.cq[0][kk * 2 + 1]; }
+        else if constexpr (KP == 4) return R.cq[1][kk];
+        else return R.cq[0][2 + kk];
     };
     HaloRegs hr;                                      // the part in flight inside the stage loop
     auto prefetch_hv = [&](HaloRegs& R, int chunk, int part) {
