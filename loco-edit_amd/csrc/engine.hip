@@ -960,17 +960,6 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 // per head h: q = qkv[h*3*CH ...], k = +CH, v = +2CH channels (QKVAttentionLegacy, unet.py:346;
                 // with one head this is the [q|k|v] stacking of the fused DDPM projection)
                 float* q = p.T(op.qkv); float* k = q + (long)CH * T; float* v = k + (long)CH * T;
-                if (attn_supported(T, CH)) {
-                    // fused QK^T -> softmax -> PV, score tile in LDS; P is stored for the Jacobian passes
-                    AttnArgs aa; std::memset(&aa, 0, sizeof(aa));
-                    const long HS = 3L * CH * T;
-                    aa.X1 = q; aa.x1_bs = p.bs(); aa.x1_hs = HS; aa.Y1 = k; aa.y1_bs = p.bs(); aa.y1_hs = HS;
-                    aa.Sout = p.T(op.S); aa.s_bs = p.bs(); aa.s_hs = (long)T * T;
-                    aa.Z1 = v; aa.z1_bs = p.bs(); aa.z1_hs = HS;
-                    aa.O = p.T(op.o); aa.o_bs = p.bs(); aa.o_hs = (long)CH * T;
-                    aa.CH = CH; aa.T = T; aa.B = B; aa.NH = NH; aa.scale = 1.0f / std::sqrt((float)CH);
-                    launch_attn_rows(0, aa, st);
-                } else {
                 GemmArgs g; std::memset(&g, 0, sizeof(g));
                 g.A = q; g.sam = 1; g.sak = T; g.sab = p.bs(); g.sah = 3L * CH * T;
                 g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = p.bs(); g.sbh = 3L * CH * T;
@@ -984,7 +973,6 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 h.C = p.T(op.o); h.scm = T; h.scn = 1; h.scb = p.bs(); h.sch = (long)CH * T;
                 h.M = CH; h.N = T; h.K = T; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
                 launch_gemm(h, st);
-                }
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = p.T(op.o); pr.in_bs = p.bs(); pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, false); pr.bias = op.proj.bias; pr.pad = 0;
@@ -1117,17 +1105,6 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 const long HS = 3L * CH * T, SS = (long)T * T;
                 float* q = TP(op.qkv); float* k = q + (long)CH * T; float* v = k + (long)CH * T;
                 float* dq = TT(op.qkv); float* dk = dq + (long)CH * T; float* dv = dk + (long)CH * T;
-                if (attn_supported(T, CH)) {
-                    // fused dS = dq^T k + q^T dk -> softmax Jacobian -> do = dv P^T + v dP^T (dS, dP stay in LDS)
-                    AttnArgs aa; std::memset(&aa, 0, sizeof(aa));
-                    aa.X1 = dq; aa.x1_bs = PS; aa.x1_hs = HS; aa.Y1 = k; aa.y1_bs = 0; aa.y1_hs = HS;
-                    aa.X2 = q; aa.x2_bs = 0; aa.x2_hs = HS; aa.Y2 = dk; aa.y2_bs = PS; aa.y2_hs = HS;
-                    aa.P = TP(op.S); aa.p_bs = 0; aa.p_hs = SS;
-                    aa.Z1 = dv; aa.z1_bs = PS; aa.z1_hs = HS; aa.Z2 = v; aa.z2_bs = 0; aa.z2_hs = HS;
-                    aa.O = TT(op.o); aa.o_bs = PS; aa.o_hs = (long)CH * T;
-                    aa.CH = CH; aa.T = T; aa.B = B; aa.NH = NH; aa.scale = 1.0f / std::sqrt((float)CH);
-                    launch_attn_rows(1, aa, st);
-                } else {
                 GemmArgs g; std::memset(&g, 0, sizeof(g));
                 g.A = dq; g.sam = 1; g.sak = T; g.sab = PS; g.sah = HS;
                 g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = HS;
@@ -1145,7 +1122,6 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 launch_gemm(h, st);
                 h.A = v; h.sab = 0; h.Bm = TT(op.S); h.sbb = PS; h.beta = 1.f;
                 launch_gemm(h, st);
-                }
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = TT(op.o); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, false); pr.pad = 0; pr.res = TT(op.in); pr.res_bs = PS;
@@ -1303,23 +1279,6 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 setw(pr, op.proj, true); pr.pad = 0;
                 pr.out = TG(op.o); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
                 run_conv(c, pr, 1, st);
-                if (attn_supported(T, CH)) {
-                    // rows: g_P = g_o^T v -> g_S (stored) -> g_q = k g_S^T;  columns: g_k = q g_S, g_v = g_o P
-                    AttnArgs aa; std::memset(&aa, 0, sizeof(aa));
-                    aa.X1 = TG(op.o); aa.x1_bs = PS; aa.x1_hs = OS; aa.Y1 = v; aa.y1_bs = 0; aa.y1_hs = HS;
-                    aa.P = TP(op.S); aa.p_bs = 0; aa.p_hs = SS;
-                    aa.Sout = TG(op.S); aa.s_bs = PS; aa.s_hs = SS;
-                    aa.Z1 = k; aa.z1_bs = 0; aa.z1_hs = HS;
-                    aa.O = gq; aa.o_bs = PS; aa.o_hs = HS;
-                    aa.CH = CH; aa.T = T; aa.B = B; aa.NH = NH; aa.scale = 1.0f / std::sqrt((float)CH);
-                    launch_attn_rows(2, aa, st);
-                    AttnArgs ab = aa;
-                    ab.X1 = q; ab.x1_bs = 0; ab.x1_hs = HS;                 // with g_S -> g_k
-                    ab.X2 = TG(op.o); ab.x2_bs = PS; ab.x2_hs = OS;         // with P   -> g_v
-                    ab.O = gk; ab.o_bs = PS; ab.o_hs = HS;
-                    ab.O2 = gv; ab.o2_bs = PS; ab.o2_hs = HS;
-                    launch_attn_cols(ab, st);
-                } else {
                 // g_v[c][j] = sum_i g_o[c][i] P[i][j]
                 GemmArgs g; std::memset(&g, 0, sizeof(g));
                 g.A = TG(op.o); g.sam = T; g.sak = 1; g.sab = PS; g.sah = OS;
@@ -1346,7 +1305,6 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 GemmArgs gk_ = gq_;
                 gk_.A = q; gk_.Bm = TG(op.S); gk_.sbk = T; gk_.sbn = 1; gk_.C = gk;
                 launch_gemm(gk_, st);
-                }
                 // g_hn = Wqkv^T g_qkv
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.qkv); a.in_bs = PS; a.Cin = 3 * C; a.Hin = to.H; a.Win = to.W;

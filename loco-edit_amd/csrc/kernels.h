@@ -86,27 +86,6 @@ struct GemmArgs {
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);
 
-// ---- fused attention (attention.hip) ----------------------------------------
-// All operands are [CH][T] channel-major slices of the q/k/v (or o) tensors of one (sample, head), addressed by a
-// batch stride (0 = the primal broadcast over probes) and a head stride; P / Sout are [T][T] per (sample, head).
-struct AttnArgs {
-    const float *X1, *Y1, *X2, *Y2;      // S-type products: S[i][j] = sum_c X1[c][i] Y1[c][j] (+ X2, Y2: tangent)
-    long x1_bs, x1_hs, y1_bs, y1_hs, x2_bs, x2_hs, y2_bs, y2_hs;
-    const float* P; long p_bs, p_hs;     // primal softmax (read by the tangent / cotangent forms)
-    float* Sout; long s_bs, s_hs;        // forward: P written here; cotangent: g_S written (rows) / read (cols)
-    const float *Z1, *Z2;                // O-type products: O[c][i] = sum_j Z1[c][j] W1[i][j] (+ Z2 W2)
-    long z1_bs, z1_hs, z2_bs, z2_hs;
-    float* O; long o_bs, o_hs;
-    float* O2; long o2_bs, o2_hs;        // column-block kernel: second output (g_v)
-    int CH, T, B, NH;
-    float scale;
-};
-bool attn_supported(int T, int CH);
-// form 0: forward (S, softmax, o);  1: tangent (dS, dP, do);  2: cotangent row blocks (g_P, g_S, g_q)
-void launch_attn_rows(int form, const AttnArgs& a, hipStream_t st);
-// cotangent column blocks: O = g_k = X1 g_S,  O2 = g_v = X2 P   (g_S = Sout of the row-block launch)
-void launch_attn_cols(const AttnArgs& a, hipStream_t st);
-
 // ---- GroupNorm statistics -------------------------------------------------
 // x: [B][C][HW] with batch stride bs; groups of cpg channels (contiguous cpg*HW floats)
 // writes mr[b][g] = {mean, rstd}, sc[b][c] = gamma*rstd, sh[b][c] = beta - mean*rstd*gamma
