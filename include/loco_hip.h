@@ -151,6 +151,21 @@ int  loco_timer_stop(loco_ctx* ctx, void* stream, float* ms);
 int  loco_set_precision(loco_ctx* ctx, int32_t mode);
 int  loco_get_precision(loco_ctx* ctx);
 
+/* Conditional denoisers (T-LOCO, reference edit.py:1286-1373 `self.unet(x, t, encoder_hidden_states=...)`): a
+ * conditioning embedding of temb_ch = 4*ch floats (device pointer) that is added to the time embedding before its
+ * SiLU -- the slot guided-diffusion uses for `label_emb(y)` (unet.py:660-662) and diffusers' UNet2DConditionModel for
+ * `addition_embed_type="text"`.  NULL clears it.  Invalidates the cached primal. */
+int  loco_set_cond(loco_ctx* ctx, const float* emb_add, void* stream);
+/* out[k, n] = mask * (cv * V + ce * E) with the mask of the last loco_pmp_primal (all ones without one): the
+ * x0_hat = (x - eps sqrt(1-at)) / sqrt(at) algebra of edit.py:1574 / 2385 applied to tangents or cotangents when eps is a
+ * CFG combination assembled by the caller.  V, E: [k, n]; out may alias either. */
+int  loco_masked_axpby(loco_ctx* ctx, const float* V, const float* E, float cv, float ce, int32_t k, float* out,
+                       void* stream);
+/* out = sum_{i<n} coef[i] * src[i], n <= 4: the classifier-free-guidance combination of eps / J V / J^T U terms of
+ * several conditions (edit.py:1324-1372).  src: host array of device pointers, coef: host array; out may alias a src. */
+int  loco_lincomb(loco_ctx* ctx, const float* const* src, const float* coef, int32_t n, float* out, int64_t count,
+                  void* stream);
+
 /* Tuning hook: average ms of one convolution shape (random scratch data) over `iters` launches.
  * mode: 0 raw, 1 GN+SiLU, 2 GN, 3 tangent, 4 cotangent; tile: -1 auto or a variant id. */
 int  loco_bench_conv(loco_ctx* ctx, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t B, int32_t mode,

@@ -55,6 +55,11 @@ MID_DDPM = UNetConfig(resolution=64, ch=32, ch_mult=(1, 1, 2), num_res_blocks=1,
 # config 2 of BASELINE.json: FFHQ-P2 (script_util.py:166-190 P2_DICT + create_model :379-435)
 FFHQ_P2 = UNetConfig(resolution=256, ch=128, ch_mult=(1, 1, 2, 2, 4, 4), num_res_blocks=1, attn_resolutions=(16,),
                      gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=True)
+# BASELINE config 5 stand-in: pixel-space 64x64 conditional denoiser in the shape class of DeepFloyd IF-I (4 levels, 3
+# ResBlocks per level, attention at 32/16/8, 64-channel heads, learned variance); the real IF U-Net is diffusers'
+# UNet2DConditionModel with T5 cross-attention (un-vendored) -- here the text enters through the time embedding only
+IF64_STANDIN = UNetConfig(resolution=64, ch=192, ch_mult=(1, 2, 3, 4), num_res_blocks=3, attn_resolutions=(32, 16, 8),
+                          gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=True)
 TINY_ADM = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,),
                       gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True)
 

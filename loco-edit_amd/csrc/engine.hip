@@ -109,6 +109,8 @@ struct loco_ctx {
     float* tmpA = nullptr;         // [64][n] temp for solver rotations
     double *G = nullptr, *Q = nullptr, *W = nullptr, *gscratch = nullptr;
     float* alphas = nullptr;
+    float* cond_add = nullptr;     // [temb_ch] conditioning embedding of the time embedding (loco_set_cond)
+    bool has_cond = false;
     float2* sxcache = nullptr;     // primal {S, xhat} per GroupNorm+SiLU input (bf16x3 path)
     long sx_total = 0;
     int prec = 0;                  // 0: exact fp32 MFMA, 1: split-bf16 (bf16x3) MFMA, 2: single f16 MFMA
@@ -882,7 +884,8 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
     const loco_unet_cfg& cfg = c->cfg;
     Pass p{c, st, B, arena, stats};
     const long SB = c->stats_per_sample;
-    launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st, cfg.arch == 1);
+    launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st, cfg.arch == 1,
+                c->has_cond ? c->cond_add : nullptr);
     launch_temb_proj(c->tact, cfg.ch * 4, c->tp_w, c->tp_b, (int)c->tproj_total, c->tproj, st);
     for (auto& op : c->ops) {
         const Tens& to = c->tens[op.out];
@@ -1388,7 +1391,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         size_t nblk = ((size_t)c->n_in + 255) / 256;
         if (dalloc(c, &c->gscratch, nblk * 64 * 64 + 4096)) return -1;
     }
-    if (dalloc(c, &c->alphas, 256)) return -1;
+    if (dalloc(c, &c->alphas, 256) || dalloc(c, &c->cond_add, (size_t)cfg->ch * 4)) return -1;
     {
         float2* sx0 = nullptr;
         if (dalloc(c, &sx0, (size_t)c->sx_total + 64)) return -1;
@@ -1685,6 +1688,34 @@ int loco_set_precision(loco_ctx* c, int32_t mode) {
     return 0;
 }
 int loco_get_precision(loco_ctx* c) { return c ? c->prec : -2; }
+
+int loco_set_cond(loco_ctx* c, const float* emb_add, void* stream) {
+    if (!c) return -2;
+    c->primal_ok = false;           // cached activations belong to the previous condition
+    if (!emb_add) { c->has_cond = false; return 0; }
+    HIPCHK(c, hipMemcpyAsync(c->cond_add, emb_add, (size_t)c->cfg.ch * 4 * sizeof(float), hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+    c->has_cond = true;
+    return 0;
+}
+
+int loco_masked_axpby(loco_ctx* c, const float* V, const float* E, float cv, float ce, int32_t k, float* out,
+                      void* stream) {
+    if (!c) return -2;
+    if (!c->primal_ok) { c->err = "loco_pmp_primal has not been called"; return -2; }
+    launch_masked_axpby(V, E, c->has_mask ? c->mask : nullptr, cv, ce, out, k, c->n_in, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_lincomb(loco_ctx* c, const float* const* src, const float* coef, int32_t n, float* out, int64_t count,
+                 void* stream) {
+    if (!c) return -2;
+    if (n < 1 || n > 4) { c->err = "lincomb: 1..4 terms"; return -2; }
+    launch_lincomb(src, coef, n, out, (long)count, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
 
 // Tuning hook: time one convolution shape on scratch data (random inputs), avg ms over `iters` launches.
 int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t B, int32_t mode,

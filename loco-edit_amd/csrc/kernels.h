@@ -123,7 +123,8 @@ void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows
 // ---- small ops ---------------------------------------------------------------
 // temb pipeline: sinusoid(t) -> dense0 -> swish -> dense1 -> swish -> all per-block projections
 void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
-                 const float* w1, const float* b1, float* scratch, hipStream_t st, int cos_first = 0);
+                 const float* w1, const float* b1, float* scratch, hipStream_t st, int cos_first = 0,
+                 const float* add = nullptr);    // add[temb_ch]: conditioning embedding added to emb before the SiLU
 void launch_temb_proj(const float* tact, int temb_ch, const float* w, const float* b, int cout,
                       float* out, hipStream_t st);
 // out[b][c][y][x] = sum of the 2x2 block of in[b][c][2y..][2x..]   (adjoint of nearest x2)
@@ -146,6 +147,8 @@ void launch_masked_axpby(const float* V, const float* dE, const uint8_t* mask, f
 void launch_cot_seed(const float* U, const uint8_t* mask, float cv, float ce, float* gE, float* gX0,
                      int k, long n, hipStream_t st);
 void launch_add(const float* a, const float* b, float* out, long count, hipStream_t st);
+// out = sum_{i<n} coef[i] * src[i]   (n <= 4, 16-byte aligned tensors of `count` floats; CFG combination of Jacobian products)
+void launch_lincomb(const float* const* src, const float* coef, int n, float* out, long count, hipStream_t st);
 
 // ---- solver --------------------------------------------------------------------
 // G[k][k] (double) = A A^T, A: [k][n] fp32

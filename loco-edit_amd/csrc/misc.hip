@@ -408,7 +408,7 @@ void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows
 // time embedding: [sin, cos] sinusoid (divisor half-1) -> dense0 -> swish -> dense1 -> swish
 // (reference diffusion.py:783-804, 154-157, and the nonlinearity(temb) of :899)
 __global__ void temb_kernel(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
-                            const float* w1, const float* b1, float* out, int cos_first) {
+                            const float* w1, const float* b1, float* out, int cos_first, const float* add) {
     extern __shared__ float sm[];
     float* emb = sm;           // [ch]
     float* h = sm + ch;        // [temb_ch]
@@ -430,13 +430,14 @@ __global__ void temb_kernel(float t, int ch, int temb_ch, const float* freq, con
     for (int o = threadIdx.x; o < temb_ch; o += blockDim.x) {
         float acc = b1[o];
         for (int i = 0; i < temb_ch; ++i) acc = fmaf(w1[(long)o * temb_ch + i], h[i], acc);
+        if (add) acc += add[o];          // conditioning embedding (class / pooled text), added to emb before the SiLU
         out[o] = acc * sigm(acc);
     }
 }
 void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0, const float* w1,
-                 const float* b1, float* scratch, hipStream_t st, int cos_first) {
+                 const float* b1, float* scratch, hipStream_t st, int cos_first, const float* add) {
     hipLaunchKernelGGL(temb_kernel, dim3(1), dim3(512), (ch + temb_ch) * sizeof(float), st, t, ch, temb_ch, freq,
-                       w0, b0, w1, b1, scratch, cos_first);
+                       w0, b0, w1, b1, scratch, cos_first, add);
 }
 // out[o] = b[o] + sum_i w[o][i]*tact[i]; one wave per output row
 __global__ __launch_bounds__(256) void temb_proj_kernel(const float* tact, int temb_ch, const float* w,
@@ -593,6 +594,37 @@ __global__ void fill_random_kernel(float* p, long count, unsigned seed, float sc
 }
 void launch_fill_random(float* p, long count, unsigned seed, float scale, hipStream_t st) {
     hipLaunchKernelGGL(fill_random_kernel, dim3(2048), dim3(256), 0, st, p, count, seed, scale);
+}
+
+// out = sum_i coef[i] * src[i] (n <= 4 terms; src[i] may alias out)
+struct LinComb { const float* src[4]; float coef[4]; int n; };
+__global__ void lincomb_kernel(LinComb lc, float* out, long count) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < count; i += (long)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= count) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < lc.n; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(lc.src[k] + i);
+                acc.x = fmaf(lc.coef[k], v.x, acc.x); acc.y = fmaf(lc.coef[k], v.y, acc.y);
+                acc.z = fmaf(lc.coef[k], v.z, acc.z); acc.w = fmaf(lc.coef[k], v.w, acc.w);
+            }
+            *reinterpret_cast<float4*>(out + i) = acc;
+        } else {
+            for (long j = i; j < count; ++j) {
+                float acc = 0.f;
+                for (int k = 0; k < lc.n; ++k) acc = fmaf(lc.coef[k], lc.src[k][j], acc);
+                out[j] = acc;
+            }
+        }
+    }
+}
+void launch_lincomb(const float* const* src, const float* coef, int n, float* out, long count, hipStream_t st) {
+    LinComb lc;
+    lc.n = n;
+    for (int k = 0; k < 4; ++k) { lc.src[k] = k < n ? src[k] : nullptr; lc.coef[k] = k < n ? coef[k] : 0.f; }
+    long blocks = (count / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)blocks), dim3(256), 0, st, lc, out, count);
 }
 
 __global__ void add_kernel(const float* a, const float* b, float* out, long count) {

@@ -75,7 +75,7 @@ _FLAGS = [
     ('edit_t_idx', _I, 1), ('num_inference_steps', _I, 3), ('random_edit', 'bool', 'False'),
 ]
 _UNET_PRESETS = {'celeba_ddpm': 'CELEBA_DDPM', 'ffhq_p2': 'FFHQ_P2', 'tiny_ddpm': 'TINY_DDPM', 'mid_ddpm': 'MID_DDPM',
-                 'tiny_adm': 'TINY_ADM'}
+                 'tiny_adm': 'TINY_ADM', 'if64_standin': 'IF64_STANDIN'}
 _TILDA_V = ["proj_null[for-null](edit-null)-direct", "(for-edit)-direct", "(edit-null)-direct",
             "null+(for-null)+(edit-null)", "null+(for-null)", "null+(edit-null)", "(for-edit)",
             "edit-proj[for](edit)", "null+for+edit-proj[for](edit)"]
@@ -94,6 +94,9 @@ def build_parser():
     p.add_argument('--max_batch', type=int, default=8, help='largest image/probe batch resident on the GPU')
     p.add_argument('--unet_preset', type=str, default=None, choices=sorted(_UNET_PRESETS),
                    help='override the architecture --model_name implies (small parity-test sizes)')
+    p.add_argument('--prompt_emb_path', type=str, default='',
+                   help="T-LOCO: torch file {'for','edit','null': [1, tokens, D]} of prompt embeddings (the text encoder is out of scope)")
+    p.add_argument('--cond_dim', type=int, default=16, help='T-LOCO stand-in: width of seeded prompt embeddings when no file is given')
     p.add_argument('--precision', type=str, default=None, choices=['f32', 'bf16x3', 'f16'],
                    help="conv arithmetic of the HIP engine: 'f32' exact fp32 MFMA (parity anchor), 'bf16x3' split-bf16 "
                         "(fp32-faithful to ~2^-16, default), 'f16' single f16 MFMA with fp32 accumulate (2^-11 operands)")
@@ -117,9 +120,13 @@ def preset(args):
     if args.seed == 0:
         args.seed = int(torch.randint(2**32, ()))
     seed_everything(args.seed)
-    if any(s in args.model_name for s in ('stable-diffusion', 'DeepFloyd', 'LCM')):
-        raise NotImplementedError('text-to-image T-LOCO (SD / DeepFloyd-IF / LCM) is outside this build (SURVEY.md 8f.2)')
-    args.is_stable_diffusion = args.is_DeepFloyd_IF_diffusion = args.is_LCM = False
+    if any(s in args.model_name for s in ('stable-diffusion', 'LCM')):
+        raise NotImplementedError('latent-space T-LOCO (Stable Diffusion / LCM: VAE-decoder Jacobian) is outside this build '
+                                  '(SURVEY.md 8f.2); the pixel-space DeepFloyd-IF path is loco_edit_amd.tloco')
+    args.is_stable_diffusion = args.is_LCM = False
+    args.is_DeepFloyd_IF_diffusion = 'DeepFloyd' in args.model_name
+    if args.is_DeepFloyd_IF_diffusion:
+        return _preset_deepfloyd(args)
     # model-name gate of define_argparser.py:166-176 (`unet_config` = an explicit architecture, tests / tiny configs)
     if getattr(args, 'unet_config', None) is None:
         if args.model_name == 'CelebA_HQ':
@@ -150,6 +157,32 @@ def preset(args):
     assert args.use_yh_custom_scheduler
     assert args.for_steps == 100
     assert args.performance_boosting_t == 0.2
+    return args
+
+
+def _preset_deepfloyd(args):
+    """define_argparser.py:155-160, 219-223, 236-239 for the DeepFloyd-IF (pixel-space T-LOCO) branch."""
+    args.exp = f'DeepFloyd-IF-{args.dataset_name}-{args.note}'
+    args.exp_folder = os.path.join(args.result_folder, args.exp)
+    os.makedirs(args.exp_folder, exist_ok=True)
+    sh = os.path.join('scripts', args.sh_file_name)
+    if args.sh_file_name and os.path.exists(sh):
+        shutil.copy(sh, os.path.join(args.exp_folder, args.sh_file_name))
+    args.obs_folder = os.path.join(args.exp_folder, 'obs')
+    args.result_folder = os.path.join(args.exp_folder, 'results')
+    os.makedirs(args.obs_folder, exist_ok=True)
+    os.makedirs(args.result_folder, exist_ok=True)
+    args.device = torch.device(args.device)
+    args.dtype = torch.float32 if args.dtype == 'fp32' else torch.float16
+    print(f'device : {args.device}, dtype : {args.dtype}')
+    if getattr(args, 'unet_config', None) is None:
+        from .config import IF64_STANDIN
+        args.unet_config = IF64_STANDIN
+    args.c_in = 3
+    args.image_size = args.unet_config.resolution          # 64 for the IF stage-I models
+    args.memory_bound = 5
+    assert args.use_yh_custom_scheduler
+    assert args.performance_boosting_t <= 0
     return args
 
 

@@ -27,7 +27,7 @@ SYMBOLS = [
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop", "loco_debug_tensor",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision",
-    "loco_bench_conv",
+    "loco_bench_conv", "loco_set_cond", "loco_lincomb", "loco_masked_axpby",
 ]
 
 
@@ -88,6 +88,9 @@ def load_library():
     lib.loco_set_precision.argtypes = [vp, i32]
     lib.loco_get_precision.argtypes = [vp]
     lib.loco_bench_conv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32), vp]
+    lib.loco_set_cond.argtypes = [vp, vp, vp]
+    lib.loco_masked_axpby.argtypes = [vp, vp, vp, f32, f32, i32, vp, vp]
+    lib.loco_lincomb.argtypes = [vp, C.POINTER(vp), C.POINTER(f32), i32, vp, i64, vp]
     lib.loco_profile_enable.argtypes = [vp, i32]
     lib.loco_profile_report.argtypes = [vp, C.c_char_p, i64]
     lib.loco_debug_tensor.argtypes = [vp, C.c_char_p, vp, i64, vp]
@@ -278,6 +281,35 @@ class LocoEngine:
     def mask_count(self) -> int:
         """L = number of selected elements of the mask given to the last ``pmp_primal`` (n when unmasked)."""
         return int(self.lib.loco_mask_count(self._ctx))
+
+    # ---- conditioning / CFG combination (T-LOCO)
+    def set_cond(self, emb_add: Optional[torch.Tensor]):
+        """Conditioning embedding [4*ch] added to the time embedding before its SiLU (None clears it)."""
+        if emb_add is not None:
+            _chk_dev(emb_add)
+            if emb_add.numel() != 4 * self.cfg.ch:
+                raise ValueError("conditioning embedding must have 4*ch elements")
+        self._check(self.lib.loco_set_cond(self._ctx, _ptr(emb_add), _stream()), "loco_set_cond")
+
+    def masked_axpby(self, V: torch.Tensor, E: torch.Tensor, cv: float, ce: float) -> torch.Tensor:
+        """mask * (cv*V + ce*E) with the mask of the last pmp_primal; V, E: [k, n]."""
+        _chk_dev(V)
+        _chk_dev(E)
+        out = torch.empty_like(V)
+        self._check(self.lib.loco_masked_axpby(self._ctx, _ptr(V), _ptr(E), float(cv), float(ce), V.shape[0], _ptr(out),
+                                               _stream()), "loco_masked_axpby")
+        return out
+
+    def lincomb(self, terms, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """sum_i coef_i * tensor_i for [(coef, tensor), ...] (<= 4 terms, same shape, fp32, contiguous)."""
+        for _, t in terms:
+            _chk_dev(t)
+        out = torch.empty_like(terms[0][1]) if out is None else out
+        n = len(terms)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, t in terms])
+        coef = (C.c_float * n)(*[float(c) for c, _ in terms])
+        self._check(self.lib.loco_lincomb(self._ctx, ptrs, coef, n, _ptr(out), out.numel(), _stream()), "loco_lincomb")
+        return out
 
     # ---- introspection
     def version(self) -> str:

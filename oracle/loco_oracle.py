@@ -179,8 +179,11 @@ def _adm_attn(p, name, x, cfg):
     return (xr + h).reshape(b, c, hh, ww)
 
 
-def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None):
-    """UNetModel.forward returning the eps half -- unet.py:636-684, constructor :398-617."""
+def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Optional[torch.Tensor] = None,
+                     full: bool = False):
+    """UNetModel.forward returning the eps half -- unet.py:636-684, constructor :398-617.
+    ``emb_add`` [B, 4*ch] (or [4*ch]) is added to the time embedding where the class embedding goes
+    (``emb = emb + self.label_emb(y)``, unet.py:660-662); ``full`` keeps the learned-variance channels."""
     def rec(name, v):
         if trace is not None:
             trace[name] = v.detach().clone()
@@ -189,6 +192,8 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None):
     emb = timestep_embedding_adm(t.to(torch.float32), cfg.ch)
     emb = F.linear(emb, p["time_embed.0.weight"], p["time_embed.0.bias"])
     emb = F.linear(F.silu(emb), p["time_embed.2.weight"], p["time_embed.2.bias"])
+    if emb_add is not None:
+        emb = emb + emb_add
     hs = []
     h = rec("input_blocks.0.0", F.conv2d(x, p["input_blocks.0.0.weight"], p["input_blocks.0.0.bias"], padding=1))
     hs.append(h)
@@ -222,7 +227,7 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None):
             ob += 1
     h = F.silu(_adm_gn(p, "out.0", h, cfg))
     h = F.conv2d(h, p["out.2.weight"], p["out.2.bias"], padding=1)
-    if cfg.learn_sigma:
+    if cfg.learn_sigma and not full:
         h = torch.split(h, h.shape[1] // 2, dim=1)[0]      # et only (unet.py:680-684)
     return h
 

@@ -50,8 +50,11 @@ STAMPS = [
      "                STAMP(row * 5 + 3)\n                stage_end();\n                STAMP(row * 5 + 4)\n            }\n        };\n        for (int ci = 0; ci < nch; ci += 2) {"),
 ]
 
+NT = "__builtin_nontemporal_store(v, &ob[(long)co * out_plane + pix]);"
 VARIANTS = {
     "v8_stamps": STAMPS,
+    "v9_store_sc1": [(NT, "__hip_atomic_store(&ob[(long)co * out_plane + pix], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")],
+    "v9_store_plain": [(NT, "ob[(long)co * out_plane + pix] = v;")],
     "v0_base": [],
     "v1_noconv": [(CONV, ""), (CONV2, "")],
     "v2_nohalo": [(CONV, ""), (CONV2, ""), (LOAD, ""), (LOAD0, ""), (WAIT, '                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n')],

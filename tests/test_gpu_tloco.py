@@ -1,0 +1,165 @@
+"""MI355X: the pixel-space T-LOCO path (loco_edit_amd.tloco.EditDeepFloydIF on the HIP engine, one engine context per
+prompt, CFG-combined Jacobian) against the fixture produced by the reference's own EditDeepFloydIF methods on the same
+stand-in conditional denoiser (tests/golden/tloco_tiny.pt).  Tolerances: single evaluation rel-L2 <= 2e-5 (f32) /
+1e-4 (bf16x3); solver s rtol 1e-3, |cos(vT_i)| >= 0.999; directions |cos| >= 0.9999."""
+import os
+from argparse import Namespace
+
+import pytest
+import torch
+
+from loco_edit_amd.config import TINY_ADM
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {"f32": 2e-5, "bf16x3": 1e-4}
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def cosrow(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a * b).sum(dim=1) / (a.norm(dim=1) * b.norm(dim=1))).abs()
+
+
+def _edit(g, tmp_path, prec, **kw):
+    from loco_edit_amd.tloco import EditDeepFloydIF
+    os.environ.pop("WORLD_SIZE", None)
+    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=TINY_ADM, synthetic_weights=0, ckpt_path="",
+                     max_batch=8, precision=prec, dataset_name="Random", for_steps=100, use_yh_custom_scheduler=True,
+                     guidance_scale=g["guidance_scale"], guidance_scale_edit=g["guidance_scale_edit"],
+                     prompt_emb={"for": g["for_e"], "edit": g["edit_e"], "null": g["null_e"]}, for_prompt="a cat",
+                     edit_prompt="a dog", edit_t=0.6, sampling_mode=False, tilda_v_score_type=kw.get("tilda", "null+(for-null)+(edit-null)"),
+                     ablation_method=kw.get("ablation", "null-space-proj"), mask_type="SAM", vT_path=kw.get("vT_path", ""),
+                     x_space_guidance_edit_step=1.0, x_space_guidance_scale=0.5, x_space_guidance_num_step=16,
+                     result_folder=str(tmp_path))
+    return EditDeepFloydIF(args)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_tloco_pieces_vs_reference_golden(prec, golden, tmp_path):
+    g = golden("tloco_tiny")
+    ed = _edit(g, tmp_path, prec)
+    tol = TOL[prec]
+    x, t = g["x"].to(DEV), g["t"]
+    F, E, N = g["for_e"], g["edit_e"], g["null_e"]
+    assert ed.edit_t_idx == g["edit_t_idx"] and float(ed.scheduler.timesteps[ed.edit_t_idx]) == float(t)
+    xb = torch.cat([g["x"], g["x"].flip(-1)], dim=0).to(DEV)
+    # 1. CFG noise, every mode (edit.py:1286-1373)
+    for mode, ref in g["eps_modes"].items():
+        assert rel(ed._classifer_free_guidance(xb, t, F, E, N, mode, True), ref) < 4 * tol, mode
+    assert rel(ed._classifer_free_guidance(xb, t, F, E, N, "null+(for-null)", False), g["eps_nocfg"][:, :3]) < tol
+    # the conditioning does something: the three branches differ
+    ef, en = ed.branches["for"].unet_forward(x, float(t)), ed.branches["null"].unet_forward(x, float(t))
+    assert rel(ef, en) > 1e-2
+    # 2. get_x0 (edit.py:1566-1587)
+    assert rel(ed.get_x0(x, t, ed.edit_t_idx, F, E, N, mask=g["mask"]), g["x0_masked"]) < 4 * tol
+    # 3. CFG-combined subspace solver (edit.py:1589-1676), three modes / masks
+    for mode, sv in g["solver"].items():
+        m = None if sv["mask"] is None else sv["mask"]
+        u, s, vT = ed.local_encoder_decoder_pullback_xt(x, t, ed.edit_t_idx, F, E, N, pca_rank=3, min_iter=sv["n_iter"],
+                                                        max_iter=sv["n_iter"], mask=m, mode=mode, v0=g["v0"].to(DEV), verbose=False)
+        assert ed.last_n_iter == sv["n_iter"]
+        assert torch.allclose(s.cpu(), sv["s"], rtol=1e-3), (mode, s.cpu(), sv["s"])
+        assert cosrow(vT, sv["vT"]).min().item() > 0.999, mode
+        assert cosrow(u.T, sv["u"].T).min().item() > 0.999, mode
+    # 4. direction through the Jacobian (edit.py:1680-1717), 5. direct directions (:1720-1741)
+    vg = ed.get_delta_xt_via_grad(x, t, ed.edit_t_idx, F, E, N, mask=g["mask"], mode="null+(for-null)+(edit-null)")
+    assert cosrow(vg, g["v_grad"]).item() > 0.9999 and abs(float(vg.norm()) - 1.0) < 1e-4
+    sgn = torch.sign((vg.cpu() * g["v_grad"]).sum())
+    assert float(sgn) == 1.0                                            # a direction, not a line: the sign is part of the edit
+    for mode, ref in g["v_direct"].items():
+        vd = ed.get_v_modify(x, t, ed.edit_t_idx, F, E, N, mask=g["mask"], mode=mode, jacobian=False)
+        c = ((vd.cpu().double() * ref.double()).sum() / ref.double().norm()).item()
+        assert c > 0.9999, (mode, c)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_tloco_sampler_vs_reference_golden(prec, golden, tmp_path):
+    """DDPMforwardsteps (edit.py:1412-1481): x_T -> x_t at the edit step under 'null+(for-null)' guidance, then the
+    decode of a 2-image batch under 'null+(for-null)+(edit-null)' to the uint8 image tensor."""
+    g = golden("tloco_tiny")
+    ed = _edit(g, tmp_path, prec)
+    F, E, N = g["for_e"], g["edit_e"], g["null_e"]
+    xt, t, i = ed.DDPMforwardsteps(g["xT"].to(DEV), 0, ed.edit_t_idx, F, E, N, mode="null+(for-null)")
+    assert i == g["edit_t_idx"] and float(t) == float(g["t_edit"])
+    ref = g["xt_edit"]
+    mse = ((xt.cpu().double() - ref.double()) ** 2).mean().item()
+    peak = float(ref.max() - ref.min())
+    import math
+    assert 10 * math.log10(peak * peak / max(mse, 1e-30)) > (60 if prec == "f32" else 35)
+    ed.EXP_NAME = "dec"
+    img = ed.DDPMforwardsteps(g["dec_in"].to(DEV), ed.edit_t_idx, -1, F, E, N, mode="null+(for-null)+(edit-null)")
+    assert img.dtype == torch.uint8 and tuple(img.shape) == tuple(g["dec_u8"].shape) == (2, 32, 32, 3)
+    differ = (img.cpu().int() - g["dec_u8"].int()).abs()
+    assert float((differ > 1).float().mean()) < (0.002 if prec == "f32" else 0.05)
+    assert os.path.exists(os.path.join(ed.result_folder, "dec_stage1.png"))
+
+
+def test_cfg_operator_adjoint_and_linear(golden, tmp_path):
+    """<J V, U> == <V, J^T U> and linearity for the CFG-combined operator, mode '(for-edit)' (weights sum to 0:
+    the identity part of d x0_hat / d x_t must not be scaled by the guidance weights)."""
+    g = golden("tloco_tiny")
+    ed = _edit(g, tmp_path, "f32")
+    x, t = g["x"].to(DEV), g["t"]
+    op = ed._operator(x, t, g["mask"], "(for-edit)")
+    gen = torch.Generator().manual_seed(3)
+    V = torch.randn(2, TINY_ADM.n, generator=gen).to(DEV)
+    U = (torch.randn(2, TINY_ADM.n, generator=gen) * g["mask"].reshape(1, -1)).to(DEV)
+    JV, JtU = op.jvp(V), op.vjp(U)
+    lhs, rhs = (JV * U).sum(dim=1), (V * JtU).sum(dim=1)
+    assert ((lhs - rhs).abs() / (JV.norm(dim=1) * U.norm(dim=1))).max().item() < 1e-4
+    assert float(JV[:, ~g["mask"].reshape(-1).to(DEV)].abs().max()) == 0.0
+    comb = (2.0 * V[0] - 0.5 * V[1])[None].contiguous()
+    assert rel(op.jvp(comb)[0], 2.0 * JV[0] - 0.5 * JV[1]) < 1e-4
+    # finite-difference check of J V against get_x0 in the same mode
+    h = 1e-2
+    v = V[0].view(1, 3, 32, 32) / V[0].norm()
+    x0p = ed.get_x0(x + h * v, t, ed.edit_t_idx, g["for_e"], g["edit_e"], g["null_e"], mask=g["mask"], mode="(for-edit)")
+    x0m = ed.get_x0(x - h * v, t, ed.edit_t_idx, g["for_e"], g["edit_e"], g["null_e"], mask=g["mask"], mode="(for-edit)")
+    fd = (x0p - x0m) / (2 * h)
+    jv = op.gather(op.jvp((V[0] / V[0].norm())[None].contiguous()))
+    assert rel(jv, fd) < 2e-2
+
+
+def test_tloco_drivers_end_to_end(golden, tmp_path):
+    """run_edit_null_space_projection_xt (edit.py:1745-1868) and ..._xt_semantic (:1871-2018, jacobian direction,
+    null-space projected): files, shapes, unit norm, orthogonality to the null basis, --vT_path reload."""
+    g = golden("tloco_tiny")
+    ed = _edit(g, tmp_path, "bf16x3")
+    masks = torch.zeros(2, 1, 32, 32, dtype=torch.bool)
+    masks[1, 0, 12:20, 8:18] = True
+    with pytest.raises(FileNotFoundError):
+        ed.run_edit_null_space_projection_xt(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1)
+    os.makedirs(os.path.join(ed.result_folder, "mask"))
+    torch.save(masks, os.path.join(ed.result_folder, "mask", "mask.pt"))
+    torch.manual_seed(5)
+    x0 = ed.run_edit_null_space_projection_xt(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1,
+                                              null_space_projection=True, pca_rank_null=2)
+    assert x0.dtype == torch.uint8 and tuple(x0.shape) == (5, 32, 32, 3)
+    bdir = os.path.join(ed.result_folder, "basis", "local_basis-0.6T-pca-rank-1-select-mask1")
+    for f in ("u-modify.pt", "vT-modify.pt", "u-null-null_space_rank_2.pt", "vT-null-null_space_rank_2.pt"):
+        assert os.path.exists(os.path.join(bdir, f)), f
+    torch.manual_seed(5)
+    x0s = ed.run_edit_null_space_projection_xt_semantic(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1,
+                                                        null_space_projection=True, pca_rank_null=2, jacobian=True)
+    assert tuple(x0s.shape) == (5, 32, 32, 3)
+    sdir = os.path.join(ed.result_folder, "basis")
+    pcs = [f for f in os.listdir(sdir) if f.startswith("Semantic_Edit_xt-") and f.endswith("-pc_000-vT.pt")]
+    assert len(pcs) == 1
+    v = torch.load(os.path.join(sdir, pcs[0]))
+    assert tuple(v.shape) == (1, TINY_ADM.n) and abs(float(v.norm()) - 1.0) < 1e-4
+    # reload through --vT_path: same frames
+    ed2 = _edit(g, tmp_path, "bf16x3", vT_path=os.path.join(sdir, pcs[0]))
+    os.makedirs(os.path.join(ed2.result_folder, "mask"), exist_ok=True)
+    torch.manual_seed(5)
+    x0r = ed2.run_edit_null_space_projection_xt_semantic(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1)
+    assert float((x0r.int() - x0s.int()).abs().float().mean()) < 1.0
+    # sega ablation decodes the unedited x_t under three-way guidance
+    ed3 = _edit(g, tmp_path, "bf16x3", ablation="sega")
+    torch.manual_seed(5)
+    xs = ed3.run_edit_null_space_projection_xt_semantic(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1)
+    assert tuple(xs.shape) == (1, 32, 32, 3)
