@@ -20,6 +20,9 @@ Workloads (--workload):
       ranks (strong scaling, 64/N per rank), keep the leading 20 rows; value = 20 /
       step time.  The default run also times one step of it and reports it under
       "extra_workloads" next to the headline line.
+  tloco_if64 (BASELINE config 5): pixel-space T-LOCO at 64x64 on the IF-shaped stand-in conditional denoiser
+      (loco_edit_amd.tloco): top-5 null-space basis of the CFG-combined Jacobian ("null+(for-null)", guidance 7.5: two
+      denoiser branches per product), 5 probes per GPU sharded like the headline; value = 5 N directions / step time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--precision P]
                     [--no-cpu-baseline] [--no-e2e] [--no-extra]
@@ -56,7 +59,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["celeba_top5", "p2_k64"], default="celeba_top5")
+    ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64"], default="celeba_top5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end phase timing (inversion ... decode)")
@@ -282,7 +285,37 @@ def main():
             elapsed = float(tt.item())
         return elapsed, res
 
+    def make_tloco(prec):
+        """config 5: CFG-combined subspace solve on the IF-shaped stand-in (one engine context per prompt)."""
+        from argparse import Namespace
+        from loco_edit_amd.config import IF64_STANDIN
+        from loco_edit_amd.tloco import EditDeepFloydIF
+        cfg = IF64_STANDIN
+        k = K_PER_GPU * world
+        args = Namespace(device=device, dtype=torch.float32, seed=1, unet_config=cfg, synthetic_weights=0, ckpt_path="", max_batch=8,
+                         precision=prec, dataset_name="Random", for_steps=100, use_yh_custom_scheduler=True, guidance_scale=7.5,
+                         guidance_scale_edit=7.5, prompt_emb=None, prompt_emb_seed=31, cond_dim=64, for_prompt="standin",
+                         edit_prompt="standin-edit", edit_t=0.75, sampling_mode=False, tilda_v_score_type="null+(for-null)+(edit-null)",
+                         ablation_method="null-space-proj", mask_type="SAM", vT_path="", x_space_guidance_edit_step=1.0,
+                         x_space_guidance_scale=10.0, x_space_guidance_num_step=1,
+                         result_folder=os.path.join(ROOT, "gpurun_out", "bench_tloco"))
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            ed = EditDeepFloydIF(args)
+        ed.sharder = sharder
+        x, mask, v0 = synthetic_inputs(cfg, k, device)
+        tt = ed.scheduler.timesteps[ed.edit_t_idx]
+        F_, E_, N_ = ed.for_prompt_emb, ed.edit_prompt_emb, ed.null_prompt_emb
+
+        def step():
+            u, s, vT = ed.local_encoder_decoder_pullback_xt(x, tt, ed.edit_t_idx, F_, E_, N_, pca_rank=k, min_iter=N_ITER,
+                                                            max_iter=N_ITER, mask=~mask, mode="null+(for-null)", v0=v0, verbose=False)
+            return u, s, vT, ed.last_n_iter
+        return dict(cfg=cfg, k=k, keep=k, eng=ed.engine, params=None, step=step, x=x, mask=~mask, v0=v0, branches=2)
+
     def make_workload(name, prec):
+        if name == "tloco_if64":
+            return make_tloco(prec)
         if name == "celeba_top5":
             cfg, k, keep = CELEBA_DDPM, K_PER_GPU * world, K_PER_GPU * world
         else:
@@ -340,7 +373,7 @@ def main():
                                                 "command, stored (not re-measured by this run)")
             except Exception:
                 traffic = None
-        executed = (1 + 2 * k_local * N_ITER) * F      # the primal runs once per solve
+        executed = w.get("branches", 1) * (1 + 2 * k_local * N_ITER) * F      # the primal runs once per solve and branch
         roofline = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -390,6 +423,21 @@ def main():
                                                 "ms_per_step": round(el * 1e3, 3), "dtype": DTYPE_NOTE[prec],
                                                 "parity": parity_vs_fixture(s2, vT2, "celeba256")}
             eng.set_precision(a.precision)
+        # BASELINE config 5 next to the headline: T-LOCO null-space basis on the IF-shaped stand-in, 2 CFG branches
+        w3 = make_workload("tloco_if64", a.precision)
+        el, (_, s5, vT5, _) = timed(w3["step"], 1, 1)
+        if rank == 0:
+            F3 = w3["eng"].unet_flops()
+            kl = sharder.rows(w3["k"])[1] - sharder.rows(w3["k"])[0]
+            extra["tloco_if64"] = {
+                "value": round(w3["k"] / el, 4), "unit": "edit-directions/s (top-5 null-space basis per GPU, CFG-combined Jacobian)",
+                "ms_per_step": round(el * 1e3, 3), "scaling": "weak", "n_gpus": world, "probes_per_gpu": kl, "n_iter": N_ITER,
+                "cfg_branches": 2, "unet_GFLOP": round(F3 / 1e9, 2),
+                "whole_step_TFLOPs_executed_per_gpu": round(2 * (1 + 2 * kl * N_ITER) * F3 / el / 1e12, 2),
+                "singular_values_head": [round(float(v), 4) for v in s5.tolist()[:5]],
+                "denoiser": "IF-shaped stand-in (64x64, ch 192 x (1,2,3,4), 3 res blocks, attention 32/16/8; text through the time "
+                            "embedding) -- the IF U-Net itself is un-vendored diffusers code"}
+        del w3
         # BASELINE config 3 next to the headline: FFHQ-P2, 64 probes over the ranks, keep 20
         w2 = make_workload("p2_k64", a.precision)
         el, (_, s3, vT3, _) = timed(w2["step"], 1, 1)
@@ -409,7 +457,12 @@ def main():
         cpu = cpu_baseline(cfg, w["params"], t)
 
     if rank == 0:
-        if a.workload == "celeba_top5":
+        if a.workload == "tloco_if64":
+            metric = "edit-directions/sec (top-5 CFG-combined PMP-Jacobian null-space basis @64^2, T-LOCO)"
+            wl = ("T-LOCO pixel space 64x64, IF-shaped stand-in conditional denoiser, mode null+(for-null) guidance 7.5 (2 branches), "
+                  "complement of an l_eye-sized mask, t=0.75T, 12 power iterations, probes sharded 5 per GPU")
+            scaling = "weak"
+        elif a.workload == "celeba_top5":
             metric = "edit-directions/sec (top-5 PMP-Jacobian SVD @256^2) + vT cos-sim vs ref"
             wl = ("CelebA-HQ DDPM 256x256 top-5 local basis (l_eye-sized mask, L=2400), t=0.6T, 12 power iterations, "
                   "probes sharded 5 per GPU")

@@ -115,12 +115,16 @@ def test_cfg_operator_adjoint_and_linear(golden, tmp_path):
     assert float(JV[:, ~g["mask"].reshape(-1).to(DEV)].abs().max()) == 0.0
     comb = (2.0 * V[0] - 0.5 * V[1])[None].contiguous()
     assert rel(op.jvp(comb)[0], 2.0 * JV[0] - 0.5 * JV[1]) < 1e-4
-    # finite-difference check of J V against get_x0 in the same mode
+    # finite-difference check of J V against get_x0 in the same mode (a denoiser evaluation overwrites the primal arena:
+    # the operator is rebuilt afterwards)
     h = 1e-2
     v = V[0].view(1, 3, 32, 32) / V[0].norm()
     x0p = ed.get_x0(x + h * v, t, ed.edit_t_idx, g["for_e"], g["edit_e"], g["null_e"], mask=g["mask"], mode="(for-edit)")
     x0m = ed.get_x0(x - h * v, t, ed.edit_t_idx, g["for_e"], g["edit_e"], g["null_e"], mask=g["mask"], mode="(for-edit)")
     fd = (x0p - x0m) / (2 * h)
+    with pytest.raises(RuntimeError):
+        op.jvp(V)                                   # stale cache is refused, not silently used
+    op = ed._operator(x, t, g["mask"], "(for-edit)")
     jv = op.gather(op.jvp((V[0] / V[0].norm())[None].contiguous()))
     assert rel(jv, fd) < 2e-2
 
@@ -163,3 +167,29 @@ def test_tloco_drivers_end_to_end(golden, tmp_path):
     torch.manual_seed(5)
     xs = ed3.run_edit_null_space_projection_xt_semantic(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1)
     assert tuple(xs.shape) == (1, 32, 32, 3)
+
+
+def test_cli_shipped_if_script_on_the_standin(tmp_path, monkeypatch):
+    """`python -m loco_edit_amd.main` with the argument list of scripts/main_T2I_DeepFloydIF_null_space_projection.sh
+    (tests/golden/script_args.json) plus the deployment flags that replace what is out of scope (architecture preset,
+    synthetic weights; SAM masks come from mask.pt): preset's DeepFloyd branch, the reference's result-folder layout,
+    the Jacobian direction projected onto the null space, the saved --vT_path file."""
+    import json
+    from loco_edit_amd.main import main
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = json.load(open(os.path.join(root, "tests", "golden", "script_args.json")))["main_T2I_DeepFloydIF_null_space_projection.sh"]
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("LOCO_PRECISION", "bf16x3")
+    rdir = tmp_path / "runs" / "DeepFloyd-IF-Random-with_prompt" / "results" / "for_prompt_A photo of a man_cfg7.5_seed2628577915_standin"
+    os.makedirs(rdir / "mask")
+    masks = torch.zeros(13, 1, 32, 32, dtype=torch.bool)
+    masks[12, 0, 12:20, 8:18] = True
+    torch.save(masks, str(rdir / "mask" / "mask.pt"))
+    x0 = main(argv + ["--device", DEV, "--unet_preset", "tiny_adm", "--synthetic_weights", "0"])
+    assert x0.dtype == torch.uint8 and tuple(x0.shape) == (3, 32, 32, 3)      # vis_num 1: frames -S, 0, +S
+    pcs = [f for f in os.listdir(rdir / "basis") if f.endswith("-pc_000-vT.pt")]
+    assert len(pcs) == 1 and "edit_prompt-A photo of a man wearing glasses-select_mask12-null_space_projection_True_null_space_rank_5_null+(for-null)+(edit-null)" in pcs[0]
+    v = torch.load(str(rdir / "basis" / pcs[0]))
+    assert tuple(v.shape) == (1, TINY_ADM.n) and abs(float(v.norm()) - 1.0) < 1e-4
+    assert any(f.endswith("_stage1.png") for f in os.listdir(rdir))
