@@ -129,6 +129,11 @@ struct loco_ctx {
     int primal_B = 0;
     double flops = 0.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // second lane (probe groups of one tangent / cotangent pass on two streams, see run_lanes)
+    int n_streams = 1;
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    double* red2 = nullptr;
     // per-launch conv profile
     bool prof_on = false;
     struct ProfRec { const char* name; double flops; hipEvent_t e0, e1; int cin, cout, h, b, ns, mode, taps; };
@@ -1337,6 +1342,49 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
 
 }  // namespace
 
+// Probe groups on two streams.  The probes of a batch are independent, so a batch of B >= 4 is cut in two groups whose
+// passes are enqueued on two streams: the MFMA-bound convolutions of one group then run beside the bandwidth-bound
+// statistics / apply / reduce kernels of the other, and the two groups' 256-workgroup rounds drift out of phase (the
+// write burst of one group's epilogue overlaps the other's stage loops).  Lane 1 works on its own samples of the T
+// arena and its own reduction / split-K scratch; the host enqueues lane 0 completely, then lane 1.
+namespace {
+struct LaneSwap {
+    loco_ctx* c; float *arenaT, *statsT, *partial, *eps_buf, *ge, *gx0; double* red; size_t partial_floats;
+    LaneSwap(loco_ctx* c_, int s0) : c(c_) {
+        arenaT = c->arenaT; statsT = c->statsT; partial = c->partial; eps_buf = c->eps_buf; ge = c->ge; gx0 = c->gx0;
+        red = c->red; partial_floats = c->partial_floats;
+        c->arenaT += (long)s0 * c->per_sample; c->statsT += (long)s0 * c->stats_per_sample;
+        c->eps_buf += (long)s0 * c->n_in; c->ge += (long)s0 * c->n_in; c->gx0 += (long)s0 * c->n_in;
+        c->partial += partial_floats / 2; c->partial_floats = partial_floats / 2;
+        c->red = c->red2;
+    }
+    ~LaneSwap() {
+        c->arenaT = arenaT; c->statsT = statsT; c->partial = partial; c->eps_buf = eps_buf; c->ge = ge; c->gx0 = gx0;
+        c->red = red; c->partial_floats = partial_floats;
+    }
+};
+template <typename F>
+int run_lanes(loco_ctx* c, int B, hipStream_t st, F body) {      // body(first sample, count, stream)
+    if (c->n_streams < 2 || c->prof_on || B < 4) return body(0, B, st);
+    const int nA = (B + 1) / 2;
+    const size_t pf = c->partial_floats;
+    HIPCHK(c, hipEventRecord(c->ev_fork, st));
+    c->partial_floats = pf / 2;                    // lane 0 keeps the lower half of the split-K workspace
+    int rc = body(0, nA, st);
+    c->partial_floats = pf;
+    if (rc) return rc;
+    HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+    {
+        LaneSwap sw(c, nA);
+        rc = body(nA, B - nA, c->st2);
+    }
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_join, c->st2));
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    return 0;
+}
+}  // namespace
+
 // =============================== C ABI =======================================
 extern "C" {
 
@@ -1380,7 +1428,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         c->arenaP = p0 + 64; c->arenaT = p1 + 64;
     }
     if (dalloc(c, &c->statsP, MB * c->stats_per_sample) || dalloc(c, &c->statsT, MB * c->stats_per_sample)) return -1;
-    if (dalloc(c, &c->red, RED_BYTES)) return -1;
+    if (dalloc(c, &c->red, RED_BYTES) || dalloc(c, &c->red2, RED_BYTES)) return -1;
     c->partial_floats = (size_t)64 << 20;   // 256 MB split-K workspace
     if (dalloc(c, &c->partial, c->partial_floats)) return -1;
     if (dalloc(c, &c->eps_buf, MB * c->n_in) || dalloc(c, &c->gx0, MB * c->n_in) || dalloc(c, &c->ge, MB * c->n_in))
@@ -1407,6 +1455,13 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         dalloc(c, &c->mask_L_dev, 4)) return -1;
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
+    {
+        const char* e = getenv("LOCO_STREAMS");
+        c->n_streams = (e && atoi(e) == 2) ? 2 : 1;
+        HIPCHK(c, hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -1415,6 +1470,9 @@ void loco_destroy(loco_ctx* c) {
     for (float* p : c->owned) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->st2) (void)hipStreamDestroy(c->st2);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
 }
@@ -1545,12 +1603,16 @@ int loco_pmp_jvp(loco_ctx* c, const float* V, int32_t k, float* U, void* stream)
     const int MB = c->cfg.max_batch;
     for (int b0 = 0; b0 < k; b0 += MB) {
         int B = (k - b0 < MB) ? k - b0 : MB;
-        const float* Vc = V + (long)b0 * c->n_in;
-        if (tangent_pass(c, Vc, B, st)) return -1;
-        // U = mask * (cv*V + ce*dEps); dEps lives strided in arena T -> gather through eps_buf
-        launch_copy(c->arenaT + c->tens[c->eps_t].off, c->per_sample, c->eps_buf, c->n_in, 0, B, c->n_in, st);
-        launch_masked_axpby(Vc, c->eps_buf, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce,
-                            U + (long)b0 * c->n_in, B, c->n_in, st);
+        int rc = run_lanes(c, B, st, [&](int s0, int nb, hipStream_t ls) -> int {
+            const float* Vc = V + (long)(b0 + s0) * c->n_in;
+            if (tangent_pass(c, Vc, nb, ls)) return -1;
+            // U = mask * (cv*V + ce*dEps); dEps lives strided in arena T -> gather through eps_buf
+            launch_copy(c->arenaT + c->tens[c->eps_t].off, c->per_sample, c->eps_buf, c->n_in, 0, nb, c->n_in, ls);
+            launch_masked_axpby(Vc, c->eps_buf, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce,
+                                U + (long)(b0 + s0) * c->n_in, nb, c->n_in, ls);
+            return 0;
+        });
+        if (rc) return rc;
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1563,9 +1625,12 @@ int loco_pmp_vjp(loco_ctx* c, const float* U, int32_t k, float* A, void* stream)
     const int MB = c->cfg.max_batch;
     for (int b0 = 0; b0 < k; b0 += MB) {
         int B = (k - b0 < MB) ? k - b0 : MB;
-        launch_cot_seed(U + (long)b0 * c->n_in, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce, c->ge, c->gx0, B,
-                        c->n_in, st);
-        if (cotangent_pass(c, c->ge, c->gx0, A + (long)b0 * c->n_in, B, st)) return -1;
+        int rc = run_lanes(c, B, st, [&](int s0, int nb, hipStream_t ls) -> int {
+            launch_cot_seed(U + (long)(b0 + s0) * c->n_in, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce, c->ge, c->gx0,
+                            nb, c->n_in, ls);
+            return cotangent_pass(c, c->ge, c->gx0, A + (long)(b0 + s0) * c->n_in, nb, ls);
+        });
+        if (rc) return rc;
     }
     HIPCHK(c, hipGetLastError());
     return 0;

@@ -644,3 +644,30 @@ def test_probe_batching_is_invariant_full_size(k, engines):
         Ai = eng.pmp_vjp(U[i:i + 1].contiguous())
         assert float((U[i] - Ui[0]).norm() / Ui[0].norm()) < 1e-5     # split-K factors differ with the batch: rounding only
         assert float((A[i] - Ai[0]).norm() / Ai[0].norm()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_two_stream_probe_groups_match_single_stream(monkeypatch):
+    """LOCO_STREAMS=2: the probes of a batch run as two groups on two streams (own arena samples, own scratch);
+    J V and J^T U agree with the single-stream engine up to the rounding of batch-dependent split-K factors."""
+    from loco_edit_amd.hip import LocoEngine
+    cfg = CELEBA_DDPM
+    s = _sched()
+    t = float(s.timesteps[40]); at = float(s.alpha_at(t))
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(1, 3, 256, 256, generator=g).to(DEV)
+    mask = torch.zeros(3, 256, 256, dtype=torch.bool); mask[:, 110:130, 70:110] = True
+    V = torch.randn(5, cfg.n, generator=g).to(DEV)
+    out = {}
+    for ns in ("1", "2"):
+        monkeypatch.setenv("LOCO_STREAMS", ns)
+        eng = LocoEngine(cfg, max_batch=8, device=torch.device(DEV))
+        eng.load_state_dict(synth_params(cfg, 0))
+        eng.set_precision("bf16x3")
+        eng.pmp_primal(x, t, at, mask.to(DEV))
+        U = eng.pmp_jvp(V)
+        A = eng.pmp_vjp(U)
+        torch.cuda.synchronize()
+        out[ns] = (U.cpu(), A.cpu())
+        del eng
+    assert rel(out["2"][0], out["1"][0]) < 1e-5 and rel(out["2"][1], out["1"][1]) < 1e-5
