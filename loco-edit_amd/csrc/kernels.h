@@ -124,7 +124,9 @@ void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows
 // temb pipeline: sinusoid(t) -> dense0 -> swish -> dense1 -> swish -> all per-block projections
 void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
                  const float* w1, const float* b1, float* scratch, hipStream_t st, int cos_first = 0,
-                 const float* add = nullptr);    // add[temb_ch]: conditioning embedding added to emb before the SiLU
+                 const float* add = nullptr,      // add[temb_ch]: conditioning embedding added to emb before the SiLU
+                 const float* t_ptr = nullptr);   // non-null: read the timestep from device memory (graph replay)
+void launch_set_scalar(float* p, float v, hipStream_t st);
 void launch_temb_proj(const float* tact, int temb_ch, const float* w, const float* b, int cout,
                       float* out, hipStream_t st);
 // out[b][c][y][x] = sum of the 2x2 block of in[b][c][2y..][2x..]   (adjoint of nearest x2)

@@ -408,8 +408,10 @@ void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows
 // time embedding: [sin, cos] sinusoid (divisor half-1) -> dense0 -> swish -> dense1 -> swish
 // (reference diffusion.py:783-804, 154-157, and the nonlinearity(temb) of :899)
 __global__ void temb_kernel(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
-                            const float* w1, const float* b1, float* out, int cos_first, const float* add) {
+                            const float* w1, const float* b1, float* out, int cos_first, const float* add,
+                            const float* t_ptr) {
     extern __shared__ float sm[];
+    if (t_ptr) t = *t_ptr;     // timestep from device memory: the launch is a node of a replayed HIP graph
     float* emb = sm;           // [ch]
     float* h = sm + ch;        // [temb_ch]
     const int half = ch / 2;
@@ -435,9 +437,14 @@ __global__ void temb_kernel(float t, int ch, int temb_ch, const float* freq, con
     }
 }
 void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0, const float* w1,
-                 const float* b1, float* scratch, hipStream_t st, int cos_first, const float* add) {
+                 const float* b1, float* scratch, hipStream_t st, int cos_first, const float* add,
+                 const float* t_ptr) {
     hipLaunchKernelGGL(temb_kernel, dim3(1), dim3(512), (ch + temb_ch) * sizeof(float), st, t, ch, temb_ch, freq,
-                       w0, b0, w1, b1, scratch, cos_first, add);
+                       w0, b0, w1, b1, scratch, cos_first, add, t_ptr);
+}
+__global__ void set_scalar_kernel(float* p, float v) { *p = v; }
+void launch_set_scalar(float* p, float v, hipStream_t st) {
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, p, v);
 }
 // out[o] = b[o] + sum_i w[o][i]*tact[i]; one wave per output row
 __global__ __launch_bounds__(256) void temb_proj_kernel(const float* tact, int temb_ch, const float* w,

@@ -671,3 +671,37 @@ def test_two_stream_probe_groups_match_single_stream(monkeypatch):
         out[ns] = (U.cpu(), A.cpu())
         del eng
     assert rel(out["2"][0], out["1"][0]) < 1e-5 and rel(out["2"][1], out["1"][1]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_graph_replay_matches_eager(monkeypatch):
+    """Denoiser evaluations replayed as HIP graphs (opt-in, LOCO_GRAPH=1) are bit-identical to the eager launch list
+    (default): a DDIM chain with a changing timestep (read from device memory by the captured time-embedding
+    kernel), two batch sizes, and a PMP solve in between (which must not see a stale graph state)."""
+    from loco_edit_amd.hip import LocoEngine
+    cfg = TINY_DDPM
+    s = _sched()
+    g = torch.Generator().manual_seed(23)
+    x1 = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=g).to(DEV)
+    x3 = torch.randn(3, 3, cfg.resolution, cfg.resolution, generator=g).to(DEV)
+    ts = [float(s.timesteps[i]) for i in (10, 30, 50, 70, 90)]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LOCO_GRAPH", mode)
+        eng = LocoEngine(cfg, max_batch=4, device=torch.device(DEV))
+        eng.load_state_dict(synth_params(cfg, 0))
+        eng.set_precision("bf16x3")
+        xs, res = x1.clone(), []
+        for i, t in enumerate(ts):
+            at = float(s.alpha_at(t)); an = float(s.alpha_at(max(t - 10.0, 0.0)))
+            xs = eng.ddim_step(xs, t, at, an)
+            res.append(xs.cpu())
+            res.append(eng.unet_forward(x3, t).cpu())
+            if i == 2:     # a solve between evaluations rebuilds the primal arena the graph also writes
+                eng.pmp_primal(x1, t, at, None)
+                res.append(eng.pmp_jvp(x3.view(3, -1)).cpu())
+        out[mode] = res
+        del eng
+    assert len(out["0"]) == len(out["1"])
+    for a, b in zip(out["0"], out["1"]):
+        assert torch.equal(a, b)

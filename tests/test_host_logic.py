@@ -122,13 +122,16 @@ def test_every_shipped_script_parses():
     assert a.mask_model_name == "facebook/sam-vit-large"
 
 
-def test_preset_accepts_unconditional_scripts_and_rejects_t2i(tmp_path, monkeypatch):
+def test_preset_accepts_unconditional_and_if_scripts_and_rejects_latent_t2i(tmp_path, monkeypatch):
     import json
     monkeypatch.chdir(tmp_path)
     scripts = json.load(open(os.path.join(ROOT, "tests", "golden", "script_args.json")))
     for name, argv in scripts.items():
         a = define_argparser.parse_args(argv + ["--device", "cpu", "--seed", "3"])
-        if "T2I" in name:
+        if "DeepFloydIF" in name:       # pixel-space T-LOCO (reference define_argparser.py:147-160 routes by model name)
+            a = define_argparser.preset(a)
+            assert a.image_size == 64 and a.exp == "DeepFloyd-IF-Random-with_prompt"
+        elif "T2I" in name:             # latent-space T-LOCO (SD / LCM): outside this build, refused loudly
             with pytest.raises(NotImplementedError):
                 define_argparser.preset(a)
         else:
