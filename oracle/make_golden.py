@@ -358,6 +358,44 @@ def gen_scheduler(YHS, extract):
     return out
 
 
+def gen_celeba256_null(redit, YHS, PullBackDDPM, tmpdir, n_iter=3, k_null=5):
+    """BASELINE config 2 at its size: the null-space solve of the reference on the COMPLEMENT of the l_eye-sized mask
+    (edit.py:2296-2310: `mask=~mask`, L = 194 208), 256x256 CelebA-DDPM architecture, V0 injected, `n_iter` iterations
+    (minutes of CPU per iteration), then the reference's projection + normalisation (edit.py:2317-2323) of the
+    12-iteration modify basis of celeba256.pt (its fp16 copy, widened) against that null basis."""
+    from loco_edit_amd.config import CELEBA_DDPM as cfg, synth_params
+    base = torch.load(os.path.join(GOLD, "celeba256.pt"))
+    model = ref_model(PullBackDDPM, cfg, synth_params(cfg, seed=0))
+    ed = ref_edit(redit, YHS, model, tmpdir)
+    x, t, mask = base["x"], base["t"], base["mask"]
+    gv = torch.Generator().manual_seed(7)
+    v0 = torch.randn(cfg.n, max(k_null, 5), generator=gv)       # the same draw the modify solve used (v0_seed 7)
+    real_randn = torch.randn
+
+    def fake_randn(*size, **kw):
+        if len(size) == 2 and size[0] == cfg.n:
+            return v0[:, :size[1]].clone()
+        return real_randn(*size, **kw)
+
+    torch.randn = fake_randn
+    try:
+        with torch.no_grad():
+            u_n, s_n, vT_n = ed.local_encoder_decoder_pullback_xt(
+                x=x, t=t, pca_rank=k_null, min_iter=n_iter, max_iter=n_iter, convergence_threshold=1e-4, mask=~mask)
+    finally:
+        torch.randn = real_randn
+    vT_m = base["vT_modify_f16"].float()
+    vT_null = vT_n[:k_null, :]
+    vT = (vT_null.T @ (vT_null @ vT_m.T)).T
+    vT = vT_m - vT
+    vT = vT / vT.norm(dim=1, keepdim=True)
+    gp = torch.Generator().manual_seed(17)
+    P = torch.randn(cfg.n, 64, generator=gp)
+    return {"n_iter": n_iter, "k_null": k_null, "v0_seed": 7, "s_null": s_n, "vT_null_f16": vT_n.to(torch.float16),
+            "vT_null_proj": vT_n @ P, "vT_proj_seed": 17, "vT_projected_proj": vT @ P,
+            "vT_projected_f16": vT.to(torch.float16), "u_null_norms": u_n.norm(dim=0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the 256x256 CelebA-DDPM summaries (minutes of CPU)")
@@ -402,6 +440,9 @@ def main():
         keep = ("cfg", "weights_seed", "x", "t", "mask", "v0_seed", "n_iter", "s_modify", "vT_modify_f16",
                 "vT_proj_seed", "vT_modify_proj")
         torch.save({k: o[k] for k in keep}, os.path.join(GOLD, "p2_solver.pt"))
+    if a.only == "celeba256_null":
+        print("config 2 at size: null-space solve on the complement mask, 3 iterations + projection")
+        torch.save(gen_celeba256_null(redit, YHS, PullBackDDPM, tmpdir), os.path.join(GOLD, "celeba256_null.pt"))
     if a.only == "eta1":
         print("tiny eta=1 decode with injected noise")
         torch.save(gen_eta1_decode(redit, YHS, PullBackDDPM, tmpdir), os.path.join(GOLD, "tiny_eta1.pt"))

@@ -705,3 +705,45 @@ def test_graph_replay_matches_eager(monkeypatch):
     assert len(out["0"]) == len(out["1"])
     for a, b in zip(out["0"], out["1"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_config2_null_space_solve_and_projection_at_size(prec, engines, golden):
+    """BASELINE.json config 2 at its stated size (edit.py:2296-2323): the null-space solve on the COMPLEMENT of the
+    l_eye-sized mask (L = 194 208 of n = 196 608) against the reference's own 3-iteration result on the same
+    x / t / V0 (oracle/make_golden.py --only celeba256_null), then the projection + normalisation of the
+    12-iteration modify basis against that null basis, the +/- edit walk and its decode, all at 256x256."""
+    from loco_edit_amd import solver
+    g, gn = golden("celeba256"), golden("celeba256_null")
+    eng = engines(CELEBA_DDPM, prec)
+    s_ = _sched()
+    at = float(s_.alpha_at(g["t"]))
+    k0, n_it = int(gn["k_null"]), int(gn["n_iter"])
+    v0 = torch.randn(CELEBA_DDPM.n, max(k0, 5), generator=torch.Generator().manual_seed(gn["v0_seed"]))[:, :k0]
+    mask = g["mask"].to(DEV)
+    u, s, vTn, it = solver.local_basis(eng, g["x"].to(DEV), float(g["t"]), at, k0, mask=~mask, min_iter=n_it,
+                                       max_iter=n_it, v0=v0.to(DEV), verbose=False)
+    assert it == n_it and u.shape == (int((~mask).sum()), k0) and eng.mask_count() == 194208
+    cos, span = _row_cos(vTn, gn["vT_null_f16"])
+    print(f"[{prec}] config-2 null solve |cos| = {cos.tolist()}, span {span.min().item():.6f}")
+    assert torch.allclose(s.cpu(), gn["s_null"], rtol=1e-3)
+    assert cos.min().item() > (0.999 if prec == "f32" else 0.99) and span.min().item() > 0.999
+    assert torch.allclose(u.norm(dim=0).cpu(), gn["u_null_norms"], rtol=2e-3)
+    # projection of the reference's modify basis against OUR null basis vs the reference's projected rows
+    vm = g["vT_modify_f16"].float().contiguous().to(DEV)
+    vTn = vTn.contiguous()
+    vT = eng.null_project(vm, vTn)
+    cosp, _ = _row_cos(vT, gn["vT_projected_f16"])
+    assert cosp.min().item() > 0.9999, cosp
+    vd, nd = vT.double(), vTn.double()
+    assert (vd.norm(dim=1) - 1).abs().max().item() < 1e-5 and (nd @ vd.T).abs().max().item() < 1e-5
+    # edit walk (edit.py:2339-2363) of the first direction and its decode from the edit step
+    alphas = torch.tensor([-8.0, -4.0, 0.0, 4.0, 8.0])        # scale 0.5 x steps {-16, -8, 0, 8, 16}
+    xb = eng.edit_axpy(g["x"].to(DEV), vT[0], alphas)
+    assert xb.shape == (5, 3, 256, 256) and torch.equal(xb[2], g["x"][0].to(DEV))
+    assert rel((xb[4] - xb[2]).reshape(-1), 8.0 * vT[0]) < 1e-5
+    x = xb
+    ts, tn = s_.timesteps, s_.timesteps_next
+    for i in range(40, 44):
+        x = eng.ddim_step(x, float(ts[i]), float(s_.alpha_at(ts[i])), float(s_.alpha_at(tn[i])))
+    assert torch.isfinite(x).all() and (x[0] - x[4]).abs().max().item() > 1e-3

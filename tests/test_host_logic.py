@@ -143,6 +143,36 @@ def test_preset_accepts_unconditional_and_if_scripts_and_rejects_latent_t2i(tmp_
         define_argparser.preset(define_argparser.parse_args(["--model_name", "CelebA_HQ", "--performance_boosting_t", "0.2", "--seed", "1"]))
 
 
+def test_lpips_properties_on_synthetic_weights(tmp_path, monkeypatch):
+    """LPIPS (AlexNet taps, eval.py:33-36 intent): with any non-negative heads d(x, x) = 0, d >= 0, d(x, y) = d(y, x),
+    grows with the perturbation; weights come from a file (here synthetic: the pretrained ones are not offline)."""
+    from loco_edit_amd.eval import lpips, lpips_weight_names, evaluate_folders
+    from loco_edit_amd.utils import save_image
+    monkeypatch.delenv("LOCO_LPIPS_WEIGHTS", raising=False)
+    g = torch.Generator().manual_seed(3)
+    shapes = {0: (64, 3, 11, 11), 3: (192, 64, 5, 5), 6: (384, 192, 3, 3), 8: (256, 384, 3, 3), 10: (256, 256, 3, 3)}
+    w = {}
+    for j, (i, sh) in enumerate(shapes.items()):
+        w[f"net.features.{i}.weight"] = torch.randn(sh, generator=g) / (sh[1] * sh[2] * sh[3]) ** 0.5
+        w[f"features.{i}.bias"] = torch.randn(sh[0], generator=g) * 0.1
+        w[f"lin{j}.model.1.weight"] = torch.rand(1, sh[0], 1, 1, generator=g)
+    assert sorted(k[4:] if k.startswith("net.") else k for k in w) == sorted(lpips_weight_names())
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    n = torch.randn(2, 3, 64, 64, generator=g)
+    y1, y2 = (x + 0.05 * n).clamp(-1, 1), (x + 0.4 * n).clamp(-1, 1)
+    assert float(lpips(x, x, weights=w)) == 0.0
+    d1, d2 = float(lpips(x, y1, weights=w)), float(lpips(x, y2, weights=w))
+    assert 0.0 < d1 < d2 and abs(float(lpips(y1, x, weights=w)) - d1) < 1e-7
+    assert abs(float(lpips((x + 1) / 2, (y1 + 1) / 2, weights=w, normalize=True)) - d1) < 1e-6
+    with pytest.raises(ValueError):
+        lpips(x, y1, weights={k: v for k, v in w.items() if "lin3" not in k})
+    f = tmp_path / "w.pt"; torch.save(w, str(f))
+    p, o = tmp_path / "p", tmp_path / "o"; os.makedirs(p); os.makedirs(o)
+    save_image((x[:1] + 1) / 2, str(o / "0.png"), padding=0); save_image((y2[:1] + 1) / 2, str(p / "0.png"), padding=0)
+    r = evaluate_folders(str(p), str(o), "lpips", lpips_weights=str(f))
+    assert r["n"] == 1 and r["mean"] > 0.0
+
+
 def test_edit_batch_alphas():
     """vis_num subsampling of edit.py:2358-2363 (S=16, vis_num=2 -> 5 frames at -16,-8,0,8,16 steps)."""
     from loco_edit_amd.edit import EditUncondDiffusion
@@ -214,7 +244,7 @@ def test_eval_masked_mse_and_folder_pairing(tmp_path):
     assert float(masked_mse(x, y, ~mask[None])) == 0.0
     with pytest.raises(ValueError):
         masked_mse(x, y, torch.zeros_like(mask)[None])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):      # no weights file: refuse instead of inventing a value
         lpips(x, y)
     p, o = tmp_path / "p", tmp_path / "o"
     os.makedirs(p / "mask"); os.makedirs(o)
