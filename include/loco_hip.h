@@ -44,7 +44,13 @@ typedef struct loco_unet_cfg {
     int32_t max_batch;         /* largest image / probe batch one call may carry */
     /* 0: Ho-DDPM U-Net (models/ddpm/diffusion.py); 1: guided-diffusion / P2 U-Net
      * (models/guided_diffusion/unet.py:398-684 with P2_DICT, script_util.py:166-190:
-     * scale-shift norm, ResBlock up/down, legacy multi-head attention, [cos,sin] embedding) */
+     * scale-shift norm, ResBlock up/down, legacy multi-head attention, [cos,sin] embedding);
+     * 2: latent decoder -- the network behind `self.vae.decode(z).sample` of the Stable Diffusion path
+     * (src/modules/edit.py:750, 770-771; diffusers AutoencoderKL decoder, un-vendored): conv_in, mid block/attn/block,
+     * up levels of num_res_blocks+1 ResnetBlocks + nearest-x2 conv, norm_out/SiLU/conv_out; no skips, no time
+     * embedding.  `resolution` is the latent resolution, the output is [out_ch, resolution << (num_levels-1), same];
+     * loco_unet_forward ignores t; loco_pmp_primal needs use_et = 1 (raw network Jacobian, mask on the OUTPUT) and
+     * loco_pmp_jvp / _vjp then map [k, in] -> [k, out] / [k, out] -> [k, in]; loco_ddim_step is refused */
     int32_t arch;
     int32_t num_head_channels; /* arch 1: channels per attention head (P2: 64) */
     int32_t learn_sigma;       /* arch 1: the head emits 2*out_ch channels, eps = first out_ch (unet.py:680-684) */

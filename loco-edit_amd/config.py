@@ -32,6 +32,9 @@ class UNetConfig:
     gn_eps: float = 1e-6
     # "ddpm": Ho et al. U-Net (models/ddpm/diffusion.py); "adm": guided-diffusion / P2 U-Net
     # (models/guided_diffusion/unet.py with P2_DICT: scale-shift norm, resblock up/down, legacy multi-head attention)
+    # "dec": latent decoder (conv_in, mid, up levels, norm_out/conv_out; no skips, no time embedding) -- the
+    # `vae.decode` network of the reference's Stable Diffusion path (edit.py:750, 770-771); `resolution` is then the
+    # LATENT resolution and the output is [out_ch, resolution * 2^(levels-1), same]
     arch: str = "ddpm"
     num_head_channels: int = -1     # adm: channels per attention head (P2: 64)
     learn_sigma: bool = False       # adm: network emits 2*out_ch channels, eps = the first out_ch (unet.py:680-684)
@@ -43,6 +46,14 @@ class UNetConfig:
     @property
     def n(self) -> int:
         return self.in_channels * self.resolution * self.resolution
+
+    @property
+    def out_resolution(self) -> int:
+        return self.resolution << (len(self.ch_mult) - 1) if self.arch == "dec" else self.resolution
+
+    @property
+    def n_out(self) -> int:
+        return self.out_ch * self.out_resolution * self.out_resolution
 
 
 # configs[0..1] of BASELINE.json: google/ddpm-celebahq-256 architecture
@@ -60,6 +71,19 @@ FFHQ_P2 = UNetConfig(resolution=256, ch=128, ch_mult=(1, 1, 2, 2, 4, 4), num_res
 # UNet2DConditionModel with T5 cross-attention (un-vendored) -- here the text enters through the time embedding only
 IF64_STANDIN = UNetConfig(resolution=64, ch=192, ch_mult=(1, 2, 3, 4), num_res_blocks=3, attn_resolutions=(32, 16, 8),
                           gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=True)
+# BASELINE config 4 stand-ins (Stable Diffusion v1.5 shape class; the real networks are diffusers' UNet2DConditionModel
+# with CLIP cross-attention and AutoencoderKL, both un-vendored): a 4-channel 64x64 latent denoiser with SD's widths
+# (320 x (1,2,4,4), 2 ResBlocks per level, attention at 32/16/8 -- the text enters through the time embedding only, as
+# in IF64_STANDIN) and the SD autoencoder's decoder geometry (128 x (1,2,4,4), 2+1 ResBlocks per level, one mid
+# attention at 64x64 = 4096 tokens, 4 -> 3 channels, 64 -> 512 pixels)
+SD64_STANDIN = UNetConfig(resolution=64, in_channels=4, out_ch=4, ch=320, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
+                          attn_resolutions=(32, 16, 8), gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=False)
+SD_VAE_DECODER = UNetConfig(resolution=64, in_channels=4, out_ch=3, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
+                            attn_resolutions=(), gn_eps=1e-6, arch="dec")
+TINY_LATENT = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=32, ch_mult=(1, 2), num_res_blocks=1,
+                         attn_resolutions=(8,), gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=False)
+TINY_DECODER = UNetConfig(resolution=16, in_channels=4, out_ch=3, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1,
+                          attn_resolutions=(), gn_eps=1e-6, arch="dec")
 TINY_ADM = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,),
                       gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True)
 
@@ -129,6 +153,8 @@ def param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     reference module tree (``diffusion.py:41-126``)."""
     if cfg.arch == "adm":
         return adm_param_shapes(cfg)
+    if cfg.arch == "dec":
+        return dec_param_shapes(cfg)
     shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
 
     def lin(name, cin, cout):
@@ -186,6 +212,51 @@ def param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
             if b == cfg.num_res_blocks:
                 skip_in = ch * in_mult[lvl]
             resblock(f"up.{lvl}.block.{b}", block_in + skip_in, block_out)
+            block_in = block_out
+            if res in cfg.attn_resolutions:
+                attn(f"up.{lvl}.attn.{b}", block_in)
+        if lvl != 0:
+            conv(f"up.{lvl}.upsample.conv", block_in, block_in, 3)
+            res *= 2
+    norm("norm_out", block_in)
+    conv("conv_out", block_in, cfg.out_ch, 3)
+    return shapes
+
+
+def dec_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict layout of the latent-diffusion ``Decoder`` (the module tree of the DDPM U-Net's up half without skip
+    inputs and without ``temb_proj``): ``conv_in``, ``mid.{block_1,attn_1,block_2}``,
+    ``up.L.block.B.{norm1,conv1,norm2,conv2,nin_shortcut}``, ``up.L.attn.B``, ``up.L.upsample.conv``, ``norm_out``,
+    ``conv_out``."""
+    shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def conv(name, cin, cout, k):
+        shapes[name + ".weight"] = (cout, cin, k, k); shapes[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        shapes[name + ".weight"] = (c,); shapes[name + ".bias"] = (c,)
+
+    def resblock(name, cin, cout):
+        norm(name + ".norm1", cin); conv(name + ".conv1", cin, cout, 3)
+        norm(name + ".norm2", cout); conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".nin_shortcut", cin, cout, 1)
+
+    def attn(name, c):
+        norm(name + ".norm", c)
+        for p in ("q", "k", "v", "proj_out"):
+            conv(name + "." + p, c, c, 1)
+
+    ch, mult = cfg.ch, tuple(cfg.ch_mult)
+    nlev = len(mult)
+    block_in = ch * mult[-1]
+    res = cfg.resolution
+    conv("conv_in", cfg.in_channels, block_in, 3)
+    resblock("mid.block_1", block_in, block_in); attn("mid.attn_1", block_in); resblock("mid.block_2", block_in, block_in)
+    for lvl in reversed(range(nlev)):
+        block_out = ch * mult[lvl]
+        for b in range(cfg.num_res_blocks + 1):
+            resblock(f"up.{lvl}.block.{b}", block_in, block_out)
             block_in = block_out
             if res in cfg.attn_resolutions:
                 attn(f"up.{lvl}.attn.{b}", block_in)

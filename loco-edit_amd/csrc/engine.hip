@@ -69,6 +69,7 @@ struct Op {
     int heads = 1;                // ATTN
     bool in_is_skip = false;
     bool has_nin = false;
+    bool has_temb = true;         // RES: false for the embedding-free blocks of the decoder (arch 2)
     // parameter name stems in the reference state_dict
     std::string pn_n1, pn_c1, pn_emb, pn_n2, pn_c2, pn_skip, pn_qkv, pn_proj, pn_conv;
     ConvP c1, c2, nin, qkvc, proj, conv;     // conv: CONV_IN / DOWN / UP / OUT
@@ -92,7 +93,8 @@ struct loco_ctx {
     long per_sample = 0;       // floats per sample in an activation arena
     long stats_per_sample = 0; // floats per sample in a stats arena
     long tproj_total = 0;
-    int n_in = 0;              // C*H*W of the image
+    int n_in = 0;              // C*H*W of the network input (image / latent)
+    int n_out = 0;             // C*H*W of the network output (= n_in for the denoisers; the decoded image for arch 2)
     int eps_t = -1;            // tensor id of the network output
 
     float *arenaP = nullptr, *arenaT = nullptr;
@@ -138,7 +140,7 @@ struct loco_ctx {
     // opt-in (LOCO_GRAPH=1).  Measured: no gain on an idle host -- the eager launch list already runs back to back
     // (B = 1: 363 kernels, 5.29 ms busy of 5.31 ms span per evaluation) -- it only takes the ~360 launches per
     // evaluation off the host thread.
-    struct FwdGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; double flops = 0.0; int calls = 0; };
+    struct FwdGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int calls = 0; };
     std::map<int, FwdGraph> fwd_graphs;
     bool graph_on = false;
     hipStream_t cap_st = nullptr;  // capture stream (the caller's may be the legacy default stream)
@@ -204,13 +206,16 @@ bool attn_at(const loco_unet_cfg& cfg, int res) {
 }
 
 int build_program_adm(loco_ctx* c);
+int build_program_dec(loco_ctx* c);
 
 // Build the op list + memory plan (mirrors DDPM.__init__/forward, reference diffusion.py:22-200)
 int build_program(loco_ctx* c) {
     if (c->cfg.arch == 1) return build_program_adm(c);
+    if (c->cfg.arch == 2) return build_program_dec(c);
     const loco_unet_cfg& cfg = c->cfg;
     const int ch = cfg.ch, nres = cfg.num_levels, R = cfg.resolution;
     c->n_in = cfg.in_channels * R * R;
+    c->n_out = cfg.out_ch * R * R;
     auto add_attn = [&](const std::string& name, int in_t, int out_t) {
         Op a; a.kind = OP_ATTN; a.name = name; a.in = in_t; a.out = out_t;
         const Tens& t = c->tens[in_t];
@@ -381,6 +386,7 @@ int build_program_adm(loco_ctx* c) {
     const loco_unet_cfg& cfg = c->cfg;
     const int mc = cfg.ch, nlev = cfg.num_levels, R = cfg.resolution;
     c->n_in = cfg.in_channels * R * R;
+    c->n_out = cfg.out_ch * R * R;
     auto heads_of = [&](int C) { return cfg.num_head_channels > 0 ? C / cfg.num_head_channels : 1; };
     auto add_res = [&](const std::string& name, int in_t, int out_t, int updown, bool in_is_skip) {
         Op r; r.kind = OP_RES; r.name = name; r.in = in_t; r.out = out_t; r.updown = updown;
@@ -524,6 +530,96 @@ int build_program_adm(loco_ctx* c) {
     return 0;
 }
 
+// Latent decoder (arch 2): the `Decoder` of the latent-diffusion autoencoder that `vae.decode` runs in the reference's
+// Stable Diffusion path (edit.py:750, 770-771; diffusers AutoencoderKL, un-vendored -- same module tree as the DDPM
+// U-Net's up half without skips and without a time embedding): conv_in (z_channels -> ch*ch_mult[-1]) at the latent
+// resolution R; mid.block_1, mid.attn_1, mid.block_2; for each level from the coarsest: num_res_blocks + 1
+// ResnetBlocks [+ attention at cfg.attn_resolutions] and, except at level 0, nearest x2 + conv3; norm_out, SiLU,
+// conv_out.  Output [out_ch, R * 2^(levels-1), same].
+int build_program_dec(loco_ctx* c) {
+    const loco_unet_cfg& cfg = c->cfg;
+    const int ch = cfg.ch, nlev = cfg.num_levels, R = cfg.resolution;
+    const int Rout = R << (nlev - 1);
+    c->n_in = cfg.in_channels * R * R;
+    c->n_out = cfg.out_ch * Rout * Rout;
+    auto add_res = [&](const std::string& name, int in_t, int cout) {
+        Op r; r.kind = OP_RES; r.name = name; r.in = in_t; r.has_temb = false;
+        const Tens ti = c->tens[in_t];
+        r.has_nin = (ti.C != cout);
+        r.out = new_tensor(c, cout, ti.H, ti.W);
+        r.h1 = new_tensor(c, cout, ti.H, ti.W);
+        r.a1 = new_tensor(c, ti.C, ti.H, ti.W);
+        r.n1 = new_norm(c, ti.C); r.n2 = new_norm(c, cout);
+        c->ops.push_back(r);
+        return r.out;
+    };
+    auto add_attn = [&](const std::string& name, int in_t) {
+        Op a; a.kind = OP_ATTN; a.name = name; a.in = in_t;
+        const Tens t = c->tens[in_t];
+        const int T = t.H * t.W;
+        a.out = new_tensor(c, t.C, t.H, t.W);
+        a.hn = new_tensor(c, t.C, t.H, t.W);
+        a.qkv = new_tensor(c, 3 * t.C, t.H, t.W);
+        a.S = new_tensor(c, 1, T, T);
+        a.o = new_tensor(c, t.C, t.H, t.W);
+        a.n1 = new_norm(c, t.C);
+        c->ops.push_back(a);
+        return a.out;
+    };
+    int res = R, block_in = ch * cfg.ch_mult[nlev - 1];
+    int cur;
+    {
+        Op o; o.kind = OP_CONV_IN; o.name = "conv_in"; o.in = -1; o.out = new_tensor(c, block_in, res, res);
+        c->ops.push_back(o);
+        cur = o.out;
+    }
+    cur = add_res("mid.block_1", cur, block_in);
+    cur = add_attn("mid.attn_1", cur);
+    cur = add_res("mid.block_2", cur, block_in);
+    for (int l = nlev - 1; l >= 0; --l) {
+        const int block_out = ch * cfg.ch_mult[l];
+        for (int b = 0; b < cfg.num_res_blocks + 1; ++b) {
+            cur = add_res("up." + std::to_string(l) + ".block." + std::to_string(b), cur, block_out);
+            if (attn_at(cfg, res)) cur = add_attn("up." + std::to_string(l) + ".attn." + std::to_string(b), cur);
+            block_in = block_out;
+        }
+        if (l != 0) {
+            Op u; u.kind = OP_UP; u.name = "up." + std::to_string(l) + ".upsample.conv";
+            u.in = cur; u.out = new_tensor(c, block_in, res * 2, res * 2);
+            u.up = new_tensor(c, block_in, res * 2, res * 2);
+            c->ops.push_back(u);
+            cur = u.out;
+            res *= 2;
+        }
+    }
+    {
+        Op o; o.kind = OP_OUT; o.name = "conv_out"; o.in = cur;
+        o.out = new_tensor(c, cfg.out_ch, Rout, Rout);
+        o.a1 = new_tensor(c, c->tens[cur].C, Rout, Rout);
+        o.n1 = new_norm(c, c->tens[cur].C);
+        c->ops.push_back(o);
+        c->eps_t = o.out;
+    }
+    for (auto& op : c->ops) {
+        if (op.kind == OP_RES) {
+            const Tens& ti = c->tens[op.in];
+            norm_cache(c, op.n1, ti.H * ti.W);
+            norm_cache(c, op.n2, ti.H * ti.W);
+            op.pn_n1 = op.name + ".norm1"; op.pn_c1 = op.name + ".conv1";
+            op.pn_n2 = op.name + ".norm2"; op.pn_c2 = op.name + ".conv2"; op.pn_skip = op.name + ".nin_shortcut";
+        } else if (op.kind == OP_ATTN) {
+            op.pn_n1 = op.name + ".norm"; op.pn_proj = op.name + ".proj_out";
+        } else if (op.kind == OP_OUT) {
+            const Tens& ti = c->tens[op.in];
+            norm_cache(c, op.n1, ti.H * ti.W);
+            op.pn_n1 = "norm_out"; op.pn_conv = "conv_out";
+        } else {
+            op.pn_conv = op.name;
+        }
+    }
+    return 0;
+}
+
 void declare_param(loco_ctx* c, const std::string& name, std::vector<int64_t> shape) {
     HostParam hp; hp.shape = shape;
     c->params[name] = hp;
@@ -546,8 +642,10 @@ void declare_all(loco_ctx* c) {
     const loco_unet_cfg& cfg = c->cfg;
     const bool adm = cfg.arch == 1;
     int temb_ch = cfg.ch * 4;
-    declare_lin(c, adm ? "time_embed.0" : "temb.dense.0", cfg.ch, temb_ch);
-    declare_lin(c, adm ? "time_embed.2" : "temb.dense.1", temb_ch, temb_ch);
+    if (cfg.arch != 2) {
+        declare_lin(c, adm ? "time_embed.0" : "temb.dense.0", cfg.ch, temb_ch);
+        declare_lin(c, adm ? "time_embed.2" : "temb.dense.1", temb_ch, temb_ch);
+    }
     for (auto& op : c->ops) {
         switch (op.kind) {
             case OP_CONV_IN: declare_conv(c, op.pn_conv, cfg.in_channels, c->tens[op.out].C, 3); break;
@@ -555,7 +653,7 @@ void declare_all(loco_ctx* c) {
                 int cin = c->tens[op.in].C, cout = c->tens[op.out].C;
                 declare_norm(c, op.pn_n1, cin);
                 declare_conv(c, op.pn_c1, cin, cout, 3);
-                declare_lin(c, op.pn_emb, temb_ch, op.scale_shift ? 2 * cout : cout);
+                if (op.has_temb) declare_lin(c, op.pn_emb, temb_ch, op.scale_shift ? 2 * cout : cout);
                 declare_norm(c, op.pn_n2, cout);
                 declare_conv(c, op.pn_c2, cout, cout, 3);
                 if (op.has_nin) declare_conv(c, op.pn_skip, cin, cout, 1);
@@ -705,10 +803,12 @@ int finalize_params(loco_ctx* c) {
     int temb_ch = cfg.ch * 4;
     const bool adm = cfg.arch == 1;
     const std::string te0 = adm ? "time_embed.0" : "temb.dense.0", te1 = adm ? "time_embed.2" : "temb.dense.1";
-    if (upload(c, &c->td0w, c->params[te0 + ".weight"].data)) return -1;
-    if (upload(c, &c->td0b, c->params[te0 + ".bias"].data)) return -1;
-    if (upload(c, &c->td1w, c->params[te1 + ".weight"].data)) return -1;
-    if (upload(c, &c->td1b, c->params[te1 + ".bias"].data)) return -1;
+    if (cfg.arch != 2) {
+        if (upload(c, &c->td0w, c->params[te0 + ".weight"].data)) return -1;
+        if (upload(c, &c->td0b, c->params[te0 + ".bias"].data)) return -1;
+        if (upload(c, &c->td1w, c->params[te1 + ".weight"].data)) return -1;
+        if (upload(c, &c->td1b, c->params[te1 + ".bias"].data)) return -1;
+    }
     // sinusoid frequencies exactly as torch computes them in fp32:
     //   DDPM: exp(float32(i) * float32(-ln(1e4)/(half-1)))            (diffusion.py:797-798)
     //   ADM : exp(float32(-ln(1e4)) * float32(i) / float32(half))     (guided_diffusion/nn.py:113-115)
@@ -731,6 +831,7 @@ int finalize_params(loco_ctx* c) {
                 if (make_norm(c, op.pn_n1, &op.n1) || make_norm(c, op.pn_n2, &op.n2)) return -1;
                 if (make_conv1(c, op.pn_c1, &op.c1) || make_conv1(c, op.pn_c2, &op.c2)) return -1;
                 if (op.has_nin && make_conv1(c, op.pn_skip, &op.nin)) return -1;
+                if (!op.has_temb) break;
                 op.tproj_off = (long)tpb.size();
                 auto& w = c->params[op.pn_emb + ".weight"].data;
                 auto& b = c->params[op.pn_emb + ".bias"].data;
@@ -757,7 +858,7 @@ int finalize_params(loco_ctx* c) {
     }
     c->tproj_total = (long)tpb.size();
     if (upload(c, &c->tp_w, tpw) || upload(c, &c->tp_b, tpb)) return -1;
-    if (dalloc(c, &c->tact, (size_t)temb_ch) || dalloc(c, &c->tproj, (size_t)c->tproj_total)) return -1;
+    if (dalloc(c, &c->tact, (size_t)temb_ch) || dalloc(c, &c->tproj, (size_t)(c->tproj_total > 0 ? c->tproj_total : 1))) return -1;
     // FLOP model (2*MAC): convolutions + attention products
     double fl = 0.0;
     for (auto& op : c->ops) {
@@ -900,9 +1001,11 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
     const loco_unet_cfg& cfg = c->cfg;
     Pass p{c, st, B, arena, stats};
     const long SB = c->stats_per_sample;
-    launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st, cfg.arch == 1,
-                c->has_cond ? c->cond_add : nullptr, t_ptr);
-    launch_temb_proj(c->tact, cfg.ch * 4, c->tp_w, c->tp_b, (int)c->tproj_total, c->tproj, st);
+    if (cfg.arch != 2) {
+        launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st, cfg.arch == 1,
+                    c->has_cond ? c->cond_add : nullptr, t_ptr);
+        launch_temb_proj(c->tact, cfg.ch * 4, c->tp_w, c->tp_b, (int)c->tproj_total, c->tproj, st);
+    }
     for (auto& op : c->ops) {
         const Tens& to = c->tens[op.out];
         const int HW = to.H * to.W;
@@ -923,7 +1026,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 ConvArgs a; conv_defaults(a);
                 a.Cin = ti.C;
                 setw(a, op.c1, false); a.bias = op.c1.bias;
-                if (!op.scale_shift) { a.bias2 = c->tproj + op.tproj_off; a.bias2_bs = 0; }
+                if (!op.scale_shift && op.has_temb) { a.bias2 = c->tproj + op.tproj_off; a.bias2_bs = 0; }
                 if (op.updown == 1) {
                     // h = conv(avg_pool(silu(gn(x)))), x' = avg_pool(x)      (unet.py:198-200, 239-244)
                     launch_gn_apply(4, nullptr, 0, p.T(op.in), p.bs(), nullptr, 0, p.T(op.a1), p.bs(), 0, B, ti.C, HWi,
@@ -1198,7 +1301,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
             case OP_OUT: {
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
-                a.in = ge; a.in_bs = c->n_in; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
+                a.in = ge; a.in_bs = c->n_out; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
                 setw(a, op.conv, true);
                 a.out = TG(op.a1); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
                 run_conv(c, a, 9, st);
@@ -1365,7 +1468,7 @@ struct LaneSwap {
         arenaT = c->arenaT; statsT = c->statsT; partial = c->partial; eps_buf = c->eps_buf; ge = c->ge; gx0 = c->gx0;
         red = c->red; partial_floats = c->partial_floats;
         c->arenaT += (long)s0 * c->per_sample; c->statsT += (long)s0 * c->stats_per_sample;
-        c->eps_buf += (long)s0 * c->n_in; c->ge += (long)s0 * c->n_in; c->gx0 += (long)s0 * c->n_in;
+        c->eps_buf += (long)s0 * c->n_out; c->ge += (long)s0 * c->n_out; c->gx0 += (long)s0 * c->n_in;
         c->partial += partial_floats / 2; c->partial_floats = partial_floats / 2;
         c->red = c->red2;
     }
@@ -1422,6 +1525,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
     {
         int r = cfg->resolution;
         for (int l = 0; l < cfg->num_levels - 1; ++l) r /= 2;
+        if (cfg->arch == 2) r = cfg->resolution;      // decoder: `resolution` is the coarsest (latent) level
         if (r < 8 || (cfg->resolution & (cfg->resolution - 1))) {
             c->err = "resolution must be a power of two with >= 8x8 at the coarsest level";
             return -2;
@@ -1443,7 +1547,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
     c->partial_floats = (size_t)64 << 20;   // 256 MB split-K workspace
     if (dalloc(c, &c->partial, c->partial_floats)) return -1;
     if (dalloc(c, &c->xin_buf, MB * c->n_in) || dalloc(c, &c->t_dev, 4)) return -1;
-    if (dalloc(c, &c->eps_buf, MB * c->n_in) || dalloc(c, &c->gx0, MB * c->n_in) || dalloc(c, &c->ge, MB * c->n_in))
+    if (dalloc(c, &c->eps_buf, MB * c->n_out) || dalloc(c, &c->gx0, MB * c->n_in) || dalloc(c, &c->ge, MB * c->n_out))
         return -1;
     if (dalloc(c, &c->tmpA, (size_t)64 * c->n_in)) return -1;
     if (dalloc(c, &c->G, 64 * 64) || dalloc(c, &c->Q, 64 * 64) || dalloc(c, &c->W, 64)) return -1;
@@ -1463,7 +1567,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         const char* t = getenv("LOCO_BF16_TILE");
         if (t) g_bf16_tile_override = atoi(t);
     }
-    if (dalloc(c, &c->mask, (size_t)c->n_in) || dalloc(c, &c->mask_idx, (size_t)c->n_in) ||
+    if (dalloc(c, &c->mask, (size_t)c->n_out) || dalloc(c, &c->mask_idx, (size_t)c->n_out) ||
         dalloc(c, &c->mask_L_dev, 4)) return -1;
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
@@ -1536,12 +1640,9 @@ int loco_params_missing(loco_ctx* c) {
 // Capture one denoiser evaluation of batch B (fixed input xin_buf, timestep read from t_dev, output in the primal
 // arena) on the engine's own stream; nothing executes during the capture.
 static int capture_forward(loco_ctx* c, int B, loco_ctx::FwdGraph& g) {
-    const double f0 = c->flops;
     HIPCHK(c, hipStreamBeginCapture(c->cap_st, hipStreamCaptureModeThreadLocal));
     int rc = forward_pass(c, c->xin_buf, 0.f, B, c->arenaP, c->statsP, c->cap_st, c->t_dev);
     hipError_t e = hipStreamEndCapture(c->cap_st, &g.graph);
-    g.flops = c->flops - f0;
-    c->flops = f0;
     if (rc) { if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; } return rc; }
     HIPCHK(c, e);
     HIPCHK(c, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
@@ -1563,16 +1664,15 @@ int loco_unet_forward(loco_ctx* c, const float* x, float t, int32_t B, float* ep
             launch_copy(x, c->n_in, c->xin_buf, c->n_in, 0, B, c->n_in, st);
             launch_set_scalar(c->t_dev, t, st);
             HIPCHK(c, hipGraphLaunch(g.exec, st));
-            c->flops += g.flops;
             c->primal_B = B;
-            launch_copy(c->arenaP + c->tens[c->eps_t].off, c->per_sample, eps, c->n_in, 0, B, c->n_in, st);
+            launch_copy(c->arenaP + c->tens[c->eps_t].off, c->per_sample, eps, c->n_out, 0, B, c->n_out, st);
             HIPCHK(c, hipGetLastError());
             return 0;
         }
     }
     if (forward_pass(c, x, t, B, c->arenaP, c->statsP, st)) return -1;
     c->primal_B = B;
-    launch_copy(c->arenaP + c->tens[c->eps_t].off, c->per_sample, eps, c->n_in, 0, B, c->n_in, st);
+    launch_copy(c->arenaP + c->tens[c->eps_t].off, c->per_sample, eps, c->n_out, 0, B, c->n_out, st);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1606,6 +1706,7 @@ int loco_ddim_step(loco_ctx* c, const float* x, float t, float at, float at_next
                    int32_t B, float* x_next, void* stream) {
     if (!c) return -2;
     if (eta != 0.f && !noise) { c->err = "eta != 0 needs a noise tensor"; return -2; }
+    if (c->n_out != c->n_in) { c->err = "loco_ddim_step: this network is not a denoiser (output and input sizes differ)"; return -2; }
     int rc = loco_unet_forward(c, x, t, B, c->eps_buf, stream);
     if (rc) return rc;
     return loco_sched_step(c, x, c->eps_buf, at, at_next, eta, noise, (int64_t)B * c->n_in, x_next, nullptr, stream);
@@ -1615,6 +1716,11 @@ int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_
                     void* stream) {
     if (!c) return -2;
     if (finalize_params(c)) return -3;
+    if (c->n_out != c->n_in && !use_et) {
+        c->err = "loco_pmp_primal: a network whose output size differs from its input has no x0 combination; use_et = 1 "
+                 "(raw network Jacobian)";
+        return -2;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (forward_pass(c, x, t, 1, c->arenaP, c->statsP, st)) return -1;
     c->primal_B = 1;
@@ -1638,12 +1744,12 @@ int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_
     if (use_et) { c->p_cv = 0.f; c->p_ce = 1.f; }
     else { c->p_cv = 1.0f / std::sqrt(at); c->p_ce = -std::sqrt(1.0f - at) / std::sqrt(at); }
     c->has_mask = (mask != nullptr);
-    c->mask_L = c->n_in;
+    c->mask_L = c->n_out;
     if (mask) {
         // masked-latent gather list built on the device (ordered prefix-sum compaction, one launch, no host sync);
         // L is read back lazily by loco_mask_count / loco_mask_gather
-        HIPCHK(c, hipMemcpyAsync(c->mask, mask, (size_t)c->n_in, hipMemcpyDeviceToDevice, st));
-        launch_mask_compact(c->mask, c->n_in, c->mask_idx, c->mask_L_dev, st);
+        HIPCHK(c, hipMemcpyAsync(c->mask, mask, (size_t)c->n_out, hipMemcpyDeviceToDevice, st));
+        launch_mask_compact(c->mask, c->n_out, c->mask_idx, c->mask_L_dev, st);
         c->mask_L = -1;
         c->mask_stream = st;
     }
@@ -1663,9 +1769,9 @@ int loco_pmp_jvp(loco_ctx* c, const float* V, int32_t k, float* U, void* stream)
             const float* Vc = V + (long)(b0 + s0) * c->n_in;
             if (tangent_pass(c, Vc, nb, ls)) return -1;
             // U = mask * (cv*V + ce*dEps); dEps lives strided in arena T -> gather through eps_buf
-            launch_copy(c->arenaT + c->tens[c->eps_t].off, c->per_sample, c->eps_buf, c->n_in, 0, nb, c->n_in, ls);
-            launch_masked_axpby(Vc, c->eps_buf, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce,
-                                U + (long)(b0 + s0) * c->n_in, nb, c->n_in, ls);
+            launch_copy(c->arenaT + c->tens[c->eps_t].off, c->per_sample, c->eps_buf, c->n_out, 0, nb, c->n_out, ls);
+            launch_masked_axpby(c->n_out == c->n_in ? Vc : nullptr, c->eps_buf, c->has_mask ? c->mask : nullptr, c->p_cv,
+                                c->p_ce, U + (long)(b0 + s0) * c->n_out, nb, c->n_out, ls);
             return 0;
         });
         if (rc) return rc;
@@ -1682,9 +1788,10 @@ int loco_pmp_vjp(loco_ctx* c, const float* U, int32_t k, float* A, void* stream)
     for (int b0 = 0; b0 < k; b0 += MB) {
         int B = (k - b0 < MB) ? k - b0 : MB;
         int rc = run_lanes(c, B, st, [&](int s0, int nb, hipStream_t ls) -> int {
-            launch_cot_seed(U + (long)(b0 + s0) * c->n_in, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce, c->ge, c->gx0,
-                            nb, c->n_in, ls);
-            return cotangent_pass(c, c->ge, c->gx0, A + (long)(b0 + s0) * c->n_in, nb, ls);
+            const bool same = c->n_out == c->n_in;
+            launch_cot_seed(U + (long)(b0 + s0) * c->n_out, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce, c->ge,
+                            same ? c->gx0 : nullptr, nb, c->n_out, ls);
+            return cotangent_pass(c, c->ge, same ? c->gx0 : nullptr, A + (long)(b0 + s0) * c->n_in, nb, ls);
         });
         if (rc) return rc;
     }
@@ -1771,12 +1878,12 @@ int loco_mask_gather(loco_ctx* c, const float* U, int32_t k, float* out, void* s
     if (!c->primal_ok) { c->err = "loco_pmp_primal has not been called"; return -2; }
     hipStream_t st = (hipStream_t)stream;
     if (!c->has_mask) {
-        HIPCHK(c, hipMemcpyAsync(out, U, (size_t)k * c->n_in * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(out, U, (size_t)k * c->n_out * sizeof(float), hipMemcpyDeviceToDevice, st));
         return 0;
     }
     const long L = mask_count_lazy(c);
     if (L < 0) { c->err = "mask count readback failed"; return -1; }
-    if (L > 0) launch_mask_gather(U, c->mask_idx, L, c->n_in, k, out, st);
+    if (L > 0) launch_mask_gather(U, c->mask_idx, L, c->n_out, k, out, st);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1824,7 +1931,7 @@ int loco_masked_axpby(loco_ctx* c, const float* V, const float* E, float cv, flo
                       void* stream) {
     if (!c) return -2;
     if (!c->primal_ok) { c->err = "loco_pmp_primal has not been called"; return -2; }
-    launch_masked_axpby(V, E, c->has_mask ? c->mask : nullptr, cv, ce, out, k, c->n_in, (hipStream_t)stream);
+    launch_masked_axpby(V, E, c->has_mask ? c->mask : nullptr, cv, ce, out, k, c->n_out, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

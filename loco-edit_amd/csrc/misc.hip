@@ -350,7 +350,8 @@ void launch_gn_cache(const float* x, int C, int HW, int cpg, const float* sc, co
 }
 
 // ---------------------------------------------------------------------------
-// softmax over rows of length T (T <= 1024, multiple of 64): one wave per row
+// softmax over rows of length T (multiple of 64): one wave per row; rows up to 1024 stay in registers, longer ones
+// (the decoder's 64x64 = 4096-token mid attention) are streamed three times through the cache
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, long rows, int T, long bs) {
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -359,6 +360,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, long rows, 
     float v[16];
     const int per = T / 64;
     float mx = -INFINITY;
+    if (per > 16) {
+        for (int i = 0; i < per; ++i) mx = fmaxf(mx, p[lane + i * 64]);
+        mx = wave_maxf(mx);
+        mx = __shfl(mx, 0, 64);
+        float sum = 0.f;
+        for (int i = 0; i < per; ++i) sum += expf(p[lane + i * 64] - mx);
+        sum = wave_sumf(sum);
+        sum = __shfl(sum, 0, 64);
+        const float inv = 1.0f / sum;
+        for (int i = 0; i < per; ++i) p[lane + i * 64] = expf(p[lane + i * 64] - mx) * inv;
+        return;
+    }
     for (int i = 0; i < per; ++i) {
         v[i] = p[lane + i * 64];
         mx = fmaxf(mx, v[i]);
@@ -389,6 +402,13 @@ __global__ __launch_bounds__(256) void softmax_jac_kernel(float* dS, const float
     const int per = T / 64;
     float dv[16], pv[16];
     float dot = 0.f;
+    if (per > 16) {
+        for (int i = 0; i < per; ++i) dot += d[lane + i * 64] * p[lane + i * 64];
+        dot = wave_sumf(dot);
+        dot = __shfl(dot, 0, 64);
+        for (int i = 0; i < per; ++i) d[lane + i * 64] = scale * p[lane + i * 64] * (d[lane + i * 64] - dot);
+        return;
+    }
     for (int i = 0; i < per; ++i) {
         dv[i] = d[lane + i * 64];
         pv[i] = p[lane + i * 64];
@@ -564,7 +584,7 @@ __global__ void masked_axpby_kernel(const float* V, const float* dE, const uint8
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long j = i % n;
         float m = (!mask || mask[j]) ? 1.f : 0.f;
-        U[i] = m * (cv * V[i] + ce * dE[i]);
+        U[i] = m * ((V ? cv * V[i] : 0.f) + ce * dE[i]);      // V == nullptr: output and input sizes differ (raw network Jacobian)
     }
 }
 void launch_masked_axpby(const float* V, const float* dE, const uint8_t* mask, float cv, float ce, float* U, int k,
@@ -581,7 +601,7 @@ __global__ void cot_seed_kernel(const float* U, const uint8_t* mask, float cv, f
         long j = i % n;
         float u = (!mask || mask[j]) ? U[i] : 0.f;
         gE[i] = ce * u;
-        gX0[i] = cv * u;
+        if (gX0) gX0[i] = cv * u;
     }
 }
 void launch_cot_seed(const float* U, const uint8_t* mask, float cv, float ce, float* gE, float* gX0, int k, long n,

@@ -138,14 +138,15 @@ class LocoEngine:
         for i, r in enumerate(cfg.attn_resolutions):
             c.attn_resolutions[i] = r
         c.gn_groups, c.gn_eps, c.max_batch = cfg.gn_groups, cfg.gn_eps, self.max_batch
-        c.arch = 1 if cfg.arch == "adm" else 0
+        c.arch = {"ddpm": 0, "adm": 1, "dec": 2}[cfg.arch]
         c.num_head_channels, c.learn_sigma = cfg.num_head_channels, int(cfg.learn_sigma)
         self._ctx = C.c_void_p()
         rc = self.lib.loco_create(C.byref(c), C.byref(self._ctx))
         if rc != 0:
             msg = self.lib.loco_last_error(self._ctx).decode() if self._ctx else "?"
             raise RuntimeError(f"loco_create failed ({rc}): {msg}")
-        self.n = cfg.n
+        self.n = cfg.n              # elements of the network input (image / latent)
+        self.n_out = cfg.n_out      # elements of its output (= n for the denoisers; the decoded image for arch "dec")
 
     def __del__(self):
         try:
@@ -174,7 +175,11 @@ class LocoEngine:
     # ---- denoiser
     def unet_forward(self, x: torch.Tensor, t: float) -> torch.Tensor:
         _chk_dev(x)
-        eps = torch.empty_like(x)
+        if self.cfg.arch == "dec":      # decoder: [B, z, R, R] -> [B, out_ch, R_out, R_out]
+            eps = torch.empty(x.shape[0], self.cfg.out_ch, self.cfg.out_resolution, self.cfg.out_resolution,
+                              device=x.device, dtype=torch.float32)
+        else:
+            eps = torch.empty_like(x)
         self._check(self.lib.loco_unet_forward(self._ctx, _ptr(x), float(t), x.shape[0], _ptr(eps), _stream()),
                     "loco_unet_forward")
         return eps
@@ -204,8 +209,8 @@ class LocoEngine:
         m8 = None
         if mask is not None:
             m8 = mask.to(device=x.device, dtype=torch.uint8).contiguous().view(-1)
-            if m8.numel() != self.n:
-                raise ValueError("mask must have C*H*W elements")
+            if m8.numel() != self.n_out:
+                raise ValueError("mask must have C*H*W elements (of the network output)")
         self._mask_keepalive = m8
         self._check(self.lib.loco_pmp_primal(self._ctx, _ptr(x), float(t), float(at), _ptr(m8), int(use_et),
                                              _stream()), "loco_pmp_primal")
@@ -213,7 +218,7 @@ class LocoEngine:
     def pmp_jvp(self, V: torch.Tensor) -> torch.Tensor:
         _chk_dev(V)
         k = V.shape[0]
-        U = torch.empty(k, self.n, device=V.device, dtype=torch.float32)
+        U = torch.empty(k, self.n_out, device=V.device, dtype=torch.float32)
         self._check(self.lib.loco_pmp_jvp(self._ctx, _ptr(V), k, _ptr(U), _stream()), "loco_pmp_jvp")
         return U
 

@@ -126,6 +126,47 @@ def unet_forward(p: Dict[str, torch.Tensor], cfg, x: torch.Tensor, t: torch.Tens
 
 
 # --------------------------------------------------------------------------
+# Latent decoder: the network behind ``self.vae.decode(z).sample`` in the reference's Stable Diffusion path
+# (edit.py:750, 770-771).  diffusers' AutoencoderKL is un-vendored; its decoder is the latent-diffusion ``Decoder``,
+# i.e. the up half of the module tree above without skip inputs and with ``temb_channels = 0`` (ResnetBlock without
+# ``temb_proj``), restated here from that published structure.  Parity of the architecture is unpinned (no diffusers,
+# no weights offline); the engine is checked against this restatement.
+# --------------------------------------------------------------------------
+def _resblock_noemb(p, name, x, cfg):
+    h = F.conv2d(_swish(_gn(p, name + ".norm1", x, cfg)), p[name + ".conv1.weight"], p[name + ".conv1.bias"], padding=1)
+    h = F.conv2d(_swish(_gn(p, name + ".norm2", h, cfg)), p[name + ".conv2.weight"], p[name + ".conv2.bias"], padding=1)
+    if (name + ".nin_shortcut.weight") in p:
+        x = F.conv2d(x, p[name + ".nin_shortcut.weight"], p[name + ".nin_shortcut.bias"])
+    return x + h
+
+
+def decoder_forward(p: Dict[str, torch.Tensor], cfg, z: torch.Tensor, trace: Optional[dict] = None) -> torch.Tensor:
+    """z [B, z_ch, R, R] -> image [B, out_ch, R * 2^(levels-1), same]."""
+    def rec(name, v):
+        if trace is not None:
+            trace[name] = v.detach().clone()
+        return v
+    nlev = len(cfg.ch_mult)
+    res = cfg.resolution
+    h = rec("conv_in", F.conv2d(z, p["conv_in.weight"], p["conv_in.bias"], padding=1))
+    h = rec("mid.block_1", _resblock_noemb(p, "mid.block_1", h, cfg))
+    h = rec("mid.attn_1", _attn(p, "mid.attn_1", h, cfg))
+    h = rec("mid.block_2", _resblock_noemb(p, "mid.block_2", h, cfg))
+    for lvl in reversed(range(nlev)):
+        for b in range(cfg.num_res_blocks + 1):
+            h = rec(f"up.{lvl}.block.{b}", _resblock_noemb(p, f"up.{lvl}.block.{b}", h, cfg))
+            if res in cfg.attn_resolutions:
+                h = rec(f"up.{lvl}.attn.{b}", _attn(p, f"up.{lvl}.attn.{b}", h, cfg))
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = rec(f"up.{lvl}.upsample.conv",
+                    F.conv2d(h, p[f"up.{lvl}.upsample.conv.weight"], p[f"up.{lvl}.upsample.conv.bias"], padding=1))
+            res *= 2
+    h = _swish(_gn(p, "norm_out", h, cfg))
+    return F.conv2d(h, p["conv_out.weight"], p["conv_out.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------
 # Denoiser B: guided-diffusion / P2 U-Net (reference src/models/guided_diffusion/unet.py, P2_DICT)
 # --------------------------------------------------------------------------
 def timestep_embedding_adm(t: torch.Tensor, dim: int) -> torch.Tensor:
