@@ -75,7 +75,9 @@ _FLAGS = [
     ('edit_t_idx', _I, 1), ('num_inference_steps', _I, 3), ('random_edit', 'bool', 'False'),
 ]
 _UNET_PRESETS = {'celeba_ddpm': 'CELEBA_DDPM', 'ffhq_p2': 'FFHQ_P2', 'tiny_ddpm': 'TINY_DDPM', 'mid_ddpm': 'MID_DDPM',
-                 'tiny_adm': 'TINY_ADM', 'if64_standin': 'IF64_STANDIN'}
+                 'tiny_adm': 'TINY_ADM', 'if64_standin': 'IF64_STANDIN', 'sd64_standin': 'SD64_STANDIN',
+                 'tiny_latent': 'TINY_LATENT'}
+_VAE_PRESETS = {'sd_vae_decoder': 'SD_VAE_DECODER', 'tiny_decoder': 'TINY_DECODER'}
 _TILDA_V = ["proj_null[for-null](edit-null)-direct", "(for-edit)-direct", "(edit-null)-direct",
             "null+(for-null)+(edit-null)", "null+(for-null)", "null+(edit-null)", "(for-edit)",
             "edit-proj[for](edit)", "null+for+edit-proj[for](edit)"]
@@ -94,6 +96,9 @@ def build_parser():
     p.add_argument('--max_batch', type=int, default=8, help='largest image/probe batch resident on the GPU')
     p.add_argument('--unet_preset', type=str, default=None, choices=sorted(_UNET_PRESETS),
                    help='override the architecture --model_name implies (small parity-test sizes)')
+    p.add_argument('--vae_preset', type=str, default=None, choices=sorted(_VAE_PRESETS),
+                   help='latent T-LOCO: decoder architecture (default: the Stable Diffusion autoencoder decoder geometry)')
+    p.add_argument('--vae_ckpt_path', type=str, default='', help='latent T-LOCO: decoder state_dict in latent-diffusion `Decoder` naming')
     p.add_argument('--prompt_emb_path', type=str, default='',
                    help="T-LOCO: torch file {'for','edit','null': [1, tokens, D]} of prompt embeddings (the text encoder is out of scope)")
     p.add_argument('--cond_dim', type=int, default=16, help='T-LOCO stand-in: width of seeded prompt embeddings when no file is given')
@@ -108,6 +113,9 @@ def parse_args(argv=None):
     if args.unet_preset:
         from . import config
         args.unet_config = getattr(config, _UNET_PRESETS[args.unet_preset])
+    if args.vae_preset:
+        from . import config
+        args.vae_config = getattr(config, _VAE_PRESETS[args.vae_preset])
     return args
 
 
@@ -120,13 +128,18 @@ def preset(args):
     if args.seed == 0:
         args.seed = int(torch.randint(2**32, ()))
     seed_everything(args.seed)
-    if any(s in args.model_name for s in ('stable-diffusion', 'LCM')):
-        raise NotImplementedError('latent-space T-LOCO (Stable Diffusion / LCM: VAE-decoder Jacobian) is outside this build '
-                                  '(SURVEY.md 8f.2); the pixel-space DeepFloyd-IF path is loco_edit_amd.tloco')
-    args.is_stable_diffusion = args.is_LCM = False
-    args.is_DeepFloyd_IF_diffusion = 'DeepFloyd' in args.model_name
+    # routing by model name, define_argparser.py:147-165
+    args.is_stable_diffusion = 'stable-diffusion' in args.model_name
+    args.is_DeepFloyd_IF_diffusion = (not args.is_stable_diffusion) and 'DeepFloyd' in args.model_name
+    args.is_LCM = (not args.is_stable_diffusion) and (not args.is_DeepFloyd_IF_diffusion) and 'LCM' in args.model_name
+    if args.is_LCM:
+        raise NotImplementedError('the latent-consistency path (EditLatentConsistency, edit.py:42-481: LCM scheduler, guidance '
+                                  'embedding) is outside this build; Stable Diffusion is loco_edit_amd.tloco_sd, DeepFloyd-IF '
+                                  'loco_edit_amd.tloco')
+    if args.is_stable_diffusion:
+        return _preset_t2i(args, 'Stable_Diffusion')
     if args.is_DeepFloyd_IF_diffusion:
-        return _preset_deepfloyd(args)
+        return _preset_t2i(args, 'DeepFloyd-IF')
     # model-name gate of define_argparser.py:166-176 (`unet_config` = an explicit architecture, tests / tiny configs)
     if getattr(args, 'unet_config', None) is None:
         if args.model_name == 'CelebA_HQ':
@@ -160,9 +173,10 @@ def preset(args):
     return args
 
 
-def _preset_deepfloyd(args):
-    """define_argparser.py:155-160, 219-223, 236-239 for the DeepFloyd-IF (pixel-space T-LOCO) branch."""
-    args.exp = f'DeepFloyd-IF-{args.dataset_name}-{args.note}'
+def _preset_t2i(args, family):
+    """define_argparser.py:147-160, 212-223, 236-239 for the text-to-image branches: Stable Diffusion (latent T-LOCO,
+    c_in 4, image_size 64) and DeepFloyd-IF (pixel-space T-LOCO, c_in 3, image_size 64)."""
+    args.exp = f'{family}-{args.dataset_name}-{args.note}'
     args.exp_folder = os.path.join(args.result_folder, args.exp)
     os.makedirs(args.exp_folder, exist_ok=True)
     sh = os.path.join('scripts', args.sh_file_name)
@@ -175,11 +189,18 @@ def _preset_deepfloyd(args):
     args.device = torch.device(args.device)
     args.dtype = torch.float32 if args.dtype == 'fp32' else torch.float16
     print(f'device : {args.device}, dtype : {args.dtype}')
-    if getattr(args, 'unet_config', None) is None:
-        from .config import IF64_STANDIN
-        args.unet_config = IF64_STANDIN
-    args.c_in = 3
-    args.image_size = args.unet_config.resolution          # 64 for the IF stage-I models
+    from . import config
+    if args.is_stable_diffusion:
+        if getattr(args, 'unet_config', None) is None:
+            args.unet_config = config.SD64_STANDIN
+        if getattr(args, 'vae_config', None) is None:
+            args.vae_config = config.SD_VAE_DECODER
+        args.c_in = args.unet_config.in_channels           # 4
+    else:
+        if getattr(args, 'unet_config', None) is None:
+            args.unet_config = config.IF64_STANDIN
+        args.c_in = 3
+    args.image_size = args.unet_config.resolution          # 64: SD latents and the IF stage-I models alike
     args.memory_bound = 5
     assert args.use_yh_custom_scheduler
     assert args.performance_boosting_t <= 0

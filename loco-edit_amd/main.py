@@ -1,5 +1,6 @@
 """CLI entry: ``python -m loco_edit_amd.main <flags>`` -- dispatch of reference
-``src/main.py:12-103`` for the unconditional (DDPM) models and the pixel-space DeepFloyd-IF T-LOCO path.
+``src/main.py:12-103`` for the unconditional (DDPM) models, the pixel-space DeepFloyd-IF and the latent-space
+Stable Diffusion T-LOCO paths.
 
 Multi-GPU: ``torchrun --nproc-per-node N -m loco_edit_amd.main <flags>`` runs one
 process per GPU; the Jacobian probes of each subspace solve are sharded over the
@@ -22,7 +23,11 @@ def main(argv=None):
         if args.seed == 0:
             args.seed = sh.agree(int(torch.randint(1, 2**32, ())))
     args = preset(args)
-    if args.is_DeepFloyd_IF_diffusion:           # main.py:24-26
+    if args.is_stable_diffusion:                 # main.py:21-23
+        from .tloco_sd import EditStableDiffusion
+        print('is stable-diffusion')
+        edit = EditStableDiffusion(args)
+    elif args.is_DeepFloyd_IF_diffusion:         # main.py:24-26
         from .tloco import EditDeepFloydIF
         print('is DeepFloyd-IF')
         edit = EditDeepFloydIF(args)
@@ -31,6 +36,16 @@ def main(argv=None):
         print('is custmized diffusion model')
         edit = EditUncondDiffusion(args)
     out = None
+    if args.run_edit_null_space_projection_zt:           # main.py:55-62
+        out = edit.run_edit_null_space_projection_zt(
+            op='mid', block_idx=0, mask_index=args.mask_index, vis_num=args.vis_num, vis_num_pc=args.pca_rank,
+            pca_rank=args.pca_rank, edit_prompt=args.edit_prompt, null_space_projection=args.null_space_projection,
+            pca_rank_null=args.pca_rank_null, non_semantic=args.non_semantic)
+    if args.run_edit_null_space_projection_zt_semantic:  # main.py:63-69
+        out = edit.run_edit_null_space_projection_zt_semantic(
+            op='mid', block_idx=0, mask_index=args.mask_index, vis_num=args.vis_num, vis_num_pc=args.pca_rank,
+            pca_rank=args.pca_rank, edit_prompt=args.edit_prompt, null_space_projection=args.null_space_projection,
+            pca_rank_null=args.pca_rank_null)
     if args.run_edit_null_space_projection_xt:           # main.py:70-76
         out = edit.run_edit_null_space_projection_xt(
             op='mid', block_idx=0, mask_index=args.mask_index, vis_num=args.vis_num, vis_num_pc=args.pca_rank,

@@ -69,3 +69,178 @@ def test_decoder_forward_jvp_vjp_vs_restatement(prec):
         if m is not None:
             assert eng.mask_count() == int(m.sum())
             assert torch.equal(eng.mask_gather(U).cpu(), U.cpu()[:, m.reshape(-1)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The latent T-LOCO class (loco_edit_amd.tloco_sd.EditStableDiffusion: per-prompt denoiser engines + decoder engine)
+# against the fixture produced by the reference's own EditStableDiffusion methods on the same stand-ins
+# (tests/golden/tloco_sd_tiny.pt).  Tolerances: single evaluation rel-L2 <= 2e-5 (f32) / 2e-4 (bf16x3) times the
+# chain length; solver s rtol 1e-3, |cos(vT_i)| >= 0.999; direction |cos| >= 0.9999.
+# ---------------------------------------------------------------------------------------------------------------------
+from argparse import Namespace  # noqa: E402
+
+from loco_edit_amd.config import TINY_LATENT  # noqa: E402
+
+
+def cosrow(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a * b).sum(dim=1) / (a.norm(dim=1) * b.norm(dim=1))).abs()
+
+
+def _edit_sd(g, tmp_path, prec, **kw):
+    from loco_edit_amd.tloco_sd import EditStableDiffusion
+    os.environ.pop("WORLD_SIZE", None)
+    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=TINY_LATENT, vae_config=TINY_DECODER,
+                     synthetic_weights=0, ckpt_path="", vae_ckpt_path="", max_batch=8, precision=prec, dataset_name="Random",
+                     for_steps=100, use_yh_custom_scheduler=True, guidance_scale=g["guidance_scale"],
+                     guidance_scale_edit=g["guidance_scale_edit"],
+                     prompt_emb={"for": g["for_e"], "edit": g["edit_e"], "null": g["null_e"]}, for_prompt="a man",
+                     edit_prompt="a man wearing glasses", edit_t=0.7, sampling_mode=False,
+                     tilda_v_score_type="null+(for-null)+(edit-null)", ablation_method="null-space-proj", mask_type="SAM",
+                     vT_path="", use_sega=kw.get("use_sega", False), x_space_guidance_edit_step=1.0,
+                     x_space_guidance_scale=0.5, x_space_guidance_num_step=16, result_folder=str(tmp_path))
+    return EditStableDiffusion(args)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_latent_tloco_pieces_vs_reference_golden(prec, golden, tmp_path):
+    g = golden("tloco_sd_tiny")
+    ed = _edit_sd(g, tmp_path, prec)
+    tol = TOL[prec]
+    z, t = g["z"].to(DEV), g["t"]
+    F, E, N = g["for_e"], g["edit_e"], g["null_e"]
+    assert ed.edit_t_idx == g["edit_t_idx"] and float(ed.scheduler.timesteps[ed.edit_t_idx]) == float(t)
+    # 0. decoder, 1. CFG noise (edit.py:636-674), 2. get_x0 with the decode (:757-781)
+    assert rel(ed.decode(g["dec_in"].to(DEV)), g["dec_out"]) < tol
+    zb = torch.cat([g["z"], g["z"].flip(-1)], dim=0).to(DEV)
+    for mode, ref in g["eps_modes"].items():
+        assert rel(ed._classifer_free_guidance(zb, t, F, E, N, mode, True), ref) < 4 * tol, mode
+    assert rel(ed.get_x0(z, t, ed.edit_t_idx, F, E, N, mask=g["mask"]), g["x0_masked"]) < 10 * tol
+    x0f = ed.get_x0(z, t, ed.edit_t_idx, F, E, N, mask=None, mode="null+(for-null)")
+    assert tuple(x0f.shape) == (1, 3, 64, 64) and rel(x0f, g["x0_full"]) < 10 * tol
+    # 3. subspace solver on the Jacobian of the decoded image (edit.py:830-915): mask and its complement
+    for key, sv in g["solver"].items():
+        u, s, vT = ed.local_encoder_decoder_pullback_zt(z, t, ed.edit_t_idx, F, E, N, pca_rank=3, min_iter=sv["n_iter"],
+                                                        max_iter=sv["n_iter"], mask=sv["mask"], mode=sv["mode"],
+                                                        v0=g["v0"].to(DEV), verbose=False)
+        assert ed.last_n_iter == sv["n_iter"] and u.shape == (int(sv["mask"].sum()), 3) and vT.shape == (3, TINY_LATENT.n)
+        assert torch.allclose(s.cpu(), sv["s"], rtol=1e-3), (key, s.cpu(), sv["s"])
+        assert cosrow(vT, sv["vT"]).min().item() > 0.999, key
+        assert torch.allclose(u.norm(dim=0).cpu(), sv["u_norms"], rtol=2e-3)
+    # 4. direction through the Jacobian (edit.py:784-828)
+    vg = ed.get_delta_zt_via_grad(z, t, ed.edit_t_idx, F, E, N, mask=g["mask"], mode="null+(for-null)+(edit-null)")
+    assert cosrow(vg, g["v_grad"]).item() > 0.9999 and abs(float(vg.norm()) - 1.0) < 1e-4
+    assert float(torch.sign((vg.cpu() * g["v_grad"]).sum())) == 1.0
+
+
+def test_latent_operator_adjoint_linear_and_finite_difference(golden, tmp_path):
+    g = golden("tloco_sd_tiny")
+    ed = _edit_sd(g, tmp_path, "f32")
+    z, t = g["z"].to(DEV), g["t"]
+    F, E, N = g["for_e"], g["edit_e"], g["null_e"]
+    mode = "null+(for-null)+(edit-null)"
+    op = ed._operator(z, t, g["mask"], mode)
+    gen = torch.Generator().manual_seed(3)
+    V = torch.randn(2, TINY_LATENT.n, generator=gen).to(DEV)
+    U = (torch.randn(2, TINY_DECODER.n_out, generator=gen) * g["mask"].reshape(1, -1)).to(DEV)
+    JV, JtU = op.jvp(V), op.vjp(U)
+    assert JV.shape == (2, TINY_DECODER.n_out) and JtU.shape == (2, TINY_LATENT.n)
+    lhs, rhs = (JV.double() * U.double()).sum(dim=1), (V.double() * JtU.double()).sum(dim=1)
+    assert ((lhs - rhs).abs() / (JV.norm(dim=1) * U.norm(dim=1)).double()).max().item() < 1e-4
+    assert float(JV[:, ~g["mask"].reshape(-1).to(DEV)].abs().max()) == 0.0
+    comb = (2.0 * V[0] - 0.5 * V[1])[None].contiguous()
+    assert rel(op.jvp(comb)[0], 2.0 * JV[0] - 0.5 * JV[1]) < 1e-4
+    h = 1e-2
+    v = (V[0] / V[0].norm()).view(1, 4, 16, 16)
+    fd = (ed.get_x0(z + h * v, t, ed.edit_t_idx, F, E, N, mask=g["mask"], mode=mode)
+          - ed.get_x0(z - h * v, t, ed.edit_t_idx, F, E, N, mask=g["mask"], mode=mode)) / (2 * h)
+    op = ed._operator(z, t, g["mask"], mode)          # the evaluations above overwrote the primal arenas
+    jv = op.gather(op.jvp((V[0] / V[0].norm())[None].contiguous()))
+    assert rel(jv, fd) < 2e-2
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_latent_sampler_and_decode_vs_reference_golden(prec, golden, tmp_path):
+    """DDIMforwardsteps (edit.py:677-754): z_T -> z_t at the edit step, then a 2-latent batch to scaled latents, the
+    decoded uint8 images and the PNG."""
+    import math
+    g = golden("tloco_sd_tiny")
+    ed = _edit_sd(g, tmp_path, prec)
+    F, E, N = g["for_e"], g["edit_e"], g["null_e"]
+    zt, t, i = ed.DDIMforwardsteps(g["zT"].to(DEV), 0, ed.edit_t_idx, F, E, N, mode="null+(for-null)")
+    assert i == g["edit_t_idx"] and float(t) == float(g["t_edit"])
+    ref = g["zt_edit"]
+    mse = ((zt.cpu().double() - ref.double()) ** 2).mean().item()
+    peak = float(ref.max() - ref.min())
+    assert 10 * math.log10(peak * peak / max(mse, 1e-30)) > (60 if prec == "f32" else 35)
+    ed.EXP_NAME = "dec"
+    lat, img = ed.DDIMforwardsteps(g["dec_lat_in"].to(DEV), ed.edit_t_idx, -1, F, E, N, mode="null+(for-null)")
+    assert img.dtype == torch.uint8 and tuple(img.shape) == tuple(g["dec_u8"].shape) == (2, 64, 64, 3)
+    assert tuple(lat.shape) == (2, 4, 16, 16)
+    differ = (img.cpu().int() - g["dec_u8"].int()).abs()
+    assert float((differ > 1).float().mean()) < (0.002 if prec == "f32" else 0.05)
+    assert os.path.exists(os.path.join(ed.result_folder, "dec.png"))
+
+
+def test_latent_drivers_end_to_end(golden, tmp_path):
+    """run_edit_null_space_projection_zt (edit.py:918-1041) and ..._zt_semantic (:1045-1174): files, shapes, unit norm,
+    orthogonality to the null basis, the sega branch."""
+    g = golden("tloco_sd_tiny")
+    ed = _edit_sd(g, tmp_path, "bf16x3")
+    masks = torch.zeros(2, 1, 64, 64, dtype=torch.bool)
+    masks[1, 0, 20:40, 12:44] = True
+    with pytest.raises(FileNotFoundError):
+        ed.run_edit_null_space_projection_zt(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1)
+    assert os.path.exists(os.path.join(ed.result_folder, "original.png"))       # the image SAM would have segmented
+    os.makedirs(os.path.join(ed.result_folder, "mask"))
+    torch.save(masks, os.path.join(ed.result_folder, "mask", "mask.pt"))
+    torch.manual_seed(5)
+    lat, x0 = ed.run_edit_null_space_projection_zt(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1,
+                                                   null_space_projection=True, pca_rank_null=2)
+    assert x0.dtype == torch.uint8 and tuple(x0.shape) == (5, 64, 64, 3) and tuple(lat.shape) == (5, 4, 16, 16)
+    bdir = os.path.join(ed.result_folder, "basis", "local_basis-0.7T-pca-rank-1-select-mask1")
+    for f in ("u-modify.pt", "vT-modify.pt", "u-null-null_space_rank_2.pt", "vT-null-null_space_rank_2.pt"):
+        assert os.path.exists(os.path.join(bdir, f)), f
+    vm, vn = torch.load(os.path.join(bdir, "vT-modify.pt")), torch.load(os.path.join(bdir, "vT-null-null_space_rank_2.pt"))
+    assert tuple(vm.shape) == (1, TINY_LATENT.n) and tuple(vn.shape) == (2, TINY_LATENT.n)
+    assert tuple(torch.load(os.path.join(bdir, "u-modify.pt")).shape) == (int(masks[1].sum()) * 3, 1)
+    proj = ed.engine.null_project(vm.to(DEV).contiguous(), vn.to(DEV).contiguous())
+    assert (vn.to(DEV).double() @ proj.double().T).abs().max().item() < 1e-5
+    torch.manual_seed(5)
+    lat2, x02 = ed.run_edit_null_space_projection_zt(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1,
+                                                     null_space_projection=True, pca_rank_null=2)     # cached basis
+    assert torch.equal(x02, x0)
+    torch.manual_seed(5)
+    lats, x0s = ed.run_edit_null_space_projection_zt_semantic(op="mid", block_idx=0, vis_num=1, mask_index=1, vis_num_pc=1,
+                                                              pca_rank=1, null_space_projection=True, pca_rank_null=2)
+    assert tuple(x0s.shape) == (3, 64, 64, 3)
+    sdir = os.path.join(ed.result_folder, "basis", 'local_basis-0.7T-"a man wearing glasses"-pca-rank-1-select-mask1')
+    v = torch.load(os.path.join(sdir, "vT-modify.pt"))
+    assert tuple(v.shape) == (1, TINY_LATENT.n) and abs(float(v.norm()) - 1.0) < 1e-4
+    ed3 = _edit_sd(g, tmp_path, "bf16x3", use_sega=True)
+    torch.manual_seed(5)
+    _, xs = ed3.run_edit_null_space_projection_zt_semantic(op="mid", block_idx=0, vis_num=2, mask_index=1, vis_num_pc=1, pca_rank=1)
+    assert tuple(xs.shape) == (1, 64, 64, 3)
+
+
+def test_cli_shipped_sd_script_on_the_standins(tmp_path, monkeypatch):
+    """`python -m loco_edit_amd.main` with the argument list of scripts/main_T2I_StableDiffusion_null_space_projection.sh
+    (tests/golden/script_args.json) plus the deployment flags that replace what is out of scope (architecture presets,
+    synthetic weights; SAM masks come from mask.pt)."""
+    import json
+    from loco_edit_amd.main import main
+    argv = json.load(open(os.path.join(ROOT, "tests", "golden", "script_args.json")))["main_T2I_StableDiffusion_null_space_projection.sh"]
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("LOCO_PRECISION", "bf16x3")
+    rdir = tmp_path / "runs" / "Stable_Diffusion-Random-with_prompt" / "results" / "for_prompt_a photo of a man_cfg7.5_seed305186554_standin"
+    os.makedirs(rdir / "mask")
+    masks = torch.zeros(3, 1, 64, 64, dtype=torch.bool)
+    masks[1, 0, 20:40, 12:44] = True
+    torch.save(masks, str(rdir / "mask" / "mask.pt"))
+    lat, x0 = main(argv + ["--device", DEV, "--unet_preset", "tiny_latent", "--vae_preset", "tiny_decoder", "--synthetic_weights", "0"])
+    assert x0.dtype == torch.uint8 and tuple(x0.shape) == (3, 64, 64, 3)      # vis_num 1: frames -S, 0, +S
+    sdir = rdir / "basis" / 'local_basis-0.7T-"a photo of a man wearing glasses"-pca-rank-1-select-mask1'
+    v = torch.load(str(sdir / "vT-modify.pt"))
+    assert tuple(v.shape) == (1, TINY_LATENT.n) and abs(float(v.norm()) - 1.0) < 1e-4
+    assert (rdir / "original.png").exists()

@@ -122,7 +122,7 @@ def test_every_shipped_script_parses():
     assert a.mask_model_name == "facebook/sam-vit-large"
 
 
-def test_preset_accepts_unconditional_and_if_scripts_and_rejects_latent_t2i(tmp_path, monkeypatch):
+def test_preset_accepts_unconditional_if_and_sd_scripts_and_rejects_lcm(tmp_path, monkeypatch):
     import json
     monkeypatch.chdir(tmp_path)
     scripts = json.load(open(os.path.join(ROOT, "tests", "golden", "script_args.json")))
@@ -131,7 +131,11 @@ def test_preset_accepts_unconditional_and_if_scripts_and_rejects_latent_t2i(tmp_
         if "DeepFloydIF" in name:       # pixel-space T-LOCO (reference define_argparser.py:147-160 routes by model name)
             a = define_argparser.preset(a)
             assert a.image_size == 64 and a.exp == "DeepFloyd-IF-Random-with_prompt"
-        elif "T2I" in name:             # latent-space T-LOCO (SD / LCM): outside this build, refused loudly
+        elif "StableDiffusion" in name:  # latent-space T-LOCO (define_argparser.py:147-153, 212-215)
+            a = define_argparser.preset(a)
+            assert (a.image_size, a.c_in) == (64, 4) and a.exp == "Stable_Diffusion-Random-with_prompt"
+            assert a.run_edit_null_space_projection_zt or a.run_edit_null_space_projection_zt_semantic
+        elif "T2I" in name:             # latent-consistency path: outside this build, refused loudly
             with pytest.raises(NotImplementedError):
                 define_argparser.preset(a)
         else:

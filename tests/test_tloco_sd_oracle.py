@@ -1,0 +1,75 @@
+"""CPU: the latent T-LOCO oracle (oracle/tloco_sd_oracle.py) against the fixture the reference's own EditStableDiffusion
+methods produced on the stand-in networks (tests/golden/tloco_sd_tiny.pt, oracle/make_golden_tloco_sd.py), plus the
+host logic of the product module (scheduler table, preset routing)."""
+import pytest
+import torch
+
+import loco_oracle as orc
+import tloco_sd_oracle as tsd
+import loco_edit_amd  # noqa: F401
+from loco_edit_amd.config import TINY_DECODER, TINY_LATENT, SD64_STANDIN, SD_VAE_DECODER, param_shapes, synth_params
+from loco_edit_amd.tloco import cond_params
+from loco_edit_amd.tloco_sd import SDScheduler
+
+
+@pytest.fixture(scope="module")
+def setup(golden):
+    g = golden("tloco_sd_tiny")
+    p = orc.to_torch(synth_params(TINY_LATENT, 0))
+    p.update({k: torch.from_numpy(v) for k, v in cond_params(TINY_LATENT, g["cond_dim"], 0).items()})
+    ot = tsd.OracleTLocoSD(p, TINY_LATENT, orc.to_torch(synth_params(TINY_DECODER, 0)), TINY_DECODER,
+                           guidance_scale=g["guidance_scale"], guidance_scale_edit=g["guidance_scale_edit"])
+    return g, ot
+
+
+def test_sd_scheduler_tables_and_shapes(setup):
+    g, ot = setup
+    s = SDScheduler()
+    assert torch.equal(s.alphas_cumprod, g["alphas_cumprod"]) and torch.equal(ot.sched.alphas_cumprod, g["alphas_cumprod"])
+    s.set_timesteps(100)
+    assert torch.equal(s.timesteps, g["timesteps"]) and float(s.timesteps[0]) == 999.0
+    assert g["edit_t_idx"] == int((s.timesteps - 700.0).abs().argmin()) == ot.edit_t_idx
+    # the decoder preset has the published size of the Stable Diffusion autoencoder's decoder
+    n_dec = sum(int(torch.tensor(sh).prod()) for sh in param_shapes(SD_VAE_DECODER).values())
+    assert n_dec == 49_490_179 and SD_VAE_DECODER.n == 4 * 64 * 64 and SD_VAE_DECODER.n_out == 3 * 512 * 512
+    assert SD64_STANDIN.n == SD64_STANDIN.n_out == 4 * 64 * 64 and TINY_DECODER.out_resolution == 64
+    assert "mid.block_1.temb_proj.weight" not in param_shapes(TINY_DECODER) and "temb.dense.0.weight" not in param_shapes(TINY_DECODER)
+
+
+def test_oracle_decoder_cfg_noise_and_x0(setup):
+    g, ot = setup
+    z, t = g["z"], g["t"]
+    F, E, N = g["for_e"], g["edit_e"], g["null_e"]
+    with torch.no_grad():
+        assert torch.allclose(ot.decode(g["dec_in"]), g["dec_out"], rtol=1e-4, atol=1e-4)
+        zb = torch.cat([z, z.flip(-1)], dim=0)
+        for mode, ref in g["eps_modes"].items():
+            assert torch.allclose(ot.cfg_noise(zb, t, F, E, N, mode), ref, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(ot.get_x0(z, t, F, E, N, mask=g["mask"]), g["x0_masked"], rtol=1e-4, atol=1e-3)
+        assert torch.allclose(ot.get_x0(z, t, F, E, N, mode="null+(for-null)"), g["x0_full"], rtol=1e-4, atol=1e-3)
+    v = ot.delta_zt_via_grad(z, t, F, E, N, g["mask"])
+    assert torch.allclose(v, g["v_grad"], rtol=1e-3, atol=1e-6) and abs(float(v.norm()) - 1.0) < 1e-5
+
+
+def test_oracle_latent_solver(setup):
+    g, ot = setup
+    sv = g["solver"]["modify"]
+    u, s, vT = ot.pullback(g["z"], g["t"], g["for_e"], g["edit_e"], g["null_e"], 3, g["v0"], min_iter=sv["n_iter"],
+                           max_iter=sv["n_iter"], mask=sv["mask"], mode=sv["mode"])
+    assert torch.allclose(s, sv["s"], rtol=1e-3)
+    assert (vT.double() * sv["vT"].double()).sum(dim=1).abs().min() > 0.9999
+    assert u.shape == (int(sv["mask"].sum()), 3) and vT.shape == (3, TINY_LATENT.n)
+
+
+def test_preset_routes_stable_diffusion_to_the_latent_path(tmp_path, monkeypatch):
+    from loco_edit_amd import define_argparser
+    monkeypatch.chdir(tmp_path)
+    a = define_argparser.parse_args(["--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Random", "--note", "n",
+                                     "--seed", "3", "--device", "cpu", "--run_edit_null_space_projection_zt", "True"])
+    a = define_argparser.preset(a)
+    assert a.is_stable_diffusion and not a.is_DeepFloyd_IF_diffusion and not a.is_LCM
+    assert a.exp == "Stable_Diffusion-Random-n" and (a.c_in, a.image_size, a.memory_bound) == (4, 64, 5)
+    assert a.unet_config is SD64_STANDIN and a.vae_config is SD_VAE_DECODER
+    b = define_argparser.parse_args(["--model_name", "SimianLuo/LCM_Dreamshaper_v7", "--seed", "3", "--device", "cpu"])
+    with pytest.raises(NotImplementedError):
+        define_argparser.preset(b)
