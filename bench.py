@@ -20,6 +20,9 @@ Workloads (--workload):
       ranks (strong scaling, 64/N per rank), keep the leading 20 rows; value = 20 /
       step time.  The default run also times one step of it and reports it under
       "extra_workloads" next to the headline line.
+  tloco_sd   (BASELINE config 4): latent T-LOCO on the Stable-Diffusion-shaped stand-ins (4x64x64 latent denoiser +
+             the SD autoencoder's decoder geometry, Jacobian of the decoded 3x512x512 image); explicit workload only
+             (three 765 M-parameter denoiser contexts take a minute to set up)
   tloco_if64 (BASELINE config 5): pixel-space T-LOCO at 64x64 on the IF-shaped stand-in conditional denoiser
       (loco_edit_amd.tloco): top-5 null-space basis of the CFG-combined Jacobian ("null+(for-null)", guidance 7.5: two
       denoiser branches per product), 5 probes per GPU sharded like the headline; value = 5 N directions / step time.
@@ -59,7 +62,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64"], default="celeba_top5")
+    ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64", "tloco_sd"], default="celeba_top5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end phase timing (inversion ... decode)")
@@ -313,9 +316,45 @@ def main():
             return u, s, vT, ed.last_n_iter
         return dict(cfg=cfg, k=k, keep=k, eng=ed.engine, params=None, step=step, x=x, mask=~mask, v0=v0, branches=2)
 
+    def make_tloco_sd(prec):
+        """config 4: CFG-combined subspace solve of the DECODED image's Jacobian w.r.t. the latent (denoiser engines per
+        prompt + decoder engine)."""
+        from argparse import Namespace
+        from loco_edit_amd.config import SD64_STANDIN, SD_VAE_DECODER
+        from loco_edit_amd.tloco_sd import EditStableDiffusion
+        cfg, vcfg = SD64_STANDIN, SD_VAE_DECODER
+        k = K_PER_GPU * world
+        args = Namespace(device=device, dtype=torch.float32, seed=1, unet_config=cfg, vae_config=vcfg, synthetic_weights=0,
+                         ckpt_path="", vae_ckpt_path="", max_batch=8, precision=prec, dataset_name="Random", for_steps=100,
+                         use_yh_custom_scheduler=True, guidance_scale=7.5, guidance_scale_edit=4.0, prompt_emb=None,
+                         prompt_emb_seed=31, cond_dim=64, for_prompt="standin", edit_prompt="standin-edit", edit_t=0.7,
+                         sampling_mode=False, tilda_v_score_type="null+(for-null)+(edit-null)", ablation_method="null-space-proj",
+                         mask_type="SAM", vT_path="", use_sega=False, x_space_guidance_edit_step=1.0, x_space_guidance_scale=8.0,
+                         x_space_guidance_num_step=1, result_folder=os.path.join(ROOT, "gpurun_out", "bench_tloco_sd"))
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            ed = EditStableDiffusion(args)
+        ed.sharder = sharder
+        z = torch.randn(1, 4, cfg.resolution, cfg.resolution, generator=torch.Generator().manual_seed(1)).to(device)
+        R = vcfg.out_resolution
+        mask = torch.zeros(3, R, R, dtype=torch.bool)
+        mask[:, R * 110 // 256:R * 130 // 256, R * 70 // 256:R * 110 // 256] = True       # the l_eye-sized rectangle at 512^2
+        mask = mask.to(device)
+        v0 = torch.randn(cfg.n, k, generator=torch.Generator().manual_seed(7)).to(device)
+        tt = ed.scheduler.timesteps[ed.edit_t_idx]
+        F_, E_, N_ = ed.for_prompt_emb, ed.edit_prompt_emb, ed.null_prompt_emb
+
+        def step():
+            u, s, vT = ed.local_encoder_decoder_pullback_zt(z, tt, ed.edit_t_idx, F_, E_, N_, pca_rank=k, min_iter=N_ITER,
+                                                            max_iter=N_ITER, mask=mask, mode="null+(for-null)", v0=v0, verbose=False)
+            return u, s, vT, ed.last_n_iter
+        return dict(cfg=cfg, k=k, keep=k, eng=ed.engine, params=None, step=step, x=z, mask=mask, v0=v0, branches=2, dec=ed.vae_engine)
+
     def make_workload(name, prec):
         if name == "tloco_if64":
             return make_tloco(prec)
+        if name == "tloco_sd":
+            return make_tloco_sd(prec)
         if name == "celeba_top5":
             cfg, k, keep = CELEBA_DDPM, K_PER_GPU * world, K_PER_GPU * world
         else:
@@ -438,6 +477,26 @@ def main():
                 "denoiser": "IF-shaped stand-in (64x64, ch 192 x (1,2,3,4), 3 res blocks, attention 32/16/8; text through the time "
                             "embedding) -- the IF U-Net itself is un-vendored diffusers code"}
         del w3
+        # BASELINE config 4 next to the headline (single GPU only: four engine contexts, ~90 GB): latent T-LOCO on the
+        # SD-shaped stand-ins, Jacobian of the decoded 512^2 image
+        if world == 1:
+            try:
+                w4 = make_workload("tloco_sd", a.precision)
+                el, (_, s4, vT4, _) = timed(w4["step"], 1, 1)
+                Fu, Fd = w4["eng"].unet_flops(), w4["dec"].unet_flops()
+                extra["tloco_sd"] = {
+                    "value": round(w4["k"] / el, 4), "unit": "edit-directions/s (top-5 basis, decoded-image Jacobian w.r.t. the latent)",
+                    "ms_per_step": round(el * 1e3, 3), "n_iter": N_ITER, "cfg_branches": 2, "mask_L": int(w4["mask"].sum().item()),
+                    "denoiser_GFLOP": round(Fu / 1e9, 2), "decoder_GFLOP": round(Fd / 1e9, 2),
+                    "whole_step_TFLOPs_executed": round((1 + 2 * w4["k"] * N_ITER) * (2 * Fu + Fd) / el / 1e12, 2),
+                    "singular_values_head": [round(float(v), 4) for v in s4.tolist()[:5]],
+                    "networks": "stand-ins: 4x64x64 latent denoiser 320x(1,2,4,4) (765 M parameters, text through the time embedding) + "
+                                "the SD autoencoder decoder geometry (49.5 M parameters); diffusers' UNet2DConditionModel / "
+                                "AutoencoderKL are un-vendored"}
+                del w4
+            except Exception as ex:        # never lose the headline line to an optional workload
+                extra["tloco_sd"] = {"error": repr(ex)[:200]}
+            torch.cuda.empty_cache()
         # BASELINE config 3 next to the headline: FFHQ-P2, 64 probes over the ranks, keep 20
         w2 = make_workload("p2_k64", a.precision)
         el, (_, s3, vT3, _) = timed(w2["step"], 1, 1)
@@ -457,7 +516,14 @@ def main():
         cpu = cpu_baseline(cfg, w["params"], t)
 
     if rank == 0:
-        if a.workload == "tloco_if64":
+        if a.workload == "tloco_sd":
+            metric = "edit-directions/sec (top-5 CFG-combined PMP-Jacobian basis of the decoded 512^2 image w.r.t. the 4x64^2 latent, T-LOCO)"
+            wl = ("T-LOCO latent space: SD-shaped stand-in denoiser (4x64x64, 320x(1,2,4,4), 765 M parameters, mode null+(for-null) "
+                  "guidance 7.5 = 2 branches) + the SD autoencoder's decoder geometry (49.5 M parameters, 64 -> 512), l_eye-sized "
+                  "mask on the decoded image, t=0.7T, 12 power iterations, probes sharded 5 per GPU; per probe-pass "
+                  f"{2 * eng.unet_flops() / 1e12:.2f} TFLOP of denoiser + {w['dec'].unet_flops() / 1e12:.2f} TFLOP of decoder")
+            scaling = "weak"
+        elif a.workload == "tloco_if64":
             metric = "edit-directions/sec (top-5 CFG-combined PMP-Jacobian null-space basis @64^2, T-LOCO)"
             wl = ("T-LOCO pixel space 64x64, IF-shaped stand-in conditional denoiser, mode null+(for-null) guidance 7.5 (2 branches), "
                   "complement of an l_eye-sized mask, t=0.75T, 12 power iterations, probes sharded 5 per GPU")
