@@ -143,6 +143,7 @@ struct loco_ctx {
     struct FwdGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int calls = 0; };
     std::map<int, FwdGraph> fwd_graphs;
     bool graph_on = false;
+    bool gemm_lowp = true;         // LOCO_GEMM_LOWP=0: every attention product on the exact f32-input kernel (A/B timing)
     hipStream_t cap_st = nullptr;  // capture stream (the caller's may be the legacy default stream)
     float* xin_buf = nullptr;      // [max_batch][n] fixed graph input
     float* t_dev = nullptr;        // timestep read by the captured time-embedding kernel
@@ -896,6 +897,12 @@ struct Pass {
     long bs() const { return c->per_sample; }
 };
 
+// attention products: exact fp32 MFMA in the f32 mode and for the short / small ones, split-bf16 on the bf16 matrix
+// pipe for the long contractions of the low-precision modes (decoder mid attention at 4096 tokens)
+inline void attn_gemm(const loco_ctx* c, const GemmArgs& g, hipStream_t st) {
+    if (c->prec >= 1 && c->gemm_lowp && gemm_prefers_bf16x3(g)) launch_gemm_bf16x3(g, st); else launch_gemm(g, st);
+}
+
 void conv_defaults(ConvArgs& a) {
     std::memset(&a, 0, sizeof(a));
     a.stride = 1; a.pad = 1; a.nsplit = 1; a.mode = CM_NONE;
@@ -1087,14 +1094,14 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = p.bs(); g.sbh = 3L * CH * T;
                 g.C = p.T(op.S); g.scm = T; g.scn = 1; g.scb = p.bs(); g.sch = (long)T * T;
                 g.M = T; g.N = T; g.K = CH; g.batch = B; g.batch2 = NH; g.alpha = 1.0f / std::sqrt((float)CH); g.beta = 0.f;
-                launch_gemm(g, st);
+                attn_gemm(c, g, st);
                 launch_softmax_rows(p.T(op.S), (long)NH * T, T, st, B, p.bs());
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
                 h.A = v; h.sam = T; h.sak = 1; h.sab = p.bs(); h.sah = 3L * CH * T;
                 h.Bm = p.T(op.S); h.sbk = 1; h.sbn = T; h.sbb = p.bs(); h.sbh = (long)T * T;
                 h.C = p.T(op.o); h.scm = T; h.scn = 1; h.scb = p.bs(); h.sch = (long)CH * T;
                 h.M = CH; h.N = T; h.K = T; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
-                launch_gemm(h, st);
+                attn_gemm(c, h, st);
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = p.T(op.o); pr.in_bs = p.bs(); pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, false); pr.bias = op.proj.bias; pr.pad = 0;
@@ -1232,18 +1239,18 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = HS;
                 g.C = TT(op.S); g.scm = T; g.scn = 1; g.scb = PS; g.sch = SS;
                 g.M = T; g.N = T; g.K = CH; g.batch = B; g.batch2 = NH; g.alpha = 1.f; g.beta = 0.f;
-                launch_gemm(g, st);
+                attn_gemm(c, g, st);
                 g.A = q; g.sab = 0; g.Bm = dk; g.sbb = PS; g.beta = 1.f;
-                launch_gemm(g, st);
+                attn_gemm(c, g, st);
                 launch_softmax_jac(TT(op.S), TP(op.S), (long)NH * T, T, (long)NH * T, 1.0f / std::sqrt((float)CH), st, B, PS);
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
                 h.A = dv; h.sam = T; h.sak = 1; h.sab = PS; h.sah = HS;
                 h.Bm = TP(op.S); h.sbk = 1; h.sbn = T; h.sbb = 0; h.sbh = SS;
                 h.C = TT(op.o); h.scm = T; h.scn = 1; h.scb = PS; h.sch = (long)CH * T;
                 h.M = CH; h.N = T; h.K = T; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
-                launch_gemm(h, st);
+                attn_gemm(c, h, st);
                 h.A = v; h.sab = 0; h.Bm = TT(op.S); h.sbb = PS; h.beta = 1.f;
-                launch_gemm(h, st);
+                attn_gemm(c, h, st);
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = TT(op.o); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, false); pr.pad = 0; pr.res = TT(op.in); pr.res_bs = PS;
@@ -1407,14 +1414,14 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 g.Bm = TP(op.S); g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = SS;
                 g.C = gv; g.scm = T; g.scn = 1; g.scb = PS; g.sch = HS;
                 g.M = CH; g.N = T; g.K = T; g.batch = B; g.batch2 = NH; g.alpha = 1.f; g.beta = 0.f;
-                launch_gemm(g, st);
+                attn_gemm(c, g, st);
                 // g_P[i][j] = sum_c g_o[c][i] v[c][j]
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
                 h.A = TG(op.o); h.sam = 1; h.sak = T; h.sab = PS; h.sah = OS;
                 h.Bm = v; h.sbk = T; h.sbn = 1; h.sbb = 0; h.sbh = HS;
                 h.C = TG(op.S); h.scm = T; h.scn = 1; h.scb = PS; h.sch = SS;
                 h.M = T; h.N = T; h.K = CH; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
-                launch_gemm(h, st);
+                attn_gemm(c, h, st);
                 launch_softmax_jac(TG(op.S), TP(op.S), (long)NH * T, T, (long)NH * T, 1.0f / std::sqrt((float)CH), st, B, PS);
                 // g_q[c][i] = sum_j k[c][j] g_S[i][j]
                 GemmArgs gq_; std::memset(&gq_, 0, sizeof(gq_));
@@ -1422,11 +1429,11 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 gq_.Bm = TG(op.S); gq_.sbk = 1; gq_.sbn = T; gq_.sbb = PS; gq_.sbh = SS;
                 gq_.C = gq; gq_.scm = T; gq_.scn = 1; gq_.scb = PS; gq_.sch = HS;
                 gq_.M = CH; gq_.N = T; gq_.K = T; gq_.batch = B; gq_.batch2 = NH; gq_.alpha = 1.f; gq_.beta = 0.f;
-                launch_gemm(gq_, st);
+                attn_gemm(c, gq_, st);
                 // g_k[c][j] = sum_i q[c][i] g_S[i][j]
                 GemmArgs gk_ = gq_;
                 gk_.A = q; gk_.Bm = TG(op.S); gk_.sbk = T; gk_.sbn = 1; gk_.C = gk;
-                launch_gemm(gk_, st);
+                attn_gemm(c, gk_, st);
                 // g_hn = Wqkv^T g_qkv
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.qkv); a.in_bs = PS; a.Cin = 3 * C; a.Hin = to.H; a.Win = to.W;
@@ -1576,6 +1583,8 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         c->n_streams = (e && atoi(e) == 2) ? 2 : 1;
         HIPCHK(c, hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->cap_st, hipStreamNonBlocking));
+        const char* gl = getenv("LOCO_GEMM_LOWP");
+        if (gl) c->gemm_lowp = atoi(gl) != 0;
         const char* gr = getenv("LOCO_GRAPH");
         c->graph_on = gr && atoi(gr) == 1;
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

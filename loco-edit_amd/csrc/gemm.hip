@@ -80,6 +80,171 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same strided batched GEMM on the bf16 matrix pipe with SPLIT-bf16 operands (hi + lo halves, three
+// v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate: fp32-faithful to ~2^-16 like the convolutions of that mode).
+// Used for the attention products that are matrix-rate bound on the f32-input MFMA (1/16 of the bf16 rate): long
+// contractions over many tokens, i.e. the latent decoder's 4096-token x 512-channel mid attention (score product
+// K = 512, value product K = 4096).  The short multi-head products (K = 64) and the 256-token blocks are bound by the
+// materialised score matrix / by launch latency and measured the same on both kernels (profiles/r02_conv_analysis.md
+// section 6), so they stay on the exact kernel above.  BM x BN tile per workgroup, 4 waves of (BM/2) x (BN/2), BK = 32
+// per stage.  Staging: a thread owns 8 consecutive k of one row (column), loaded with that operand's k stride --
+// coalesced across lanes when the row index is the unit-stride one, 32-byte runs when k is -- converts them to one
+// 16-byte hi and one 16-byte lo piece and writes the two pieces of the row's 64-byte record
+// [hi k0-7|hi k8-15|lo k0-7|lo k8-15] (piece index XORed with (row>>2)&3: conflict-free ds_read_b128 fragments).
+typedef __bf16 bf16x8_g __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_piece(const float* v, uint4& hi, uint4& lo) {
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 hb = (__bf16)v[j];
+        __bf16 lb = (__bf16)(v[j] - (float)hb);
+        h[j] = __builtin_bit_cast(unsigned short, hb);
+        l[j] = __builtin_bit_cast(unsigned short, lb);
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+__device__ __forceinline__ int grec(int row, int piece) { return row * 64 + ((piece ^ ((row >> 2) & 3)) << 4); }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
+    constexpr int BK = 32, KS = BK / 16;            // two MFMA k-steps per stage
+    constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 blocks per wave and dimension
+    constexpr int NA = BM * 4 / 256, NB = BN * 4 / 256;   // (row, 8-k group) items per thread
+    __shared__ __attribute__((aligned(16))) unsigned char As[KS * BM * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[KS * BN * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int nb2 = g.batch2 > 0 ? g.batch2 : 1;
+    const int bz = blockIdx.z / nb2, hz = blockIdx.z % nb2;
+    const float* A = g.A + (long)bz * g.sab + (long)hz * g.sah;
+    const float* B = g.Bm + (long)bz * g.sbb + (long)hz * g.sbh;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[NA][8], rb[NB][8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int e = tid + it * 256, m = e % BM, kq = e / BM;
+            const bool vm = m0 + m < g.M;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + kq * 8 + j;
+                const bool v = vm && k < g.K;
+                const float x = A[v ? (long)(m0 + m) * g.sam + (long)k * g.sak : 0];
+                ra[it][j] = v ? x : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int e = tid + it * 256, n = e % BN, kq = e / BN;
+            const bool vn = n0 + n < g.N;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + kq * 8 + j;
+                const bool v = vn && k < g.K;
+                const float x = B[v ? (long)k * g.sbk + (long)(n0 + n) * g.sbn : 0];
+                rb[it][j] = v ? x : 0.f;
+            }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int e = tid + it * 256, m = e % BM, kq = e / BM;      // kq 0..3: k-step kq>>1, half kq&1
+            uint4 hi, lo;
+            split_piece(ra[it], hi, lo);
+            unsigned char* rec = As + (kq >> 1) * BM * 64;
+            *reinterpret_cast<uint4*>(rec + grec(m, kq & 1)) = hi;
+            *reinterpret_cast<uint4*>(rec + grec(m, 2 + (kq & 1))) = lo;
+        }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int e = tid + it * 256, n = e % BN, kq = e / BN;
+            uint4 hi, lo;
+            split_piece(rb[it], hi, lo);
+            unsigned char* rec = Bs + (kq >> 1) * BN * 64;
+            *reinterpret_cast<uint4*>(rec + grec(n, kq & 1)) = hi;
+            *reinterpret_cast<uint4*>(rec + grec(n, 2 + (kq & 1))) = lo;
+        }
+        __syncthreads();
+        if (k0 + BK < g.K) fetch(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8_g ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = (wm * TM + i) * 32 + l31;
+                ah[i] = *reinterpret_cast<const bf16x8_g*>(As + ks * BM * 64 + grec(m, khalf));
+                al[i] = *reinterpret_cast<const bf16x8_g*>(As + ks * BM * 64 + grec(m, 2 + khalf));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = (wn * TN + j) * 32 + l31;
+                bh[j] = *reinterpret_cast<const bf16x8_g*>(Bs + ks * BN * 64 + grec(n, khalf));
+                bl[j] = *reinterpret_cast<const bf16x8_g*>(Bs + ks * BN * 64 + grec(n, 2 + khalf));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + l31;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (m >= g.M) continue;
+                const long off = (long)m * g.scm + (long)n * g.scn;
+                float v = g.alpha * acc[i][j][r];
+                float* c = g.C + (long)bz * g.scb + (long)hz * g.sch + off;
+                if (g.beta != 0.f) v += g.beta * (*c);
+                if (g.bias) v += g.bias[m];
+                if (g.R) v += g.R[(long)bz * g.srb + (long)hz * g.sch + off];
+                *c = v;
+            }
+        }
+}
+
+bool gemm_prefers_bf16x3(const GemmArgs& g) {
+    // long contractions with enough work per launch to be bound by the f32-input matrix rate
+    const double macs = (double)g.M * g.N * g.K * g.batch * (g.batch2 > 0 ? g.batch2 : 1);
+    return g.K >= 256 && macs >= 4e9;
+}
+
+void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t st) {
+    const int nb = g.batch * (g.batch2 > 0 ? g.batch2 : 1);
+    const long big = (long)((g.N + 127) / 128) * ((g.M + 127) / 128) * nb;
+    if (big >= 512 && g.M >= 128 && g.N >= 128) {
+        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, nb);
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128>), grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, nb);
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64>), grid, dim3(256), 0, st, g);
+    }
+}
+
 void launch_gemm(const GemmArgs& g, hipStream_t st) {
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, g.batch * (g.batch2 > 0 ? g.batch2 : 1));
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);

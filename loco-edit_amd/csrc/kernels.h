@@ -84,7 +84,9 @@ struct GemmArgs {
     // second-level batch (attention heads): blockIdx.z = b * batch2 + h, strides added per h
     int batch2; long sah, sbh, sch;
 };
-void launch_gemm(const GemmArgs& g, hipStream_t st);
+void launch_gemm(const GemmArgs& g, hipStream_t st);              // exact fp32 (f32-input MFMA)
+void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t st);       // split-bf16 operands on the bf16 matrix pipe
+bool gemm_prefers_bf16x3(const GemmArgs& g);                      // long contraction, matrix-rate bound on the f32 MFMA
 
 // ---- GroupNorm statistics -------------------------------------------------
 // x: [B][C][HW] with batch stride bs; groups of cpg channels (contiguous cpg*HW floats)

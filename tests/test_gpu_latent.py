@@ -281,3 +281,30 @@ def test_latent_solver_at_stable_diffusion_size(tmp_path):
     assert u.shape == (int(mask.sum()), 3) and vT.shape == (3, 16384) and bool((s[:-1] >= s[1:]).all())
     vd = vT.double()
     assert (vd @ vd.T - torch.eye(3, device=DEV, dtype=torch.float64)).abs().max().item() < 2e-6
+
+
+def test_long_attention_products_on_the_bf16_pipe():
+    """A decoder whose mid attention has 4096 tokens x 256 channels: in the split-bf16 mode its score / value products
+    (and their tangent / cotangent forms) run on `gemm_bf16x3_kernel` (K >= 256, >= 4e9 MACs per launch).  Forward vs
+    the CPU restatement, J V and U^T J vs the same engine in the exact-fp32 mode."""
+    from loco_edit_amd.config import UNetConfig
+    from loco_edit_amd.hip import LocoEngine
+    cfg = UNetConfig(resolution=64, in_channels=4, out_ch=3, ch=256, ch_mult=(1,), num_res_blocks=0, attn_resolutions=(),
+                     gn_eps=1e-6, arch="dec")
+    params = synth_params(cfg, 0)
+    eng = LocoEngine(cfg, max_batch=2, device=torch.device(DEV))
+    eng.load_state_dict(params)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(1, 4, 64, 64, generator=g)
+    V = torch.randn(2, eng.n, generator=g).to(DEV)
+    U = torch.randn(2, eng.n_out, generator=g).to(DEV)
+    res = {}
+    for prec in ("f32", "bf16x3"):
+        eng.set_precision(prec)
+        x = eng.unet_forward(z.to(DEV), 0.0)
+        eng.pmp_primal(z.to(DEV), 0.0, 1.0, None, use_et=True)
+        res[prec] = (x.cpu(), eng.pmp_jvp(V).cpu(), eng.pmp_vjp(U).cpu())
+    with torch.no_grad():
+        x_ref = orc.decoder_forward(orc.to_torch(params), cfg, z)
+    assert rel(res["f32"][0], x_ref) < 2e-5 and rel(res["bf16x3"][0], x_ref) < 2e-4
+    assert rel(res["bf16x3"][1], res["f32"][1]) < 5e-4 and rel(res["bf16x3"][2], res["f32"][2]) < 5e-4
