@@ -1239,18 +1239,22 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = HS;
                 g.C = TT(op.S); g.scm = T; g.scn = 1; g.scb = PS; g.sch = SS;
                 g.M = T; g.N = T; g.K = CH; g.batch = B; g.batch2 = NH; g.alpha = 1.f; g.beta = 0.f;
+                // dS = dq^T k + q^T dk and do = dv P^T + v dP^T: one launch per pair (K-concatenation) where the launches
+                // are latency-shaped (T <= 256: 327.7 vs 330.0 ms per headline step); at 1024 tokens two launches with
+                // beta = 1 measured faster (616 vs 639 ms per tloco_if64 step)
+                const bool kcat = T <= 256;
+                if (kcat) { g.A2 = q; g.sab2 = 0; g.Bm2 = dk; g.sbb2 = PS; }
                 attn_gemm(c, g, st);
-                g.A = q; g.sab = 0; g.Bm = dk; g.sbb = PS; g.beta = 1.f;
-                attn_gemm(c, g, st);
+                if (!kcat) { g.A = q; g.sab = 0; g.Bm = dk; g.sbb = PS; g.beta = 1.f; attn_gemm(c, g, st); }
                 launch_softmax_jac(TT(op.S), TP(op.S), (long)NH * T, T, (long)NH * T, 1.0f / std::sqrt((float)CH), st, B, PS);
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
                 h.A = dv; h.sam = T; h.sak = 1; h.sab = PS; h.sah = HS;
                 h.Bm = TP(op.S); h.sbk = 1; h.sbn = T; h.sbb = 0; h.sbh = SS;
                 h.C = TT(op.o); h.scm = T; h.scn = 1; h.scb = PS; h.sch = (long)CH * T;
                 h.M = CH; h.N = T; h.K = T; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
+                if (kcat) { h.A2 = v; h.sab2 = 0; h.Bm2 = TT(op.S); h.sbb2 = PS; }
                 attn_gemm(c, h, st);
-                h.A = v; h.sab = 0; h.Bm = TT(op.S); h.sbb = PS; h.beta = 1.f;
-                attn_gemm(c, h, st);
+                if (!kcat) { h.A = v; h.sab = 0; h.Bm = TT(op.S); h.sbb = PS; h.beta = 1.f; attn_gemm(c, h, st); }
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = TT(op.o); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, false); pr.pad = 0; pr.res = TT(op.in); pr.res_bs = PS;

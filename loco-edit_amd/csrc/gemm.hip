@@ -12,6 +12,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GBM = 64, GBN = 64, GBK = 64;
 
+template <int NSEG>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __shared__ float As[GBK][GBM + 1];
     __shared__ float Bs[GBK][GBN + 1];
@@ -49,18 +50,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             rb[i] = vb ? xb : 0.f;
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < g.K; k0 += GBK) {
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NE; ++i) { As[ak[i]][am[i]] = ra[i]; Bs[bk[i]][bn[i]] = rb[i]; }
-        __syncthreads();
-        if (k0 + GBK < g.K) fetch(k0 + GBK);
+    for (int seg = 0; seg < NSEG; ++seg) {
+        if (seg) {
+            A = g.A2 + (long)bz * g.sab2 + (long)hz * g.sah;
+            B = g.Bm2 + (long)bz * g.sbb2 + (long)hz * g.sbh;
+        }
+        fetch(0);
+        for (int k0 = 0; k0 < g.K; k0 += GBK) {
+            __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < GBK / 2; ++kk) {
-            float a = As[2 * kk + khalf][wm * 32 + l31];
-            float b = Bs[2 * kk + khalf][wn * 32 + l31];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            for (int i = 0; i < NE; ++i) { As[ak[i]][am[i]] = ra[i]; Bs[bk[i]][bn[i]] = rb[i]; }
+            __syncthreads();
+            if (k0 + GBK < g.K) fetch(k0 + GBK);
+#pragma unroll
+            for (int kk = 0; kk < GBK / 2; ++kk) {
+                float a = As[2 * kk + khalf][wm * 32 + l31];
+                float b = Bs[2 * kk + khalf][wn * 32 + l31];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
         }
     }
     const int n = n0 + wn * 32 + l31;
@@ -108,7 +116,7 @@ __device__ __forceinline__ void split_piece(const float* v, uint4& hi, uint4& lo
 }
 __device__ __forceinline__ int grec(int row, int piece) { return row * 64 + ((piece ^ ((row >> 2) & 3)) << 4); }
 
-template <int BM, int BN>
+template <int BM, int BN, int NSEG>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     constexpr int BK = 32, KS = BK / 16;            // two MFMA k-steps per stage
     constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 blocks per wave and dimension
@@ -158,6 +166,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             }
         }
     };
+#pragma unroll
+    for (int seg = 0; seg < NSEG; ++seg) {
+    if (seg) {
+        A = g.A2 + (long)bz * g.sab2 + (long)hz * g.sah;
+        B = g.Bm2 + (long)bz * g.sbb2 + (long)hz * g.sbh;
+    }
     fetch(0);
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         __syncthreads();
@@ -206,6 +220,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 }
         }
     }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 
 bool gemm_prefers_bf16x3(const GemmArgs& g) {
     // long contractions with enough work per launch to be bound by the f32-input matrix rate
-    const double macs = (double)g.M * g.N * g.K * g.batch * (g.batch2 > 0 ? g.batch2 : 1);
+    const double macs = (double)g.M * g.N * g.K * (g.A2 ? 2 : 1) * g.batch * (g.batch2 > 0 ? g.batch2 : 1);
     return g.K >= 256 && macs >= 4e9;
 }
 
@@ -238,16 +253,19 @@ void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t st) {
     const long big = (long)((g.N + 127) / 128) * ((g.M + 127) / 128) * nb;
     if (big >= 512 && g.M >= 128 && g.N >= 128) {
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, nb);
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128>), grid, dim3(256), 0, st, g);
+        if (g.A2) hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128, 2>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128, 1>), grid, dim3(256), 0, st, g);
     } else {
         dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, nb);
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64>), grid, dim3(256), 0, st, g);
+        if (g.A2) hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 2>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1>), grid, dim3(256), 0, st, g);
     }
 }
 
 void launch_gemm(const GemmArgs& g, hipStream_t st) {
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, g.batch * (g.batch2 > 0 ? g.batch2 : 1));
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
+    if (g.A2) hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, g);
 }
 
 }  // namespace loco

@@ -83,6 +83,10 @@ struct GemmArgs {
     float alpha, beta;
     // second-level batch (attention heads): blockIdx.z = b * batch2 + h, strides added per h
     int batch2; long sah, sbh, sch;
+    // optional second contraction segment (K-concatenation): C = alpha * (A B + A2 B2) + ..., same shapes and
+    // row / column / k / head strides, own batch strides (the tangent forms dq^T k + q^T dk and dv P^T + v dP^T pair a
+    // per-probe operand with a broadcast primal one)
+    const float* A2; long sab2; const float* Bm2; long sbb2;
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);              // exact fp32 (f32-input MFMA)
 void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t st);       // split-bf16 operands on the bf16 matrix pipe
