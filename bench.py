@@ -22,7 +22,7 @@ Workloads (--workload):
       "extra_workloads" next to the headline line.
   tloco_sd   (BASELINE config 4): latent T-LOCO on the Stable-Diffusion-shaped stand-ins (4x64x64 latent denoiser +
              the SD autoencoder's decoder geometry, Jacobian of the decoded 3x512x512 image); explicit workload only
-             (three 765 M-parameter denoiser contexts take a minute to set up)
+             (three 832 M-parameter denoiser contexts take a minute to set up)
   tloco_if64 (BASELINE config 5): pixel-space T-LOCO at 64x64 on the IF-shaped stand-in conditional denoiser
       (loco_edit_amd.tloco): top-5 null-space basis of the CFG-combined Jacobian ("null+(for-null)", guidance 7.5: two
       denoiser branches per product), 5 probes per GPU sharded like the headline; value = 5 N directions / step time.
@@ -320,9 +320,9 @@ def main():
         """config 4: CFG-combined subspace solve of the DECODED image's Jacobian w.r.t. the latent (denoiser engines per
         prompt + decoder engine)."""
         from argparse import Namespace
-        from loco_edit_amd.config import SD64_STANDIN, SD_VAE_DECODER
+        from loco_edit_amd.config import SD64_XATTN_STANDIN, SD_VAE_DECODER
         from loco_edit_amd.tloco_sd import EditStableDiffusion
-        cfg, vcfg = SD64_STANDIN, SD_VAE_DECODER
+        cfg, vcfg = SD64_XATTN_STANDIN, SD_VAE_DECODER
         k = K_PER_GPU * world
         args = Namespace(device=device, dtype=torch.float32, seed=1, unet_config=cfg, vae_config=vcfg, synthetic_weights=0,
                          ckpt_path="", vae_ckpt_path="", max_batch=8, precision=prec, dataset_name="Random", for_steps=100,
@@ -490,7 +490,7 @@ def main():
                     "denoiser_GFLOP": round(Fu / 1e9, 2), "decoder_GFLOP": round(Fd / 1e9, 2),
                     "whole_step_TFLOPs_executed": round((1 + 2 * w4["k"] * N_ITER) * (2 * Fu + Fd) / el / 1e12, 2),
                     "singular_values_head": [round(float(v), 4) for v in s4.tolist()[:5]],
-                    "networks": "stand-ins: 4x64x64 latent denoiser 320x(1,2,4,4) (765 M parameters, text through the time embedding) + "
+                    "networks": "stand-ins: 4x64x64 latent denoiser 320x(1,2,4,4) with text cross-attention (77x768 prompt states) + "
                                 "the SD autoencoder decoder geometry (49.5 M parameters); diffusers' UNet2DConditionModel / "
                                 "AutoencoderKL are un-vendored"}
                 del w4
@@ -518,7 +518,7 @@ def main():
     if rank == 0:
         if a.workload == "tloco_sd":
             metric = "edit-directions/sec (top-5 CFG-combined PMP-Jacobian basis of the decoded 512^2 image w.r.t. the 4x64^2 latent, T-LOCO)"
-            wl = ("T-LOCO latent space: SD-shaped stand-in denoiser (4x64x64, 320x(1,2,4,4), 765 M parameters, mode null+(for-null) "
+            wl = ("T-LOCO latent space: SD-shaped stand-in denoiser (4x64x64, 320x(1,2,4,4), text cross-attention over 77x768 prompt states behind every attention block, mode null+(for-null) "
                   "guidance 7.5 = 2 branches) + the SD autoencoder's decoder geometry (49.5 M parameters, 64 -> 512), l_eye-sized "
                   "mask on the decoded image, t=0.7T, 12 power iterations, probes sharded 5 per GPU; per probe-pass "
                   f"{2 * eng.unet_flops() / 1e12:.2f} TFLOP of denoiser + {w['dec'].unet_flops() / 1e12:.2f} TFLOP of decoder")

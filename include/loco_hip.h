@@ -54,6 +54,12 @@ typedef struct loco_unet_cfg {
     int32_t arch;
     int32_t num_head_channels; /* arch 1: channels per attention head (P2: 64) */
     int32_t learn_sigma;       /* arch 1: the head emits 2*out_ch channels, eps = first out_ch (unet.py:680-684) */
+    /* arch 1, text-to-image stand-ins: when context_dim > 0 every attention block is followed by a text
+     * cross-attention stage  h += proj(softmax(q(GN(h))^T k(ctx) / sqrt(d)) applied to v(ctx))  over the
+     * context_len x context_dim encoder states given to loco_set_context (the role of encoder_hidden_states in
+     * edit.py:636-674 / 1286-1373; the reference's cross-attention lives in un-vendored diffusers blocks) */
+    int32_t context_dim;
+    int32_t context_len;
 } loco_unet_cfg;
 
 /* Library / device probes (no ctx). */
@@ -169,6 +175,11 @@ int  loco_masked_axpby(loco_ctx* ctx, const float* V, const float* E, float cv, 
                        void* stream);
 /* out = sum_{i<n} coef[i] * src[i], n <= 4: the classifier-free-guidance combination of eps / J V / J^T U terms of
  * several conditions (edit.py:1324-1372).  src: host array of device pointers, coef: host array; out may alias a src. */
+/* Encoder states of the prompt for the cross-attention stages (context_dim > 0): tokens = device pointer to
+ * [context_len][context_dim] fp32.  Projects them to the per-block keys / values once; the cached primal is
+ * invalidated.  Replaces `encoder_hidden_states=prompt_emb` of self.unet(...) (edit.py:664-667, 1319-1322). */
+int  loco_set_context(loco_ctx* ctx, const float* tokens, void* stream);
+
 int  loco_lincomb(loco_ctx* ctx, const float* const* src, const float* coef, int32_t n, float* out, int64_t count,
                   void* stream);
 

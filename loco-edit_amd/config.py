@@ -38,6 +38,10 @@ class UNetConfig:
     arch: str = "ddpm"
     num_head_channels: int = -1     # adm: channels per attention head (P2: 64)
     learn_sigma: bool = False       # adm: network emits 2*out_ch channels, eps = the first out_ch (unet.py:680-684)
+    # adm, text-to-image stand-ins: context_dim > 0 puts a text cross-attention stage behind every attention block
+    # (queries from the image tokens, keys / values from the context_len x context_dim encoder states of the prompt)
+    context_dim: int = 0
+    context_len: int = 0
 
     @property
     def temb_ch(self) -> int:
@@ -84,6 +88,13 @@ TINY_LATENT = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=32, ch_mult=
                          attn_resolutions=(8,), gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=False)
 TINY_DECODER = UNetConfig(resolution=16, in_channels=4, out_ch=3, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1,
                           attn_resolutions=(), gn_eps=1e-6, arch="dec")
+# the same with text cross-attention behind every attention block (77 x 768 = the CLIP states of SD v1.x; 7 x 16 tiny)
+SD64_XATTN_STANDIN = UNetConfig(resolution=64, in_channels=4, out_ch=4, ch=320, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
+                                attn_resolutions=(32, 16, 8), gn_eps=1e-5, arch="adm", num_head_channels=64,
+                                learn_sigma=False, context_dim=768, context_len=77)
+TINY_LATENT_XATTN = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=32, ch_mult=(1, 2), num_res_blocks=1,
+                               attn_resolutions=(16, 8), gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=False,
+                               context_dim=16, context_len=7)
 TINY_ADM = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,),
                       gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True)
 
@@ -110,6 +121,13 @@ def adm_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
         shapes[name + ".norm.weight"] = (c,); shapes[name + ".norm.bias"] = (c,)
         shapes[name + ".qkv.weight"] = (3 * c, c, 1); shapes[name + ".qkv.bias"] = (3 * c,)
         shapes[name + ".proj_out.weight"] = (c, c, 1); shapes[name + ".proj_out.bias"] = (c,)
+        if cfg.context_dim > 0:     # cross-attention stage (not part of guided_diffusion: stand-in for the diffusers blocks)
+            x = name + ".xattn"
+            shapes[x + ".norm.weight"] = (c,); shapes[x + ".norm.bias"] = (c,)
+            shapes[x + ".q.weight"] = (c, c, 1); shapes[x + ".q.bias"] = (c,)
+            shapes[x + ".k.weight"] = (c, cfg.context_dim); shapes[x + ".k.bias"] = (c,)
+            shapes[x + ".v.weight"] = (c, cfg.context_dim); shapes[x + ".v.bias"] = (c,)
+            shapes[x + ".proj_out.weight"] = (c, c, 1); shapes[x + ".proj_out.bias"] = (c,)
 
     shapes["time_embed.0.weight"] = (ted, mc); shapes["time_embed.0.bias"] = (ted,)
     shapes["time_embed.2.weight"] = (ted, ted); shapes["time_embed.2.bias"] = (ted,)

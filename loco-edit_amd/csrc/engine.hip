@@ -67,6 +67,14 @@ struct Op {
     int updown = 0;               // RES: 0 none, 1 down (avg-pool 2x2 on both branches), 2 up (nearest x2)
     bool scale_shift = false;     // RES: GN(h)*(1+scale)+shift from the embedding (ADM); else conv1 += Linear(temb) (DDPM)
     int heads = 1;                // ATTN
+    // ATTN with a text cross-attention stage behind it (cfg.context_dim > 0): xmid = output of the self-attention
+    // stage, xhn = GN(xmid), xq = q projection [C][T], xS = scores / probabilities [heads][T][Lp], xo = attended values
+    bool has_x = false;
+    int xmid = -1, xhn = -1, xq = -1, xS = -1, xo = -1;
+    NormP nx;
+    ConvP xqc, xproj;
+    float *xkw = nullptr, *xkb = nullptr, *xvw = nullptr, *xvb = nullptr;   // key / value projections of the context [C][D], [C]
+    float *xK = nullptr, *xV = nullptr;                                     // projected context [C][Lp] (loco_set_context)
     bool in_is_skip = false;
     bool has_nin = false;
     bool has_temb = true;         // RES: false for the embedding-free blocks of the decoder (arch 2)
@@ -111,6 +119,9 @@ struct loco_ctx {
     float* tmpA = nullptr;         // [64][n] temp for solver rotations
     double *G = nullptr, *Q = nullptr, *W = nullptr, *gscratch = nullptr;
     float* alphas = nullptr;
+    int ctx_Lp = 0;                // context length padded to a multiple of 64 (score row length of the cross-attention)
+    float* ctx_colbias = nullptr;  // [Lp]: 0 for real tokens, -1e30 for the padding
+    bool has_ctx = false;
     float* cond_add = nullptr;     // [temb_ch] conditioning embedding of the time embedding (loco_set_cond)
     bool has_cond = false;
     float2* sxcache = nullptr;     // primal {S, xhat} per GroupNorm+SiLU input (bf16x3 path)
@@ -388,6 +399,7 @@ int build_program_adm(loco_ctx* c) {
     const int mc = cfg.ch, nlev = cfg.num_levels, R = cfg.resolution;
     c->n_in = cfg.in_channels * R * R;
     c->n_out = cfg.out_ch * R * R;
+    c->ctx_Lp = cfg.context_dim > 0 ? ((cfg.context_len + 63) / 64) * 64 : 0;
     auto heads_of = [&](int C) { return cfg.num_head_channels > 0 ? C / cfg.num_head_channels : 1; };
     auto add_res = [&](const std::string& name, int in_t, int out_t, int updown, bool in_is_skip) {
         Op r; r.kind = OP_RES; r.name = name; r.in = in_t; r.out = out_t; r.updown = updown;
@@ -415,6 +427,15 @@ int build_program_adm(loco_ctx* c) {
         a.o = new_tensor(c, t.C, t.H, t.W);
         a.n1 = new_norm(c, t.C);
         a.pn_n1 = name + ".norm"; a.pn_qkv = name + ".qkv"; a.pn_proj = name + ".proj_out";
+        if (cfg.context_dim > 0) {
+            a.has_x = true;
+            a.xmid = new_tensor(c, t.C, t.H, t.W);
+            a.xhn = new_tensor(c, t.C, t.H, t.W);
+            a.xq = new_tensor(c, t.C, t.H, t.W);
+            a.xS = new_tensor(c, a.heads, T, c->ctx_Lp);
+            a.xo = new_tensor(c, t.C, t.H, t.W);
+            a.nx = new_norm(c, t.C);
+        }
         c->ops.push_back(a);
     };
     // pass 1: skip stack (channels, resolution) in push order
@@ -668,6 +689,14 @@ void declare_all(loco_ctx* c) {
                     declare_param(c, op.pn_qkv + ".bias", {3 * C});
                     declare_param(c, op.pn_proj + ".weight", {C, C, 1});
                     declare_param(c, op.pn_proj + ".bias", {C});
+                    if (op.has_x) {
+                        const std::string x = op.name + ".xattn";
+                        declare_norm(c, x + ".norm", C);
+                        declare_param(c, x + ".q.weight", {C, C, 1}); declare_param(c, x + ".q.bias", {C});
+                        declare_lin(c, x + ".k", cfg.context_dim, C);
+                        declare_lin(c, x + ".v", cfg.context_dim, C);
+                        declare_param(c, x + ".proj_out.weight", {C, C, 1}); declare_param(c, x + ".proj_out.bias", {C});
+                    }
                 } else {
                     for (const char* p : {"q", "k", "v"}) declare_conv(c, op.name + "." + p, C, C, 1);
                     declare_conv(c, op.pn_proj, C, C, 1);
@@ -849,6 +878,16 @@ int finalize_params(loco_ctx* c) {
                                      {&c->params[op.name + ".q.bias"], &c->params[op.name + ".k.bias"],
                                       &c->params[op.name + ".v.bias"]}, &op.qkvc)) return -1;
                 if (make_conv1(c, op.pn_proj, &op.proj)) return -1;
+                if (op.has_x) {
+                    const std::string x = op.name + ".xattn";
+                    if (make_norm(c, x + ".norm", &op.nx) || make_conv1(c, x + ".q", &op.xqc) ||
+                        make_conv1(c, x + ".proj_out", &op.xproj)) return -1;
+                    if (upload(c, &op.xkw, c->params[x + ".k.weight"].data) || upload(c, &op.xkb, c->params[x + ".k.bias"].data) ||
+                        upload(c, &op.xvw, c->params[x + ".v.weight"].data) || upload(c, &op.xvb, c->params[x + ".v.bias"].data))
+                        return -1;
+                    const size_t kv = (size_t)c->tens[op.in].C * c->ctx_Lp;
+                    if (dalloc(c, &op.xK, kv) || dalloc(c, &op.xV, kv)) return -1;
+                }
                 break;
             }
             case OP_DOWN: case OP_UP: if (make_conv1(c, op.pn_conv, &op.conv)) return -1; break;
@@ -875,6 +914,10 @@ int finalize_params(loco_ctx* c) {
                 convf(op.qkvc, to.H, to.W); convf(op.proj, to.H, to.W);
                 double T = (double)to.H * to.W;
                 fl += 2.0 * 2.0 * T * T * to.C;
+                if (op.has_x) {
+                    convf(op.xqc, to.H, to.W); convf(op.xproj, to.H, to.W);
+                    fl += 2.0 * 2.0 * T * c->cfg.context_len * to.C;
+                }
                 break;
             }
         }
@@ -1002,6 +1045,52 @@ void gn_forward_stats(const Pass& p, const NormP& n, const float* x, long xbs, i
                     p.c->stats_per_sample, p.c->red, p.st);
 }
 
+
+// ------------------------------ text cross-attention stage of an attention block ------------------------------
+// out = xmid + proj(o),  o = V_ctx P^T,  P = softmax_l(scale q^T K_ctx),  q = Wq GN(xmid); K_ctx / V_ctx [C][Lp] are the
+// projected encoder states (loco_set_context), constant with respect to the image, so the tangent / cotangent only
+// travel through q.  Generic GEMM + row kernels: the score rows are only Lp (<= 128) long.
+struct XA {                     // tensors of one pass: `a` = the arena holding this pass's values, `ap` = the primal arena
+    loco_ctx* c; const Op* op; hipStream_t st; int B; int C, T, NH, CH, Lp;
+    float scale;
+};
+XA xa_of(loco_ctx* c, const Op& op, int B, hipStream_t st) {
+    XA x; x.c = c; x.op = &op; x.st = st; x.B = B;
+    const Tens& t = c->tens[op.in];
+    x.C = t.C; x.T = t.H * t.W; x.NH = op.heads; x.CH = x.C / x.NH; x.Lp = c->ctx_Lp;
+    x.scale = 1.0f / std::sqrt((float)x.CH);
+    return x;
+}
+// S[b][h][i][l] = alpha * sum_c X[b][h*CH+c][i] K[h*CH+c][l]      (X: q / dq / g_o, K: K_ctx or V_ctx)
+void xa_scores(const XA& x, const float* X, long x_bs, const float* K, float* S, long s_bs, float alpha, bool mask) {
+    GemmArgs g; std::memset(&g, 0, sizeof(g));
+    g.A = X; g.sam = 1; g.sak = x.T; g.sab = x_bs; g.sah = (long)x.CH * x.T;
+    g.Bm = K; g.sbk = x.Lp; g.sbn = 1; g.sbb = 0; g.sbh = (long)x.CH * x.Lp;
+    g.C = S; g.scm = x.Lp; g.scn = 1; g.scb = s_bs; g.sch = (long)x.T * x.Lp;
+    g.M = x.T; g.N = x.Lp; g.K = x.CH; g.batch = x.B; g.batch2 = x.NH; g.alpha = alpha; g.beta = 0.f;
+    g.colbias = mask ? x.c->ctx_colbias : nullptr;
+    launch_gemm(g, x.st);
+}
+// O[b][h*CH+c][i] = sum_l K[h*CH+c][l] S[b][h][i][l]              (K: V_ctx or K_ctx, S: P / dP / g_S)
+void xa_values(const XA& x, const float* K, const float* S, long s_bs, float* O, long o_bs) {
+    GemmArgs g; std::memset(&g, 0, sizeof(g));
+    g.A = K; g.sam = x.Lp; g.sak = 1; g.sab = 0; g.sah = (long)x.CH * x.Lp;
+    g.Bm = S; g.sbk = 1; g.sbn = x.Lp; g.sbb = s_bs; g.sbh = (long)x.T * x.Lp;
+    g.C = O; g.scm = x.T; g.scn = 1; g.scb = o_bs; g.sch = (long)x.CH * x.T;
+    g.M = x.CH; g.N = x.T; g.K = x.Lp; g.batch = x.B; g.batch2 = x.NH; g.alpha = 1.f; g.beta = 0.f;
+    launch_gemm(g, x.st);
+}
+void xa_conv1x1(loco_ctx* c, const ConvP& w, bool dgrad, const float* in, long in_bs, float* out, long out_bs, int C, int H,
+                int W, int B, const float* res, long res_bs, bool with_bias, hipStream_t st) {
+    ConvArgs a; conv_defaults(a);
+    a.in = in; a.in_bs = in_bs; a.Cin = C; a.Hin = H; a.Win = W;
+    setw(a, w, dgrad); a.pad = 0;
+    if (with_bias) a.bias = w.bias;
+    a.res = res; a.res_bs = res_bs;
+    a.out = out; a.out_bs = out_bs; a.Cout = C; a.Hout = H; a.Wout = W; a.B = B;
+    run_conv(c, a, 1, st);
+}
+
 // ------------------------------ forward ------------------------------------
 int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, float* stats, hipStream_t st,
                  const float* t_ptr = nullptr) {
@@ -1106,8 +1195,25 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 pr.in = p.T(op.o); pr.in_bs = p.bs(); pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, false); pr.bias = op.proj.bias; pr.pad = 0;
                 pr.res = p.T(op.in); pr.res_bs = p.bs();
-                pr.out = p.T(op.out); pr.out_bs = p.bs(); pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
+                pr.out = p.T(op.has_x ? op.xmid : op.out); pr.out_bs = p.bs(); pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
                 run_conv(c, pr, 1, st);
+                if (op.has_x) {
+                    if (!c->has_ctx) { c->err = "this architecture has cross-attention stages: call loco_set_context first"; return -1; }
+                    const XA x = xa_of(c, op, B, st);
+                    gn_forward_stats(p, op.nx, p.T(op.xmid), p.bs(), HW);
+                    NS sx = nstats(c, stats, op.nx);
+                    ConvArgs qa; conv_defaults(qa);
+                    qa.in = p.T(op.xmid); qa.in_bs = p.bs(); qa.Cin = C; qa.Hin = to.H; qa.Win = to.W;
+                    setw(qa, op.xqc, false); qa.bias = op.xqc.bias; qa.pad = 0;
+                    qa.mode = CM_GN; qa.sc = sx.sc; qa.sh = sx.sh; qa.scsh_bs = SB;
+                    qa.out = p.T(op.xq); qa.out_bs = p.bs(); qa.Cout = C; qa.Hout = to.H; qa.Wout = to.W; qa.B = B;
+                    run_conv(c, qa, 1, st);
+                    xa_scores(x, p.T(op.xq), p.bs(), op.xK, p.T(op.xS), p.bs(), x.scale, true);
+                    launch_softmax_rows(p.T(op.xS), (long)NH * T, x.Lp, st, B, p.bs());
+                    xa_values(x, op.xV, p.T(op.xS), p.bs(), p.T(op.xo), p.bs());
+                    xa_conv1x1(c, op.xproj, false, p.T(op.xo), p.bs(), p.T(op.out), p.bs(), C, to.H, to.W, B,
+                               p.T(op.xmid), p.bs(), true, st);
+                }
                 break;
             }
             case OP_DOWN: case OP_UP: {
@@ -1258,8 +1364,21 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = TT(op.o); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, false); pr.pad = 0; pr.res = TT(op.in); pr.res_bs = PS;
-                pr.out = TT(op.out); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
+                pr.out = TT(op.has_x ? op.xmid : op.out); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
                 run_conv(c, pr, 1, st);
+                if (op.has_x) {
+                    const XA x = xa_of(c, op, B, st);
+                    tangent_stats(c, op.nx, TT(op.xmid), PS, TP(op.xmid), HW, B, st);
+                    NS spx = nstats(c, c->statsP, op.nx);
+                    NS stx = nstats(c, c->statsT, op.nx);
+                    launch_gn_apply(1, TT(op.xmid), PS, TP(op.xmid), 0, nullptr, 0, TT(op.xhn), PS, 0, B, C, HW,
+                                    cfg.gn_groups, spx.sc, spx.sh, spx.mr, 0, 0, stx.tst, c->stats_per_sample, st);
+                    xa_conv1x1(c, op.xqc, false, TT(op.xhn), PS, TT(op.xq), PS, C, to.H, to.W, B, nullptr, 0, false, st);
+                    xa_scores(x, TT(op.xq), PS, op.xK, TT(op.xS), PS, 1.f, false);                  // dS = dq^T K
+                    launch_softmax_jac(TT(op.xS), TP(op.xS), (long)NH * T, x.Lp, (long)NH * T, x.scale, st, B, PS);
+                    xa_values(x, op.xV, TT(op.xS), PS, TT(op.xo), PS);                              // do = V dP^T
+                    xa_conv1x1(c, op.xproj, false, TT(op.xo), PS, TT(op.out), PS, C, to.H, to.W, B, TT(op.xmid), PS, false, st);
+                }
                 break;
             }
             case OP_DOWN: case OP_UP: {
@@ -1406,9 +1525,24 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 const long HS = 3L * CH * T, SS = (long)T * T, OS = (long)CH * T;
                 float* q = TP(op.qkv); float* k = q + (long)CH * T; float* v = k + (long)CH * T;
                 float* gq = TG(op.qkv); float* gk = gq + (long)CH * T; float* gv = gk + (long)CH * T;
+                const int so = op.has_x ? op.xmid : op.out;       // output tensor of the self-attention stage
+                if (op.has_x) {
+                    // cotangent of the cross-attention stage: g_out -> g_xmid (residual + the q path through GN)
+                    const XA x = xa_of(c, op, B, st);
+                    xa_conv1x1(c, op.xproj, true, TG(op.out), PS, TG(op.xo), PS, C, to.H, to.W, B, nullptr, 0, false, st);
+                    xa_scores(x, TG(op.xo), PS, op.xV, TG(op.xS), PS, 1.f, false);                  // g_P = g_o^T V
+                    launch_softmax_jac(TG(op.xS), TP(op.xS), (long)NH * T, x.Lp, (long)NH * T, x.scale, st, B, PS);
+                    xa_values(x, op.xK, TG(op.xS), PS, TG(op.xq), PS);                              // g_q = K g_S^T
+                    xa_conv1x1(c, op.xqc, true, TG(op.xq), PS, TG(op.xhn), PS, C, to.H, to.W, B, nullptr, 0, false, st);
+                    cot_stats(c, op.nx, TG(op.xhn), PS, TP(op.xmid), HW, B, 2, st);
+                    NS spx = nstats(c, c->statsP, op.nx);
+                    NS stx = nstats(c, c->statsT, op.nx);
+                    launch_gn_apply(3, TG(op.xhn), PS, TP(op.xmid), 0, TG(op.out), PS, TG(op.xmid), PS, 0, B, C, HW, G,
+                                    spx.sc, spx.sh, spx.mr, 0, 0, stx.tst, c->stats_per_sample, st);
+                }
                 // g_o = proj^T g_out
                 ConvArgs pr; conv_defaults(pr);
-                pr.in = TG(op.out); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
+                pr.in = TG(so); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, true); pr.pad = 0;
                 pr.out = TG(op.o); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
                 run_conv(c, pr, 1, st);
@@ -1447,7 +1581,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 cot_stats(c, op.n1, TG(op.hn), PS, TP(op.in), HW, B, 2, st);
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
-                launch_gn_apply(3, TG(op.hn), PS, TP(op.in), 0, TG(op.out), PS, TG(op.in), PS,
+                launch_gn_apply(3, TG(op.hn), PS, TP(op.in), 0, TG(so), PS, TG(op.in), PS,
                                 op.in_is_skip ? 1 : 0, B, C, HW, G, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
                 break;
             }
@@ -1937,6 +2071,40 @@ int loco_set_cond(loco_ctx* c, const float* emb_add, void* stream) {
     HIPCHK(c, hipMemcpyAsync(c->cond_add, emb_add, (size_t)c->cfg.ch * 4 * sizeof(float), hipMemcpyDeviceToDevice,
                              (hipStream_t)stream));
     c->has_cond = true;
+    return 0;
+}
+
+int loco_set_context(loco_ctx* c, const float* tokens, void* stream) {
+    if (!c) return -2;
+    if (c->cfg.context_dim <= 0) { c->err = "this architecture has no cross-attention stages (context_dim = 0)"; return -2; }
+    if (!tokens) { c->err = "loco_set_context: null tokens"; return -2; }
+    if (finalize_params(c)) return -3;
+    hipStream_t st = (hipStream_t)stream;
+    c->primal_ok = false;
+    const int L = c->cfg.context_len, D = c->cfg.context_dim, Lp = c->ctx_Lp;
+    if (!c->ctx_colbias) {
+        std::vector<float> cb(Lp, -1e30f);
+        for (int l = 0; l < L; ++l) cb[l] = 0.f;
+        if (upload(c, &c->ctx_colbias, cb)) return -1;
+    }
+    for (auto& op : c->ops) {
+        if (op.kind != OP_ATTN || !op.has_x) continue;
+        const int C = c->tens[op.in].C;
+        for (int w = 0; w < 2; ++w) {
+            float* dst = w ? op.xV : op.xK;
+            HIPCHK(c, hipMemsetAsync(dst, 0, (size_t)C * Lp * sizeof(float), st));
+            // dst[c][l] = sum_d W[c][d] tokens[l][d] + b[c]
+            GemmArgs g; std::memset(&g, 0, sizeof(g));
+            g.A = w ? op.xvw : op.xkw; g.sam = D; g.sak = 1;
+            g.Bm = tokens; g.sbk = 1; g.sbn = D;
+            g.C = dst; g.scm = Lp; g.scn = 1;
+            g.bias = w ? op.xvb : op.xkb;
+            g.M = C; g.N = L; g.K = D; g.batch = 1; g.alpha = 1.f; g.beta = 0.f;
+            launch_gemm(g, st);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    c->has_ctx = true;
     return 0;
 }
 

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             float* c = g.C + (long)bz * g.scb + (long)hz * g.sch + off;
             if (g.beta != 0.f) v += g.beta * (*c);
             if (g.bias) v += g.bias[m];
+                if (g.colbias) v += g.colbias[n];
             if (g.R) v += g.R[(long)bz * g.srb + (long)hz * g.sch + off];
             *c = v;
         }
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 float* c = g.C + (long)bz * g.scb + (long)hz * g.sch + off;
                 if (g.beta != 0.f) v += g.beta * (*c);
                 if (g.bias) v += g.bias[m];
+                if (g.colbias) v += g.colbias[n];
                 if (g.R) v += g.R[(long)bz * g.srb + (long)hz * g.sch + off];
                 *c = v;
             }

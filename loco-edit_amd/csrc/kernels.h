@@ -78,6 +78,7 @@ struct GemmArgs {
     const float* Bm; long sbk, sbn, sbb;
     float* C; long scm, scn, scb;
     const float* bias;           // per m or nullptr
+    const float* colbias;        // per n or nullptr (mask of padded context columns: 0 / -1e30)
     const float* R; long srb;    // residual with C's (m,n) strides, batch stride srb; or nullptr
     int M, N, K, batch;
     float alpha, beta;

@@ -76,7 +76,7 @@ _FLAGS = [
 ]
 _UNET_PRESETS = {'celeba_ddpm': 'CELEBA_DDPM', 'ffhq_p2': 'FFHQ_P2', 'tiny_ddpm': 'TINY_DDPM', 'mid_ddpm': 'MID_DDPM',
                  'tiny_adm': 'TINY_ADM', 'if64_standin': 'IF64_STANDIN', 'sd64_standin': 'SD64_STANDIN',
-                 'tiny_latent': 'TINY_LATENT'}
+                 'sd64_xattn_standin': 'SD64_XATTN_STANDIN', 'tiny_latent': 'TINY_LATENT', 'tiny_latent_xattn': 'TINY_LATENT_XATTN'}
 _VAE_PRESETS = {'sd_vae_decoder': 'SD_VAE_DECODER', 'tiny_decoder': 'TINY_DECODER'}
 _TILDA_V = ["proj_null[for-null](edit-null)-direct", "(for-edit)-direct", "(edit-null)-direct",
             "null+(for-null)+(edit-null)", "null+(for-null)", "null+(edit-null)", "(for-edit)",
@@ -192,7 +192,7 @@ def _preset_t2i(args, family):
     from . import config
     if args.is_stable_diffusion:
         if getattr(args, 'unet_config', None) is None:
-            args.unet_config = config.SD64_STANDIN
+            args.unet_config = config.SD64_XATTN_STANDIN      # latent U-Net with text cross-attention (BASELINE config 4)
         if getattr(args, 'vae_config', None) is None:
             args.vae_config = config.SD_VAE_DECODER
         args.c_in = args.unet_config.in_channels           # 4

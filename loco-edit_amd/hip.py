@@ -27,7 +27,7 @@ SYMBOLS = [
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop", "loco_debug_tensor",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision",
-    "loco_bench_conv", "loco_set_cond", "loco_lincomb", "loco_masked_axpby",
+    "loco_bench_conv", "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby",
 ]
 
 
@@ -38,6 +38,7 @@ class LocoCfg(C.Structure):
         ("num_attn_res", C.c_int32), ("attn_resolutions", C.c_int32 * 8), ("gn_groups", C.c_int32),
         ("gn_eps", C.c_float), ("max_batch", C.c_int32),
         ("arch", C.c_int32), ("num_head_channels", C.c_int32), ("learn_sigma", C.c_int32),
+        ("context_dim", C.c_int32), ("context_len", C.c_int32),
     ]
 
 
@@ -89,6 +90,7 @@ def load_library():
     lib.loco_get_precision.argtypes = [vp]
     lib.loco_bench_conv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32), vp]
     lib.loco_set_cond.argtypes = [vp, vp, vp]
+    lib.loco_set_context.argtypes = [vp, vp, vp]
     lib.loco_masked_axpby.argtypes = [vp, vp, vp, f32, f32, i32, vp, vp]
     lib.loco_lincomb.argtypes = [vp, C.POINTER(vp), C.POINTER(f32), i32, vp, i64, vp]
     lib.loco_profile_enable.argtypes = [vp, i32]
@@ -140,6 +142,7 @@ class LocoEngine:
         c.gn_groups, c.gn_eps, c.max_batch = cfg.gn_groups, cfg.gn_eps, self.max_batch
         c.arch = {"ddpm": 0, "adm": 1, "dec": 2}[cfg.arch]
         c.num_head_channels, c.learn_sigma = cfg.num_head_channels, int(cfg.learn_sigma)
+        c.context_dim, c.context_len = cfg.context_dim, cfg.context_len
         self._ctx = C.c_void_p()
         rc = self.lib.loco_create(C.byref(c), C.byref(self._ctx))
         if rc != 0:
@@ -295,6 +298,15 @@ class LocoEngine:
             if emb_add.numel() != 4 * self.cfg.ch:
                 raise ValueError("conditioning embedding must have 4*ch elements")
         self._check(self.lib.loco_set_cond(self._ctx, _ptr(emb_add), _stream()), "loco_set_cond")
+
+    def set_context(self, tokens: torch.Tensor):
+        """Encoder states of the prompt [context_len, context_dim] for the cross-attention stages (the
+        ``encoder_hidden_states`` of ``self.unet(...)``, edit.py:664-667); projected to keys / values once."""
+        _chk_dev(tokens)
+        if tuple(tokens.shape) != (self.cfg.context_len, self.cfg.context_dim):
+            raise ValueError(f"context must be [{self.cfg.context_len}, {self.cfg.context_dim}], got {tuple(tokens.shape)}")
+        self._check(self.lib.loco_set_context(self._ctx, _ptr(tokens), _stream()), "loco_set_context")
+        torch.cuda.current_stream().synchronize()     # `tokens` may be a temporary
 
     def masked_axpby(self, V: torch.Tensor, E: torch.Tensor, cv: float, ce: float) -> torch.Tensor:
         """mask * (cv*V + ce*E) with the mask of the last pmp_primal; V, E: [k, n]."""

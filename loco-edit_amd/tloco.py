@@ -160,10 +160,13 @@ class EditDeepFloydIF(object):
         pe = getattr(args, "prompt_emb", None)
         if pe is None and getattr(args, "prompt_emb_path", ""):
             pe = torch.load(args.prompt_emb_path)
+        # text enters through cross-attention stages when the architecture has them (context_dim > 0: tokens
+        # [context_len, context_dim] via loco_set_context), otherwise pooled through the time embedding (loco_set_cond)
+        self.use_context = cfg.context_dim > 0
         if pe is None:
             g = torch.Generator().manual_seed(int(getattr(args, "prompt_emb_seed", 31)))
-            D = int(getattr(args, "cond_dim", 16))
-            pe = {k: torch.randn(1, 7, D, generator=g) for k in ("for", "edit", "null")}
+            ntok, D = (cfg.context_len, cfg.context_dim) if self.use_context else (7, int(getattr(args, "cond_dim", 16)))
+            pe = {k: torch.randn(1, ntok, D, generator=g) for k in ("for", "edit", "null")}
         self.for_prompt_emb, self.edit_prompt_emb, self.null_prompt_emb = pe["for"], pe["edit"], pe["null"]
         self.for_prompt, self.edit_prompt, self.null_prompt = args.for_prompt, args.edit_prompt, ""
         # ---- the conditional denoiser: one engine context per prompt
@@ -177,9 +180,11 @@ class EditDeepFloydIF(object):
                 if seed is None:
                     raise ValueError("no checkpoint: pass --ckpt_path or --synthetic_weights SEED")
                 params = dict(synth_params(cfg, seed=int(seed)))
-                params.update(cond_params(cfg, self.for_prompt_emb.shape[-1], seed=int(seed)))
-        self.cond_w = torch.as_tensor(np.asarray(params["cond_proj.weight"]), dtype=torch.float32)
-        self.cond_b = torch.as_tensor(np.asarray(params["cond_proj.bias"]), dtype=torch.float32)
+                if not self.use_context:
+                    params.update(cond_params(cfg, self.for_prompt_emb.shape[-1], seed=int(seed)))
+        if not self.use_context:
+            self.cond_w = torch.as_tensor(np.asarray(params["cond_proj.weight"]), dtype=torch.float32)
+            self.cond_b = torch.as_tensor(np.asarray(params["cond_proj.bias"]), dtype=torch.float32)
         unet_params = {k: v for k, v in params.items() if not k.startswith("cond_proj.")}
         self.branches: Dict[str, LocoEngine] = {}
         prec = getattr(args, "precision", None) or os.environ.get("LOCO_PRECISION")
@@ -222,7 +227,10 @@ class EditDeepFloydIF(object):
     def _bind(self, name: str, prompt_emb: torch.Tensor):
         key = (prompt_emb.data_ptr(), tuple(prompt_emb.shape), float(prompt_emb.sum()))
         if self._cond_of.get(name) != key:
-            self.branches[name].set_cond(self.cond_embedding(prompt_emb).to(self.device).contiguous())
+            if self.use_context:
+                self.branches[name].set_context(prompt_emb[0].to(self.device, torch.float32).contiguous())
+            else:
+                self.branches[name].set_cond(self.cond_embedding(prompt_emb).to(self.device).contiguous())
             self._cond_of[name] = key
 
     def _bind_all(self, for_e, edit_e, null_e):

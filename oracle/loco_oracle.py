@@ -220,8 +220,26 @@ def _adm_attn(p, name, x, cfg):
     return (xr + h).reshape(b, c, hh, ww)
 
 
+def _adm_xattn(p, name, x, context, cfg):
+    """Text cross-attention stage of the stand-in denoisers (no counterpart in guided_diffusion; the reference's
+    cross-attention lives in un-vendored diffusers blocks): h = x + proj(softmax(q^T k / sqrt(d)) v) with q from
+    GN(x) per image token and k, v Linear projections of the [B, L, D] encoder states, heads of num_head_channels."""
+    b, c, hh, ww = x.shape
+    nh = c // cfg.num_head_channels if cfg.num_head_channels > 0 else 1
+    ch = c // nh
+    h = _adm_gn(p, name + ".norm", x, cfg).reshape(b, c, -1)
+    q = F.conv1d(h, p[name + ".q.weight"], p[name + ".q.bias"])                        # [B, C, T]
+    k = F.linear(context, p[name + ".k.weight"], p[name + ".k.bias"]).transpose(1, 2)   # [B, C, L]
+    v = F.linear(context, p[name + ".v.weight"], p[name + ".v.bias"]).transpose(1, 2)
+    q, k, v = (z.reshape(b * nh, ch, -1) for z in (q, k, v))
+    w_ = torch.softmax(torch.einsum("bct,bcl->btl", q, k) * (ch ** -0.5), dim=-1)
+    o = torch.einsum("btl,bcl->bct", w_, v).reshape(b, c, -1)
+    o = F.conv1d(o, p[name + ".proj_out.weight"], p[name + ".proj_out.bias"])
+    return x + o.reshape(b, c, hh, ww)
+
+
 def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Optional[torch.Tensor] = None,
-                     full: bool = False):
+                     full: bool = False, context: Optional[torch.Tensor] = None):
     """UNetModel.forward returning the eps half -- unet.py:636-684, constructor :398-617.
     ``emb_add`` [B, 4*ch] (or [4*ch]) is added to the time embedding where the class embedding goes
     (``emb = emb + self.label_emb(y)``, unet.py:660-662); ``full`` keeps the learned-variance channels."""
@@ -229,6 +247,13 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Option
         if trace is not None:
             trace[name] = v.detach().clone()
         return v
+
+    def attn(name, h):     # self-attention [+ the text cross-attention stage of the stand-in denoisers]
+        h = _adm_attn(p, name, h, cfg)
+        if getattr(cfg, "context_dim", 0) > 0:
+            ctx = context if context.dim() == 3 else context[None]
+            h = _adm_xattn(p, name + ".xattn", h, ctx.expand(h.shape[0], -1, -1), cfg)
+        return h
     t = t.reshape(1) if t.dim() == 0 else t
     emb = timestep_embedding_adm(t.to(torch.float32), cfg.ch)
     emb = F.linear(emb, p["time_embed.0.weight"], p["time_embed.0.bias"])
@@ -245,14 +270,14 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Option
         for _ in range(cfg.num_res_blocks):
             h = rec(f"input_blocks.{ib}.0", _adm_resblock(p, f"input_blocks.{ib}.0", h, emb, cfg))
             if res_px in cfg.attn_resolutions:
-                h = rec(f"input_blocks.{ib}.1", _adm_attn(p, f"input_blocks.{ib}.1", h, cfg))
+                h = rec(f"input_blocks.{ib}.1", attn(f"input_blocks.{ib}.1", h))
             hs.append(h); ib += 1
         if lvl != nlev - 1:
             h = rec(f"input_blocks.{ib}.0", _adm_resblock(p, f"input_blocks.{ib}.0", h, emb, cfg, down=True))
             hs.append(h); ib += 1
             res_px //= 2
     h = rec("middle_block.0", _adm_resblock(p, "middle_block.0", h, emb, cfg))
-    h = rec("middle_block.1", _adm_attn(p, "middle_block.1", h, cfg))
+    h = rec("middle_block.1", attn("middle_block.1", h))
     h = rec("middle_block.2", _adm_resblock(p, "middle_block.2", h, emb, cfg))
     ob = 0
     for lvl in reversed(range(nlev)):
@@ -261,7 +286,7 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Option
             h = rec(f"output_blocks.{ob}.0", _adm_resblock(p, f"output_blocks.{ob}.0", h, emb, cfg))
             j = 1
             if res_px in cfg.attn_resolutions:
-                h = rec(f"output_blocks.{ob}.{j}", _adm_attn(p, f"output_blocks.{ob}.{j}", h, cfg)); j += 1
+                h = rec(f"output_blocks.{ob}.{j}", attn(f"output_blocks.{ob}.{j}", h)); j += 1
             if lvl and i == cfg.num_res_blocks:
                 h = rec(f"output_blocks.{ob}.{j}", _adm_resblock(p, f"output_blocks.{ob}.{j}", h, emb, cfg, up=True))
                 res_px *= 2

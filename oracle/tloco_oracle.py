@@ -78,6 +78,8 @@ class OracleTLoco:
         self.edit_t_idx = int((self.sched.timesteps - edit_t * 1000).abs().argmin())
 
     def unet_full(self, x, t, prompt_emb):
+        if getattr(self.cfg, "context_dim", 0) > 0:       # text through the cross-attention stages
+            return orc.unet_forward_adm(self.p, self.cfg, x, t, full=True, context=prompt_emb)
         return orc.unet_forward_adm(self.p, self.cfg, x, t, emb_add=cond_embedding(self.p, prompt_emb), full=True)
 
     # -- edit.py:1286-1373

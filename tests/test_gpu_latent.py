@@ -247,14 +247,15 @@ def test_cli_shipped_sd_script_on_the_standins(tmp_path, monkeypatch):
 
 
 def test_latent_solver_at_stable_diffusion_size(tmp_path):
-    """BASELINE config 4 at its size on the stand-ins: 4x64x64 latent, SD-width denoiser (2 CFG branches), the SD
+    """BASELINE config 4 at its size on the stand-ins: 4x64x64 latent, SD-width denoiser with text cross-attention over
+    77 x 768 prompt states (2 CFG branches), the SD
     autoencoder's decoder geometry (64 -> 512, 4096-token mid attention), mask on the decoded 3x512x512 image.
     No reference fixture at this size (parity of the architectures is unpinned): adjointness of the composed operator,
     orthonormal descending basis, shapes."""
-    from loco_edit_amd.config import SD64_STANDIN, SD_VAE_DECODER
+    from loco_edit_amd.config import SD64_XATTN_STANDIN, SD_VAE_DECODER
     from loco_edit_amd.tloco_sd import EditStableDiffusion
     os.environ.pop("WORLD_SIZE", None)
-    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=SD64_STANDIN, vae_config=SD_VAE_DECODER,
+    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=SD64_XATTN_STANDIN, vae_config=SD_VAE_DECODER,
                      synthetic_weights=0, ckpt_path="", vae_ckpt_path="", max_batch=4, precision="bf16x3", dataset_name="Random",
                      for_steps=100, use_yh_custom_scheduler=True, guidance_scale=7.5, guidance_scale_edit=4.0, prompt_emb=None,
                      prompt_emb_seed=31, cond_dim=64, for_prompt="a", edit_prompt="b", edit_t=0.7, sampling_mode=False,
@@ -308,3 +309,86 @@ def test_long_attention_products_on_the_bf16_pipe():
         x_ref = orc.decoder_forward(orc.to_torch(params), cfg, z)
     assert rel(res["f32"][0], x_ref) < 2e-5 and rel(res["bf16x3"][0], x_ref) < 2e-4
     assert rel(res["bf16x3"][1], res["f32"][1]) < 5e-4 and rel(res["bf16x3"][2], res["f32"][2]) < 5e-4
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_text_cross_attention_stages_vs_restatement(prec):
+    """Denoiser with a text cross-attention stage behind every attention block (`context_dim > 0`, encoder states via
+    `loco_set_context`): forward on a batch, J V and U^T J of eps against the CPU restatement (autodiff of
+    unet_forward_adm with `context=`); a second context changes the output; missing context is refused."""
+    from loco_edit_amd.config import TINY_LATENT_XATTN as cfg
+    from loco_edit_amd.hip import LocoEngine
+    params = synth_params(cfg, 0)
+    p = orc.to_torch(params)
+    eng = LocoEngine(cfg, max_batch=4, device=torch.device(DEV))
+    eng.load_state_dict(params)
+    eng.set_precision(prec)
+    g = torch.Generator().manual_seed(41)
+    z = torch.randn(1, 4, 16, 16, generator=g)
+    ctx = torch.randn(cfg.context_len, cfg.context_dim, generator=g)
+    t = torch.tensor(603.0)
+    with pytest.raises(RuntimeError):
+        eng.unet_forward(z.to(DEV), float(t))
+    eng.set_context(ctx.to(DEV).contiguous())
+    f = lambda z_: orc.unet_forward_adm(p, cfg, z_, t, context=ctx)
+    tol = TOL[prec]
+    zb = torch.cat([z, 0.5 * z.flip(-1), z + 0.2], dim=0)
+    with torch.no_grad():
+        assert rel(eng.unet_forward(zb.to(DEV), float(t)), f(zb)) < tol
+    V = torch.randn(3, cfg.n, generator=g)
+    JV = torch.stack([torch.func.jvp(f, (z,), (v.view_as(z),))[1].reshape(-1) for v in V])
+    eng.pmp_primal(z.to(DEV), float(t), 0.5, None, use_et=True)
+    U = eng.pmp_jvp(V.to(DEV))
+    assert rel(U, JV) < 5 * tol
+    Uc = torch.randn(3, cfg.n, generator=g)
+    zz = z.clone().requires_grad_(True)
+    out = f(zz).reshape(-1)
+    Aref = torch.stack([torch.autograd.grad((out * u).sum(), zz, retain_graph=True)[0].reshape(-1) for u in Uc])
+    A = eng.pmp_vjp(Uc.to(DEV))
+    assert rel(A, Aref) < 5 * tol
+    lhs, rhs = (U.double().cpu() * Uc.double()).sum(), (V.double() * A.double().cpu()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-4
+    e1 = eng.unet_forward(z.to(DEV), float(t))
+    eng.set_context((0.5 * ctx).to(DEV).contiguous())
+    with pytest.raises(RuntimeError):
+        eng.pmp_jvp(V.to(DEV))                      # a new context invalidates the cached primal
+    with torch.no_grad():
+        e2 = eng.unet_forward(z.to(DEV), float(t))
+        assert rel(e2, orc.unet_forward_adm(p, cfg, z, t, context=0.5 * ctx)) < tol and rel(e2, e1) > 1e-3
+
+
+def test_latent_tloco_with_text_cross_attention_vs_restatement(tmp_path):
+    """BASELINE config 4's shape class: latent denoiser WITH text cross-attention (prompt tokens through
+    `loco_set_context`, one context per CFG branch) + decoder.  CFG noise, decoded x0_hat and the 3-iteration subspace
+    solve of the class against the CPU restatement (oracle/tloco_sd_oracle.py with `context=`); the orchestration
+    itself is pinned by the reference-generated fixture of the tests above."""
+    import tloco_sd_oracle as tsd
+    from loco_edit_amd.config import TINY_LATENT_XATTN as cfg
+    from loco_edit_amd.tloco_sd import EditStableDiffusion
+    os.environ.pop("WORLD_SIZE", None)
+    g = torch.Generator().manual_seed(31)
+    pe = {k: torch.randn(1, cfg.context_len, cfg.context_dim, generator=g) for k in ("for", "edit", "null")}
+    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=cfg, vae_config=TINY_DECODER,
+                     synthetic_weights=0, ckpt_path="", vae_ckpt_path="", max_batch=8, precision="f32", dataset_name="Random",
+                     for_steps=100, use_yh_custom_scheduler=True, guidance_scale=7.5, guidance_scale_edit=4.0, prompt_emb=pe,
+                     for_prompt="a", edit_prompt="b", edit_t=0.7, sampling_mode=False, tilda_v_score_type="null+(for-null)+(edit-null)",
+                     ablation_method="null-space-proj", mask_type="SAM", vT_path="", use_sega=False,
+                     x_space_guidance_edit_step=1.0, x_space_guidance_scale=0.5, x_space_guidance_num_step=16,
+                     result_folder=str(tmp_path))
+    ed = EditStableDiffusion(args)
+    assert ed.use_context
+    ot = tsd.OracleTLocoSD(orc.to_torch(synth_params(cfg, 0)), cfg, orc.to_torch(synth_params(TINY_DECODER, 0)), TINY_DECODER,
+                           guidance_scale=7.5, guidance_scale_edit=4.0)
+    z = torch.randn(1, 4, 16, 16, generator=g)
+    t = ed.scheduler.timesteps[ed.edit_t_idx]
+    F, E, N = pe["for"], pe["edit"], pe["null"]
+    mask = torch.zeros(3, 64, 64, dtype=torch.bool); mask[:, 20:40, 12:44] = True
+    with torch.no_grad():
+        for mode in ("null+(for-null)+(edit-null)", "(for-edit)"):
+            assert rel(ed._classifer_free_guidance(z.to(DEV), t, F, E, N, mode, True), ot.cfg_noise(z, t, F, E, N, mode)) < 1e-4
+        assert rel(ed.get_x0(z.to(DEV), t, ed.edit_t_idx, F, E, N, mask=mask), ot.get_x0(z, t, F, E, N, mask=mask)) < 2e-4
+    v0 = torch.randn(cfg.n, 2, generator=g)
+    u, s, vT = ed.local_encoder_decoder_pullback_zt(z.to(DEV), t, ed.edit_t_idx, F, E, N, pca_rank=2, min_iter=3, max_iter=3,
+                                                    mask=mask, mode="null+(for-null)", v0=v0.to(DEV), verbose=False)
+    ou, os_, ovT = ot.pullback(z, t, F, E, N, 2, v0, min_iter=3, max_iter=3, mask=mask, mode="null+(for-null)")
+    assert torch.allclose(s.cpu(), os_, rtol=1e-3) and cosrow(vT, ovT).min().item() > 0.999

@@ -7,7 +7,8 @@ import torch
 import loco_oracle as orc
 import tloco_sd_oracle as tsd
 import loco_edit_amd  # noqa: F401
-from loco_edit_amd.config import TINY_DECODER, TINY_LATENT, SD64_STANDIN, SD_VAE_DECODER, param_shapes, synth_params
+from loco_edit_amd.config import (TINY_DECODER, TINY_LATENT, SD64_STANDIN, SD64_XATTN_STANDIN, SD_VAE_DECODER, param_shapes,
+                                  synth_params)
 from loco_edit_amd.tloco import cond_params
 from loco_edit_amd.tloco_sd import SDScheduler
 
@@ -69,7 +70,8 @@ def test_preset_routes_stable_diffusion_to_the_latent_path(tmp_path, monkeypatch
     a = define_argparser.preset(a)
     assert a.is_stable_diffusion and not a.is_DeepFloyd_IF_diffusion and not a.is_LCM
     assert a.exp == "Stable_Diffusion-Random-n" and (a.c_in, a.image_size, a.memory_bound) == (4, 64, 5)
-    assert a.unet_config is SD64_STANDIN and a.vae_config is SD_VAE_DECODER
+    assert a.unet_config is SD64_XATTN_STANDIN and a.vae_config is SD_VAE_DECODER
+    assert (a.unet_config.context_len, a.unet_config.context_dim) == (77, 768)
     b = define_argparser.parse_args(["--model_name", "SimianLuo/LCM_Dreamshaper_v7", "--seed", "3", "--device", "cpu"])
     with pytest.raises(NotImplementedError):
         define_argparser.preset(b)
