@@ -122,3 +122,88 @@ def vendored_to_hf_unet2d(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[
                     v = v.reshape(v.shape[0], v.shape[1])
                 out[f"mid_block.attentions.0.{inv_attn[p[2]]}.{suffix}"] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# diffusers ``AutoencoderKL`` (the ``vae`` of a Stable Diffusion pipeline, reference edit.py:498) -> the decoder engine's
+# latent-diffusion ``Decoder`` naming (config.dec_param_shapes).  Only ``post_quant_conv`` and ``decoder.*`` are
+# consumed (``vae.decode``); written from the published layout, **parity unpinned** like the U-Net map above.
+def is_hf_autoencoder_kl(sd: Dict[str, torch.Tensor]) -> bool:
+    return "decoder.conv_norm_out.weight" in sd and any(k.startswith("decoder.up_blocks.") for k in sd)
+
+
+def hf_autoencoder_kl_to_decoder(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    nlev = len(cfg.ch_mult)
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        p = k.split(".")
+        suffix = p[-1]
+        if p[0] == "post_quant_conv":
+            out[k] = v
+            continue
+        if p[0] != "decoder":
+            continue                                    # encoder.*, quant_conv.*: vae.encode is not on the path
+        p = p[1:]
+        if p[0] in ("conv_in", "conv_out"):
+            out[".".join(p)] = v
+        elif p[0] == "conv_norm_out":
+            out[f"norm_out.{suffix}"] = v
+        elif p[0] == "up_blocks":
+            lvl = nlev - 1 - int(p[1])                  # diffusers counts up blocks from the coarsest
+            if p[2] == "resnets":
+                out[f"up.{lvl}.block.{p[3]}.{_RES[p[4]]}.{suffix}"] = v
+            elif p[2] == "upsamplers":
+                out[f"up.{lvl}.upsample.conv.{suffix}"] = v
+            else:
+                raise KeyError(k)
+        elif p[0] == "mid_block":
+            if p[1] == "resnets":
+                out[f"mid.block_{int(p[2]) + 1}.{_RES[p[3]]}.{suffix}"] = v
+            elif p[1] == "attentions":
+                name = _ATTN[".".join(p[3:-1])]
+                if name != "norm" and suffix == "weight" and v.dim() == 2:
+                    v = v[:, :, None, None]             # nn.Linear [C,C] -> 1x1 conv
+                out[f"mid.attn_1.{name}.{suffix}"] = v
+            else:
+                raise KeyError(k)
+        else:
+            raise KeyError(f"unexpected key {k}")
+    want = param_shapes(cfg)
+    missing = [n for n in want if n not in out]
+    if missing:
+        raise KeyError(f"{len(missing)} decoder parameters missing after conversion, first: {missing[0]}")
+    for n, shp in want.items():
+        if tuple(out[n].shape) != tuple(shp):
+            raise ValueError(f"shape mismatch for {n}: {tuple(out[n].shape)} vs {tuple(shp)}")
+    return {n: out[n] for n in want}
+
+
+def decoder_to_hf_autoencoder_kl(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """Inverse map (round-trip test; export for a diffusers user), attention projections as nn.Linear."""
+    nlev = len(cfg.ch_mult)
+    inv_res = {v: k for k, v in _RES.items()}
+    inv_attn = {"norm": "group_norm", "q": "to_q", "k": "to_k", "v": "to_v", "proj_out": "to_out.0"}
+    out = {}
+    for k, v in sd.items():
+        p = k.split(".")
+        suffix = p[-1]
+        if p[0] == "post_quant_conv":
+            out[k] = v
+        elif p[0] in ("conv_in", "conv_out"):
+            out["decoder." + k] = v
+        elif p[0] == "norm_out":
+            out[f"decoder.conv_norm_out.{suffix}"] = v
+        elif p[0] == "up":
+            idx = nlev - 1 - int(p[1])
+            if p[2] == "block":
+                out[f"decoder.up_blocks.{idx}.resnets.{p[3]}.{inv_res[p[4]]}.{suffix}"] = v
+            elif p[2] == "upsample":
+                out[f"decoder.up_blocks.{idx}.upsamplers.0.conv.{suffix}"] = v
+        elif p[0] == "mid":
+            if p[1].startswith("block_"):
+                out[f"decoder.mid_block.resnets.{int(p[1][-1]) - 1}.{inv_res[p[2]]}.{suffix}"] = v
+            else:
+                if p[2] != "norm" and suffix == "weight":
+                    v = v.reshape(v.shape[0], v.shape[1])
+                out[f"decoder.mid_block.attentions.0.{inv_attn[p[2]]}.{suffix}"] = v
+    return out

@@ -245,7 +245,7 @@ def dec_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     """state_dict layout of the latent-diffusion ``Decoder`` (the module tree of the DDPM U-Net's up half without skip
     inputs and without ``temb_proj``): ``conv_in``, ``mid.{block_1,attn_1,block_2}``,
     ``up.L.block.B.{norm1,conv1,norm2,conv2,nin_shortcut}``, ``up.L.attn.B``, ``up.L.upsample.conv``, ``norm_out``,
-    ``conv_out``."""
+    ``conv_out``, preceded by the autoencoder's ``post_quant_conv`` (1x1 on the latent channels)."""
     shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
 
     def conv(name, cin, cout, k):
@@ -269,6 +269,7 @@ def dec_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     nlev = len(mult)
     block_in = ch * mult[-1]
     res = cfg.resolution
+    conv("post_quant_conv", cfg.in_channels, cfg.in_channels, 1)      # AutoencoderKL.decode = decoder(post_quant_conv(z))
     conv("conv_in", cfg.in_channels, block_in, 3)
     resblock("mid.block_1", block_in, block_in); attn("mid.attn_1", block_in); resblock("mid.block_2", block_in, block_in)
     for lvl in reversed(range(nlev)):

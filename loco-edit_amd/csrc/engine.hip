@@ -54,7 +54,7 @@ struct NormP {
     long sx_off = -1;   // offset (in float2) into the primal {S, xhat} cache, -1: none
 };
 
-enum OpKind { OP_CONV_IN, OP_RES, OP_ATTN, OP_DOWN, OP_UP, OP_OUT };
+enum OpKind { OP_CONV_IN, OP_RES, OP_ATTN, OP_DOWN, OP_UP, OP_OUT, OP_CONV };   // OP_CONV: plain 3x3 conv, tensor -> tensor
 
 struct Op {
     OpKind kind;
@@ -67,6 +67,7 @@ struct Op {
     int updown = 0;               // RES: 0 none, 1 down (avg-pool 2x2 on both branches), 2 up (nearest x2)
     bool scale_shift = false;     // RES: GN(h)*(1+scale)+shift from the embedding (ADM); else conv1 += Linear(temb) (DDPM)
     int heads = 1;                // ATTN
+    int ksize = 3;                // CONV_IN: 3 (conv_in of the denoisers) or 1 (post_quant_conv of the latent decoder)
     // ATTN with a text cross-attention stage behind it (cfg.context_dim > 0): xmid = output of the self-attention
     // stage, xhn = GN(xmid), xq = q projection [C][T], xS = scores / probabilities [heads][T][Lp], xo = attended values
     bool has_x = false;
@@ -590,10 +591,13 @@ int build_program_dec(loco_ctx* c) {
     };
     int res = R, block_in = ch * cfg.ch_mult[nlev - 1];
     int cur;
-    {
-        Op o; o.kind = OP_CONV_IN; o.name = "conv_in"; o.in = -1; o.out = new_tensor(c, block_in, res, res);
+    {   // AutoencoderKL.decode = decoder(post_quant_conv(z)): the 1x1 conv on the latent channels comes first
+        Op o; o.kind = OP_CONV_IN; o.name = "post_quant_conv"; o.in = -1; o.ksize = 1;
+        o.out = new_tensor(c, cfg.in_channels, res, res);
         c->ops.push_back(o);
-        cur = o.out;
+        Op ci; ci.kind = OP_CONV; ci.name = "conv_in"; ci.in = o.out; ci.out = new_tensor(c, block_in, res, res);
+        c->ops.push_back(ci);
+        cur = ci.out;
     }
     cur = add_res("mid.block_1", cur, block_in);
     cur = add_attn("mid.attn_1", cur);
@@ -670,7 +674,8 @@ void declare_all(loco_ctx* c) {
     }
     for (auto& op : c->ops) {
         switch (op.kind) {
-            case OP_CONV_IN: declare_conv(c, op.pn_conv, cfg.in_channels, c->tens[op.out].C, 3); break;
+            case OP_CONV_IN: declare_conv(c, op.pn_conv, cfg.in_channels, c->tens[op.out].C, op.ksize); break;
+            case OP_CONV: declare_conv(c, op.pn_conv, c->tens[op.in].C, c->tens[op.out].C, 3); break;
             case OP_RES: {
                 int cin = c->tens[op.in].C, cout = c->tens[op.out].C;
                 declare_norm(c, op.pn_n1, cin);
@@ -856,7 +861,7 @@ int finalize_params(loco_ctx* c) {
     std::vector<float> tpw, tpb;
     for (auto& op : c->ops) {
         switch (op.kind) {
-            case OP_CONV_IN: if (make_conv1(c, op.pn_conv, &op.conv)) return -1; break;
+            case OP_CONV_IN: case OP_CONV: if (make_conv1(c, op.pn_conv, &op.conv)) return -1; break;
             case OP_RES: {
                 if (make_norm(c, op.pn_n1, &op.n1) || make_norm(c, op.pn_n2, &op.n2)) return -1;
                 if (make_conv1(c, op.pn_c1, &op.c1) || make_conv1(c, op.pn_c2, &op.c2)) return -1;
@@ -905,7 +910,7 @@ int finalize_params(loco_ctx* c) {
         auto convf = [&](const ConvP& p, int H, int W) { fl += 2.0 * p.cin * p.cout * p.taps * (double)H * W; };
         const Tens& to = c->tens[op.out];
         switch (op.kind) {
-            case OP_CONV_IN: case OP_DOWN: case OP_UP: case OP_OUT: convf(op.conv, to.H, to.W); break;
+            case OP_CONV_IN: case OP_CONV: case OP_DOWN: case OP_UP: case OP_OUT: convf(op.conv, to.H, to.W); break;
             case OP_RES:
                 convf(op.c1, to.H, to.W); convf(op.c2, to.H, to.W);
                 if (op.has_nin) convf(op.nin, to.H, to.W);
@@ -1111,6 +1116,16 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 a.in = x; a.in_bs = c->n_in; a.Cin = cfg.in_channels; a.Hin = cfg.resolution; a.Win = cfg.resolution;
                 setw(a, op.conv, false); a.bias = op.conv.bias;
                 a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                if (op.ksize == 1) a.pad = 0;
+                run_conv(c, a, op.ksize == 1 ? 1 : 9, st);
+                break;
+            }
+            case OP_CONV: {
+                const Tens& ti = c->tens[op.in];
+                ConvArgs a; conv_defaults(a);
+                a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
+                setw(a, op.conv, false); a.bias = op.conv.bias;
+                a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
                 break;
             }
@@ -1276,6 +1291,16 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
             case OP_CONV_IN: {
                 ConvArgs a; conv_defaults(a);
                 a.in = V; a.in_bs = c->n_in; a.Cin = cfg.in_channels; a.Hin = cfg.resolution; a.Win = cfg.resolution;
+                setw(a, op.conv, false);
+                a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                if (op.ksize == 1) a.pad = 0;
+                run_conv(c, a, op.ksize == 1 ? 1 : 9, st);
+                break;
+            }
+            case OP_CONV: {
+                const Tens& ti = c->tens[op.in];
+                ConvArgs a; conv_defaults(a);
+                a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false);
                 a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 run_conv(c, a, 9, st);
@@ -1591,6 +1616,16 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 setw(a, op.conv, true); a.res = gx0; a.res_bs = c->n_in;
                 a.out = Aout; a.out_bs = c->n_in; a.Cout = cfg.in_channels; a.Hout = cfg.resolution;
                 a.Wout = cfg.resolution; a.B = B;
+                if (op.ksize == 1) a.pad = 0;
+                run_conv(c, a, op.ksize == 1 ? 1 : 9, st);
+                break;
+            }
+            case OP_CONV: {
+                const Tens& ti = c->tens[op.in];
+                ConvArgs a; conv_defaults(a);
+                a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
+                setw(a, op.conv, true);
+                a.out = TG(op.in); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
                 run_conv(c, a, 9, st);
                 break;
             }

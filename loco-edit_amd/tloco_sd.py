@@ -21,9 +21,13 @@ all shipped Stable Diffusion scripts do), so ``vae.encode`` / ``run_DDIMinversio
 
 NOT built (stated, not hidden): the networks themselves are diffusers' ``UNet2DConditionModel`` (CLIP cross-attention)
 and ``AutoencoderKL`` (un-vendored, hub weights).  The denoiser here is the guided-diffusion U-Net of the engine on 4
-latent channels with the text entering through the time embedding (``config.SD64_STANDIN``); the decoder is the
-latent-diffusion ``Decoder`` module tree (``config.SD_VAE_DECODER``: the published geometry of the SD autoencoder's
-decoder, 49.5 M parameters) -- a real decoder state_dict in LDM naming loads unchanged, the denoiser stays a stand-in.
+latent channels with a text cross-attention stage behind every attention block (``config.SD64_XATTN_STANDIN``: the
+prompt's 77 x 768 encoder states go to ``loco_set_context``, one context per CFG branch; ``SD64_STANDIN`` feeds the pooled
+prompt through the time embedding instead); the decoder is the
+latent-diffusion ``Decoder`` module tree behind the autoencoder's ``post_quant_conv`` (``config.SD_VAE_DECODER``: the
+published geometry of the SD autoencoder's decoder, 49.5 M parameters) -- a decoder state_dict in LDM naming loads
+unchanged and a diffusers ``AutoencoderKL`` state_dict through ``checkpoints.hf_autoencoder_kl_to_decoder`` (key map
+written from the published layout, unpinned); the denoiser stays a stand-in.
 Architecture parity is therefore unpinned; the orchestration is pinned against the reference's own methods run on the
 same stand-ins (oracle/make_golden_tloco_sd.py).  SAM masks are an input (``mask/mask.pt``).
 """
@@ -103,6 +107,9 @@ class EditStableDiffusion(EditDeepFloydIF):
             if getattr(args, "vae_ckpt_path", ""):
                 vparams = torch.load(args.vae_ckpt_path, map_location="cpu")
                 vparams = vparams.get("state_dict", vparams)
+                from .checkpoints import hf_autoencoder_kl_to_decoder, is_hf_autoencoder_kl
+                if is_hf_autoencoder_kl(vparams):          # diffusers AutoencoderKL file: keep post_quant_conv + decoder.*
+                    vparams = hf_autoencoder_kl_to_decoder(vparams, vcfg)
             else:
                 seed = getattr(args, "synthetic_weights", None)
                 if seed is None:

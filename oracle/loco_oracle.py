@@ -148,7 +148,8 @@ def decoder_forward(p: Dict[str, torch.Tensor], cfg, z: torch.Tensor, trace: Opt
         return v
     nlev = len(cfg.ch_mult)
     res = cfg.resolution
-    h = rec("conv_in", F.conv2d(z, p["conv_in.weight"], p["conv_in.bias"], padding=1))
+    h = rec("post_quant_conv", F.conv2d(z, p["post_quant_conv.weight"], p["post_quant_conv.bias"]))   # AutoencoderKL.decode
+    h = rec("conv_in", F.conv2d(h, p["conv_in.weight"], p["conv_in.bias"], padding=1))
     h = rec("mid.block_1", _resblock_noemb(p, "mid.block_1", h, cfg))
     h = rec("mid.attn_1", _attn(p, "mid.attn_1", h, cfg))
     h = rec("mid.block_2", _resblock_noemb(p, "mid.block_2", h, cfg))

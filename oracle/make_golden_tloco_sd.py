@@ -51,6 +51,7 @@ class RefDecoder(torch.nn.Module):
         ch, mult = cfg.ch, tuple(cfg.ch_mult)
         self.cfg = cfg
         block_in = ch * mult[-1]
+        self.post_quant_conv = nn.Conv2d(cfg.in_channels, cfg.in_channels, 1)     # AutoencoderKL.decode applies it first
         self.conv_in = nn.Conv2d(cfg.in_channels, block_in, 3, 1, 1)
         self.mid = nn.Module()
         rb = lambda i, o: ResnetBlock(in_channels=i, out_channels=o, dropout=0.0, temb_channels=8)
@@ -84,7 +85,7 @@ class RefDecoder(torch.nn.Module):
     def decode(self, z):
         from models.ddpm.diffusion import nonlinearity
         temb = torch.zeros(z.shape[0], 8)
-        h = self.conv_in(z)
+        h = self.conv_in(self.post_quant_conv(z))
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h, temb)), temb)
         for lvl in reversed(range(len(self.up))):
             up = self.up[lvl]

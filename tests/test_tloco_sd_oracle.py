@@ -32,7 +32,7 @@ def test_sd_scheduler_tables_and_shapes(setup):
     assert g["edit_t_idx"] == int((s.timesteps - 700.0).abs().argmin()) == ot.edit_t_idx
     # the decoder preset has the published size of the Stable Diffusion autoencoder's decoder
     n_dec = sum(int(torch.tensor(sh).prod()) for sh in param_shapes(SD_VAE_DECODER).values())
-    assert n_dec == 49_490_179 and SD_VAE_DECODER.n == 4 * 64 * 64 and SD_VAE_DECODER.n_out == 3 * 512 * 512
+    assert n_dec == 49_490_179 + 20 and SD_VAE_DECODER.n == 4 * 64 * 64 and SD_VAE_DECODER.n_out == 3 * 512 * 512
     assert SD64_STANDIN.n == SD64_STANDIN.n_out == 4 * 64 * 64 and TINY_DECODER.out_resolution == 64
     assert "mid.block_1.temb_proj.weight" not in param_shapes(TINY_DECODER) and "temb.dense.0.weight" not in param_shapes(TINY_DECODER)
 
@@ -75,3 +75,22 @@ def test_preset_routes_stable_diffusion_to_the_latent_path(tmp_path, monkeypatch
     b = define_argparser.parse_args(["--model_name", "SimianLuo/LCM_Dreamshaper_v7", "--seed", "3", "--device", "cpu"])
     with pytest.raises(NotImplementedError):
         define_argparser.preset(b)
+
+
+def test_autoencoder_kl_key_map_round_trip():
+    """diffusers AutoencoderKL naming <-> the decoder engine's naming: every decoder parameter survives the round trip,
+    encoder / quant_conv entries are ignored, Linear attention projections become 1x1 convs."""
+    from loco_edit_amd.checkpoints import decoder_to_hf_autoencoder_kl, hf_autoencoder_kl_to_decoder, is_hf_autoencoder_kl
+    sd = {k: torch.from_numpy(v) for k, v in synth_params(TINY_DECODER, 3).items()}
+    hf = decoder_to_hf_autoencoder_kl(sd, TINY_DECODER)
+    assert is_hf_autoencoder_kl(hf) and not is_hf_autoencoder_kl(sd)
+    assert "decoder.up_blocks.0.resnets.0.conv1.weight" in hf and "decoder.mid_block.attentions.0.to_q.weight" in hf
+    assert hf["decoder.mid_block.attentions.0.to_q.weight"].dim() == 2 and "post_quant_conv.weight" in hf
+    # the coarsest level is up_blocks.0 in diffusers, up.<levels-1> here
+    assert torch.equal(hf["decoder.up_blocks.0.resnets.0.conv1.weight"], sd[f"up.{len(TINY_DECODER.ch_mult) - 1}.block.0.conv1.weight"])
+    hf["encoder.conv_in.weight"] = torch.zeros(1); hf["quant_conv.weight"] = torch.zeros(1)
+    back = hf_autoencoder_kl_to_decoder(hf, TINY_DECODER)
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    del hf["decoder.conv_out.bias"]
+    with pytest.raises(KeyError):
+        hf_autoencoder_kl_to_decoder(hf, TINY_DECODER)
