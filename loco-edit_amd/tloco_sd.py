@@ -228,6 +228,15 @@ class EditStableDiffusion(EditDeepFloydIF):
 
     DDPMforwardsteps = None
 
+    @torch.no_grad()
+    def run_DDIMforward(self, num_samples=5):
+        """edit.py:557-566: sample `num_samples` latents from z_T ~ N(0, I) and decode them."""
+        print('start DDIMforward')
+        self.EXP_NAME = f'DDIMforward-for_{self.for_prompt}'
+        zT = torch.randn(num_samples, self.c_in, self.image_size, self.image_size).to(device=self.device, dtype=self.dtype)
+        return self.DDIMforwardsteps(zT, t_start_idx=0, t_end_idx=-1, for_prompt_emb=self.for_prompt_emb,
+                                     edit_prompt_emb=self.edit_prompt_emb, null_prompt_emb=self.null_prompt_emb)
+
     # ------------------------------------------------------------------ drivers
     def _zT(self):
         if self.dataset_name != 'Random':

@@ -177,6 +177,8 @@ def test_latent_sampler_and_decode_vs_reference_golden(prec, golden, tmp_path):
     lat, img = ed.DDIMforwardsteps(g["dec_lat_in"].to(DEV), ed.edit_t_idx, -1, F, E, N, mode="null+(for-null)")
     assert img.dtype == torch.uint8 and tuple(img.shape) == tuple(g["dec_u8"].shape) == (2, 64, 64, 3)
     assert tuple(lat.shape) == (2, 4, 16, 16)
+    lat5, img5 = ed.run_DDIMforward(num_samples=3)                                  # edit.py:557-566
+    assert tuple(img5.shape) == (3, 64, 64, 3) and os.path.exists(os.path.join(ed.result_folder, "DDIMforward-for_a man.png"))
     differ = (img.cpu().int() - g["dec_u8"].int()).abs()
     assert float((differ > 1).float().mean()) < (0.002 if prec == "f32" else 0.05)
     assert os.path.exists(os.path.join(ed.result_folder, "dec.png"))

@@ -346,3 +346,24 @@ def test_mask_pt_consumer_and_sampling_mode(tmp_path):
     assert e._get_xT_and_mask(4, False)[1] is None
     e.args.sampling_mode = True
     assert e._get_xT_and_mask(4, True) == (None, None)
+
+
+def test_integration_md_binding_stub_matches_the_header():
+    """INTEGRATION.md shows the ctypes `Cfg` a reference maintainer would paste; it must stay field for field the
+    `loco_unet_cfg` of include/loco_hip.h (= hip.LocoCfg, which test_abi_symbols_exported pins to the header): a stale
+    stub would make loco_create read past the caller's struct (it refuses by struct_size, but the doc must be right)."""
+    import ctypes as C
+    import re
+    from loco_edit_amd.hip import LocoCfg
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class Cfg\(C\.Structure\):.*?\n(?=lib\.)", md, re.S)
+    assert m, "Cfg stub not found in INTEGRATION.md"
+    ns = {"C": C}
+    exec(m.group(0), ns)
+    stub = ns["Cfg"]
+    assert [f[0] for f in stub._fields_] == [f[0] for f in LocoCfg._fields_]
+    assert C.sizeof(stub) == C.sizeof(LocoCfg)
+    hdr = open(os.path.join(ROOT, "include", "loco_hip.h")).read()
+    body = hdr[hdr.index("typedef struct loco_unet_cfg {"):hdr.index("} loco_unet_cfg;")]
+    names = re.findall(r"^\s*(?:int32_t|float)\s+(\w+)", body, re.M)
+    assert names == [f[0] for f in LocoCfg._fields_]
