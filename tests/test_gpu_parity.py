@@ -747,3 +747,46 @@ def test_config2_null_space_solve_and_projection_at_size(prec, engines, golden):
     for i in range(40, 44):
         x = eng.ddim_step(x, float(ts[i]), float(s_.alpha_at(ts[i])), float(s_.alpha_at(tn[i])))
     assert torch.isfinite(x).all() and (x[0] - x[4]).abs().max().item() > 1e-3
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a C ABI, not a Python extension: tests/c/loco_abi_smoke.c (C11, no torch, no C++) is compiled
+    against include/loco_hip.h + libloco_hip.so, creates a context, loads the parameters from host memory, and runs
+    `loco_unet_forward` and `loco_pmp_primal` / `loco_pmp_jvp` on buffers it allocated with hipMalloc; its outputs are
+    bit-identical to the same calls made through the ctypes binding."""
+    import struct
+    import subprocess
+    import numpy as np
+    from loco_edit_amd.hip import LocoEngine, library_path
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "loco_abi_smoke")
+    libdir = os.path.dirname(library_path())
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(root, "tests", "c", "loco_abi_smoke.c"), "-L", libdir, "-lloco_hip", "-L", "/opt/rocm/lib",
+                           "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    cfg = TINY_DDPM
+    params = synth_params(cfg, 0)
+    with open(tmp_path / "params.bin", "wb") as f:
+        for name, a in params.items():
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            f.write(struct.pack("<i", len(name))); f.write(name.encode())
+            f.write(struct.pack("<i", a.ndim)); f.write(struct.pack(f"<{a.ndim}q", *a.shape)); f.write(a.tobytes())
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 3, 32, 32, generator=g)
+    V = torch.randn(2, cfg.n, generator=g)
+    with open(tmp_path / "x.bin", "wb") as f:
+        f.write(x.numpy().tobytes()); f.write(V.numpy().tobytes())
+    env = dict(os.environ, LOCO_PRECISION="bf16x3")
+    out = subprocess.run([exe, str(tmp_path / "params.bin"), str(tmp_path / "x.bin"), "412.25", str(tmp_path / "eps.bin"),
+                          str(tmp_path / "jv.bin")], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "loco_hip" in out.stdout and "parameters %d" % len(params) in out.stdout
+    eps_c = torch.from_numpy(np.fromfile(tmp_path / "eps.bin", dtype=np.float32)).view(1, 3, 32, 32)
+    jv_c = torch.from_numpy(np.fromfile(tmp_path / "jv.bin", dtype=np.float32)).view(2, cfg.n)
+    eng = LocoEngine(cfg, max_batch=4, device=torch.device(DEV))
+    eng.load_state_dict(params)
+    eng.set_precision("bf16x3")
+    assert torch.equal(eng.unet_forward(x.to(DEV), 412.25).cpu(), eps_c)
+    eng.pmp_primal(x.to(DEV), 412.25, 0.5, None)
+    assert torch.equal(eng.pmp_jvp(V.to(DEV)).cpu(), jv_c)
+    assert rel(eps_c, orc.unet_forward(orc.to_torch(params), cfg, x, torch.tensor(412.25))) < 2e-4
