@@ -790,3 +790,32 @@ def test_c_abi_from_plain_c(tmp_path):
     eng.pmp_primal(x.to(DEV), 412.25, 0.5, None)
     assert torch.equal(eng.pmp_jvp(V.to(DEV)).cpu(), jv_c)
     assert rel(eps_c, orc.unet_forward(orc.to_torch(params), cfg, x, torch.tensor(412.25))) < 2e-4
+
+
+def test_cli_shipped_celeba_script_at_size(tmp_path, monkeypatch):
+    """`python -m loco_edit_amd.main` with the argument list of scripts/main_celeba_hf_null_space_projection.sh
+    (tests/golden/script_args.json) at its real size -- CelebA-HQ DDPM architecture 256x256, 100/100 steps, pca_rank 1,
+    pca_rank_null 5, convergence-checked solves -- with the dataset and checkpoint replaced by the synthetic ones (no
+    CelebAMask-HQ files, no hub weights here): files in the reference's layout, unit-norm projected direction
+    orthogonal to the null basis, 5 decoded frames."""
+    import json
+    from loco_edit_amd.main import main
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = json.load(open(os.path.join(root, "tests", "golden", "script_args.json")))["main_celeba_hf_null_space_projection.sh"]
+    argv = list(argv)
+    for flag, val in (("--dataset_name", "Synthetic"), ("--dataset_root", ""), ("--seed", "5")):
+        argv[argv.index(flag) + 1] = val
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("LOCO_PRECISION", "bf16x3")
+    xt = main(argv + ["--device", DEV, "--synthetic_weights", "0"])
+    assert tuple(xt.shape) == (5, 3, 256, 256) and torch.isfinite(xt).all()
+    rdir = tmp_path / "runs" / "CelebA_HQ_HF-Synthetic" / "results" / "sample_idx7"
+    bdir = rdir / "basis" / "local_basis-0.6T-select-mask-l_eye"
+    v = torch.load(str(bdir / "7-Edit_xt-noise-False_l_eye-edit_0.6T_null_proj_True_rank5_scale_0.5-pc_000-vT.pt"))
+    vn = torch.load(str(bdir / "vT-null-5.pt"))
+    assert tuple(v.shape) == (1, CELEBA_DDPM.n) and tuple(vn.shape) == (5, CELEBA_DDPM.n)
+    assert abs(float(v.double().norm()) - 1.0) < 1e-5 and (vn.double() @ v.double().T).abs().max().item() < 1e-5
+    for f in ("original.png", "xT-DDIMinversion-Synthetic_7.png",
+              "7-Edit-randomFalse_xt-noise-False_l_eye-edit_0.6T_null_proj_True_rank5_scale_0.5-pc_000.png"):
+        assert (rdir / f).exists(), f
