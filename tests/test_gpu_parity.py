@@ -819,3 +819,43 @@ def test_cli_shipped_celeba_script_at_size(tmp_path, monkeypatch):
     for f in ("original.png", "xT-DDIMinversion-Synthetic_7.png",
               "7-Edit-randomFalse_xt-noise-False_l_eye-edit_0.6T_null_proj_True_rank5_scale_0.5-pc_000.png"):
         assert (rdir / f).exists(), f
+
+
+def test_cli_shipped_p2_script_at_size(tmp_path, monkeypatch):
+    """The argument list of scripts/main_hf_null_space_projection_FFHQ_P2.sh at its real size (FFHQ-P2 architecture
+    256x256, edit at t = 0.2T, pca_rank 3 / pca_rank_null 5, one guidance step of scale 12) on an image folder and a
+    cached SAM-format mask.pt: first as shipped (`--sampling_mode True`: the mask-generation pass ends before any
+    solve), then with `--sampling_mode False`."""
+    import json
+    from loco_edit_amd.main import main
+    from loco_edit_amd.utils import save_image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = list(json.load(open(os.path.join(root, "tests", "golden", "script_args.json")))["main_hf_null_space_projection_FFHQ_P2.sh"])
+    data = tmp_path / "ffhq"
+    os.makedirs(data)
+    g = torch.Generator().manual_seed(11)
+    for i in range(8):      # sample_idx 7 = the 8th file by integer stem
+        save_image(torch.rand(1, 3, 64, 64, generator=g), str(data / f"{i:05d}.png"), padding=0)
+    for flag, val in (("--dataset_root", str(data)), ("--seed", "5")):
+        argv[argv.index(flag) + 1] = val
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("LOCO_PRECISION", "bf16x3")
+    rdir = tmp_path / "runs" / "FFHQ_P2-FFHQ" / "results" / "sample_idx7"
+    os.makedirs(rdir / "mask")
+    masks = torch.zeros(2, 1, 256, 256, dtype=torch.bool)
+    masks[0, 0, 110:130, 70:110] = True
+    torch.save(masks, str(rdir / "mask" / "mask.pt"))
+    extra = ["--device", DEV, "--synthetic_weights", "0"]
+    assert main(argv + extra) is None                                   # as shipped: sampling mode
+    assert not (rdir / "basis").exists()
+    argv[argv.index("--sampling_mode") + 1] = "False"
+    xt = main(argv + extra)
+    assert tuple(xt.shape) == (3, 3, 256, 256) and torch.isfinite(xt).all()      # one guidance step, vis_num 2: -1, 0, +1
+    bdir = rdir / "basis" / "local_basis-0.2T-select-mask-0"
+    vm, vn = torch.load(str(bdir / "vT-modify-pca-rank-3.pt")), torch.load(str(bdir / "vT-null-5.pt"))
+    assert tuple(vm.shape) == (3, FFHQ_P2.n) and tuple(vn.shape) == (5, FFHQ_P2.n)
+    pcs = sorted(f for f in os.listdir(bdir) if f.endswith("-vT.pt"))
+    assert len(pcs) == 3
+    v = torch.load(str(bdir / pcs[0]))
+    assert abs(float(v.double().norm()) - 1.0) < 1e-5 and (vn.double().to(v.device) @ v.double().T).abs().max().item() < 1e-5
