@@ -360,7 +360,11 @@ def main():
         else:
             cfg, k, keep = FFHQ_P2, 64, 20
         params = synth_params(cfg, seed=0)
-        eng = LocoEngine(cfg, max_batch=8, device=device)
+        # probe batch resident per pass: 8 for the top-5 workload; the 64-probe workload fills the deep levels better
+        # with its whole shard in one pass (measured 2.87 / 2.67 / 2.62 s per solve at 8 / 16 / 32; 0.8 GB of arena per probe)
+        k_rank = (k + world - 1) // world
+        mb = int(os.environ.get("LOCO_BENCH_MAX_BATCH", "0")) or (8 if name == "celeba_top5" else min(32, max(8, k_rank)))
+        eng = LocoEngine(cfg, max_batch=mb, device=device)
         eng.load_state_dict(params)
         eng.set_precision(prec)
         x, mask, v0 = synthetic_inputs(cfg, k, device)
