@@ -95,6 +95,12 @@ SD64_XATTN_STANDIN = UNetConfig(resolution=64, in_channels=4, out_ch=4, ch=320, 
 TINY_LATENT_XATTN = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=32, ch_mult=(1, 2), num_res_blocks=1,
                                attn_resolutions=(16, 8), gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=False,
                                context_dim=16, context_len=7)
+# IF-I reads its T5 states (77 x 4096) through attention as well: the same shape class with cross-attention stages
+IF64_XATTN_STANDIN = UNetConfig(resolution=64, ch=192, ch_mult=(1, 2, 3, 4), num_res_blocks=3, attn_resolutions=(32, 16, 8),
+                                gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=True, context_dim=4096,
+                                context_len=77)
+TINY_ADM_XATTN = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,),
+                            gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True, context_dim=16, context_len=7)
 TINY_ADM = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,),
                       gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True)
 

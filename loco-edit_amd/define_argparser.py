@@ -76,7 +76,8 @@ _FLAGS = [
 ]
 _UNET_PRESETS = {'celeba_ddpm': 'CELEBA_DDPM', 'ffhq_p2': 'FFHQ_P2', 'tiny_ddpm': 'TINY_DDPM', 'mid_ddpm': 'MID_DDPM',
                  'tiny_adm': 'TINY_ADM', 'if64_standin': 'IF64_STANDIN', 'sd64_standin': 'SD64_STANDIN',
-                 'sd64_xattn_standin': 'SD64_XATTN_STANDIN', 'tiny_latent': 'TINY_LATENT', 'tiny_latent_xattn': 'TINY_LATENT_XATTN'}
+                 'sd64_xattn_standin': 'SD64_XATTN_STANDIN', 'tiny_latent': 'TINY_LATENT', 'tiny_latent_xattn': 'TINY_LATENT_XATTN',
+                 'if64_xattn_standin': 'IF64_XATTN_STANDIN', 'tiny_adm_xattn': 'TINY_ADM_XATTN'}
 _VAE_PRESETS = {'sd_vae_decoder': 'SD_VAE_DECODER', 'tiny_decoder': 'TINY_DECODER'}
 _TILDA_V = ["proj_null[for-null](edit-null)-direct", "(for-edit)-direct", "(edit-null)-direct",
             "null+(for-null)+(edit-null)", "null+(for-null)", "null+(edit-null)", "(for-edit)",

@@ -193,3 +193,40 @@ def test_cli_shipped_if_script_on_the_standin(tmp_path, monkeypatch):
     v = torch.load(str(rdir / "basis" / pcs[0]))
     assert tuple(v.shape) == (1, TINY_ADM.n) and abs(float(v.norm()) - 1.0) < 1e-4
     assert any(f.endswith("_stage1.png") for f in os.listdir(rdir))
+
+
+def test_pixel_space_tloco_with_text_cross_attention_vs_restatement(tmp_path):
+    """The pixel-space class on a denoiser WITH text cross-attention stages (IF-I reads its T5 states through attention):
+    prompt tokens go to `loco_set_context`, one context per CFG branch.  CFG noise (learned-variance half split off),
+    x0_hat and a 3-iteration CFG-combined solve against the CPU restatement with `context=`."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import loco_oracle as orc
+    import tloco_oracle as tl
+    from loco_edit_amd.config import TINY_ADM_XATTN as cfg, synth_params
+    from loco_edit_amd.tloco import EditDeepFloydIF
+    os.environ.pop("WORLD_SIZE", None)
+    g = torch.Generator().manual_seed(31)
+    pe = {k: torch.randn(1, cfg.context_len, cfg.context_dim, generator=g) for k in ("for", "edit", "null")}
+    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=cfg, synthetic_weights=0, ckpt_path="",
+                     max_batch=8, precision="f32", dataset_name="Random", for_steps=100, use_yh_custom_scheduler=True,
+                     guidance_scale=7.5, guidance_scale_edit=4.0, prompt_emb=pe, for_prompt="a", edit_prompt="b", edit_t=0.6,
+                     sampling_mode=False, tilda_v_score_type="null+(for-null)+(edit-null)", ablation_method="null-space-proj",
+                     mask_type="SAM", vT_path="", x_space_guidance_edit_step=1.0, x_space_guidance_scale=0.5,
+                     x_space_guidance_num_step=16, result_folder=str(tmp_path))
+    ed = EditDeepFloydIF(args)
+    assert ed.use_context
+    ot = tl.OracleTLoco(orc.to_torch(synth_params(cfg, 0)), cfg, guidance_scale=7.5, guidance_scale_edit=4.0)
+    x = torch.randn(1, 3, 32, 32, generator=g)
+    t = ed.scheduler.timesteps[ed.edit_t_idx]
+    F, E, N = pe["for"], pe["edit"], pe["null"]
+    mask = torch.zeros(3, 32, 32, dtype=torch.bool); mask[:, 12:20, 8:18] = True
+    with torch.no_grad():
+        for mode in ("null+(for-null)+(edit-null)", "(for-edit)"):
+            assert rel(ed._classifer_free_guidance(x.to(DEV), t, F, E, N, mode, True), ot.cfg_noise(x, t, F, E, N, mode)) < 1e-4
+        assert rel(ed.get_x0(x.to(DEV), t, ed.edit_t_idx, F, E, N, mask=mask), ot.get_x0(x, t, F, E, N, mask=mask)) < 1e-4
+    v0 = torch.randn(cfg.n, 2, generator=g)
+    u, s, vT = ed.local_encoder_decoder_pullback_xt(x.to(DEV), t, ed.edit_t_idx, F, E, N, pca_rank=2, min_iter=3, max_iter=3,
+                                                    mask=mask, mode="null+(for-null)", v0=v0.to(DEV), verbose=False)
+    ou, os_, ovT = ot.pullback(x, t, F, E, N, 2, v0, min_iter=3, max_iter=3, mask=mask, mode="null+(for-null)")
+    assert torch.allclose(s.cpu(), os_, rtol=1e-3) and cosrow(vT, ovT).min().item() > 0.999
