@@ -367,3 +367,14 @@ def test_integration_md_binding_stub_matches_the_header():
     body = hdr[hdr.index("typedef struct loco_unet_cfg {"):hdr.index("} loco_unet_cfg;")]
     names = re.findall(r"^\s*(?:int32_t|float)\s+(\w+)", body, re.M)
     assert names == [f[0] for f in LocoCfg._fields_]
+
+
+def test_max_batch_follows_the_probe_counts():
+    """--max_batch 0 (default): the probe batch resident per pass is derived from pca_rank / pca_rank_null for the
+    unconditional models (8..32) and stays 8 for the text-to-image paths; an explicit value wins."""
+    pa = define_argparser.parse_args
+    assert pa(["--pca_rank", "50", "--pca_rank_null", "10"]).max_batch == 32        # the reference's defaults
+    assert pa(["--pca_rank", "1", "--pca_rank_null", "5"]).max_batch == 8           # the shipped CelebA script
+    assert pa(["--pca_rank", "12"]).max_batch == 12
+    assert pa(["--model_name", "runwayml/stable-diffusion-v1-5", "--pca_rank", "50"]).max_batch == 8
+    assert pa(["--max_batch", "4", "--pca_rank", "50"]).max_batch == 4
