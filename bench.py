@@ -210,6 +210,13 @@ def e2e_phases(eng, cfg, sched_cls, solver, device):
     sync(); t0 = time.perf_counter()
     _, _, vTm, _ = solver.local_basis(eng, xt, t, at, 5, mask=mask, min_iter=N_ITER, max_iter=N_ITER, v0=v0m, verbose=False)
     _, _, vTn, _ = solver.local_basis(eng, xt, t, at, 5, mask=~mask, min_iter=N_ITER, max_iter=N_ITER, v0=v0n, verbose=False)
+    sync(); out["two_solves_sequential_s"] = round(time.perf_counter() - t0, 4)
+    # what run_edit_null_space_projection does by default: both solves' probes in one batch per pass (one untimed call
+    # first: the 10-probe launch shapes have not run yet in this process, the 5-probe ones were warmed by the headline)
+    solver.local_basis_pair(eng, xt, t, at, 5, mask, 5, ~mask, min_iter=1, max_iter=1, v0_a=v0m, v0_b=v0n, verbose=False)
+    sync(); t0 = time.perf_counter()
+    (_, _, vTm, _), (_, _, vTn, _) = solver.local_basis_pair(eng, xt, t, at, 5, mask, 5, ~mask, min_iter=N_ITER, max_iter=N_ITER,
+                                                             v0_a=v0m, v0_b=v0n, verbose=False)
     sync(); out["two_solves_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     vT = eng.null_project(vTm, vTn)
@@ -360,10 +367,11 @@ def main():
         else:
             cfg, k, keep = FFHQ_P2, 64, 20
         params = synth_params(cfg, seed=0)
-        # probe batch resident per pass: 8 for the top-5 workload; the 64-probe workload fills the deep levels better
+        # probe batch resident per pass: the top-5 workload carries 5 (its e2e leg 5 + 5, the paired modify / null
+        # solves: room for 16); the 64-probe workload fills the deep levels better
         # with its whole shard in one pass (measured 2.87 / 2.67 / 2.62 s per solve at 8 / 16 / 32; 0.8 GB of arena per probe)
         k_rank = (k + world - 1) // world
-        mb = int(os.environ.get("LOCO_BENCH_MAX_BATCH", "0")) or (8 if name == "celeba_top5" else min(32, max(8, k_rank)))
+        mb = int(os.environ.get("LOCO_BENCH_MAX_BATCH", "0")) or (16 if name == "celeba_top5" else min(32, max(8, k_rank)))
         eng = LocoEngine(cfg, max_batch=mb, device=device)
         eng.load_state_dict(params)
         eng.set_precision(prec)

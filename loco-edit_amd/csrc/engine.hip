@@ -136,6 +136,9 @@ struct loco_ctx {
     float p_cv = 0.f, p_ce = 0.f;
     uint8_t* mask = nullptr;       // device, [n] (owned copy)
     bool has_mask = false;
+    uint8_t* mask2 = nullptr;      // device, [n] (owned copy): mask of the probe rows >= mask2_from (loco_pmp_set_second_mask)
+    bool has_mask2 = false;
+    int mask2_from = 0;
     int* mask_idx = nullptr;       // device: indices of the selected elements, ascending
     int* mask_L_dev = nullptr;     // device: their count
     long mask_L = 0;               // host copy, -1 = not read back yet
@@ -1747,6 +1750,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         const char* t = getenv("LOCO_BF16_TILE");
         if (t) g_bf16_tile_override = atoi(t);
     }
+    if (dalloc(c, &c->mask2, (size_t)c->n_out)) return -1;
     if (dalloc(c, &c->mask, (size_t)c->n_out) || dalloc(c, &c->mask_idx, (size_t)c->n_out) ||
         dalloc(c, &c->mask_L_dev, 4)) return -1;
     HIPCHK(c, hipEventCreate(&c->ev0));
@@ -1926,6 +1930,7 @@ int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_
     if (use_et) { c->p_cv = 0.f; c->p_ce = 1.f; }
     else { c->p_cv = 1.0f / std::sqrt(at); c->p_ce = -std::sqrt(1.0f - at) / std::sqrt(at); }
     c->has_mask = (mask != nullptr);
+    c->has_mask2 = false;
     c->mask_L = c->n_out;
     if (mask) {
         // masked-latent gather list built on the device (ordered prefix-sum compaction, one launch, no host sync);
@@ -1937,6 +1942,18 @@ int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_
     }
     HIPCHK(c, hipGetLastError());
     c->primal_ok = true;
+    return 0;
+}
+
+int loco_pmp_set_second_mask(loco_ctx* c, const uint8_t* mask2, int32_t from_row, void* stream) {
+    if (!c) return -2;
+    if (!c->primal_ok) { c->err = "loco_pmp_primal has not been called"; return -2; }
+    if (!mask2) { c->has_mask2 = false; return 0; }
+    if (!c->has_mask) { c->err = "a second mask needs a first one (loco_pmp_primal with mask)"; return -2; }
+    if (from_row < 0) { c->err = "from_row must be >= 0"; return -2; }
+    HIPCHK(c, hipMemcpyAsync(c->mask2, mask2, (size_t)c->n_out, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    c->has_mask2 = true;
+    c->mask2_from = from_row;
     return 0;
 }
 
@@ -1953,7 +1970,8 @@ int loco_pmp_jvp(loco_ctx* c, const float* V, int32_t k, float* U, void* stream)
             // U = mask * (cv*V + ce*dEps); dEps lives strided in arena T -> gather through eps_buf
             launch_copy(c->arenaT + c->tens[c->eps_t].off, c->per_sample, c->eps_buf, c->n_out, 0, nb, c->n_out, ls);
             launch_masked_axpby(c->n_out == c->n_in ? Vc : nullptr, c->eps_buf, c->has_mask ? c->mask : nullptr, c->p_cv,
-                                c->p_ce, U + (long)(b0 + s0) * c->n_out, nb, c->n_out, ls);
+                                c->p_ce, U + (long)(b0 + s0) * c->n_out, nb, c->n_out, ls,
+                                c->has_mask2 ? c->mask2 : nullptr, (long)c->mask2_from - (b0 + s0));
             return 0;
         });
         if (rc) return rc;
@@ -1972,7 +1990,8 @@ int loco_pmp_vjp(loco_ctx* c, const float* U, int32_t k, float* A, void* stream)
         int rc = run_lanes(c, B, st, [&](int s0, int nb, hipStream_t ls) -> int {
             const bool same = c->n_out == c->n_in;
             launch_cot_seed(U + (long)(b0 + s0) * c->n_out, c->has_mask ? c->mask : nullptr, c->p_cv, c->p_ce, c->ge,
-                            same ? c->gx0 : nullptr, nb, c->n_out, ls);
+                            same ? c->gx0 : nullptr, nb, c->n_out, ls, c->has_mask2 ? c->mask2 : nullptr,
+                            (long)c->mask2_from - (b0 + s0));
             return cotangent_pass(c, c->ge, same ? c->gx0 : nullptr, A + (long)(b0 + s0) * c->n_in, nb, ls);
         });
         if (rc) return rc;

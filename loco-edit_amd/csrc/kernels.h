@@ -149,12 +149,12 @@ void launch_copy(const float* in, long in_bs, float* out, long out_bs, int accum
 void launch_ddim_step(const float* x, const float* eps, const float* noise, float* out, float* x0_out, long count,
                       float c_x0_x, float c_x0_e, float c_next_x0, float c_next_e, float c_noise,
                       hipStream_t st);
-// U = mask * (cv*V + ce*dEps)
+// U = mask * (cv*V + ce*dEps); rows >= split use mask2 when it is given (two solves sharing a probe batch)
 void launch_masked_axpby(const float* V, const float* dE, const uint8_t* mask, float cv, float ce,
-                         float* U, int k, long n, hipStream_t st);
+                         float* U, int k, long n, hipStream_t st, const uint8_t* mask2 = nullptr, long split = 0);
 // G = mask*U (cotangent seed); outputs gE = ce*G  and keeps cv*G in gX0
 void launch_cot_seed(const float* U, const uint8_t* mask, float cv, float ce, float* gE, float* gX0,
-                     int k, long n, hipStream_t st);
+                     int k, long n, hipStream_t st, const uint8_t* mask2 = nullptr, long split = 0);
 void launch_add(const float* a, const float* b, float* out, long count, hipStream_t st);
 // out = sum_{i<n} coef[i] * src[i]   (n <= 4, 16-byte aligned tensors of `count` floats; CFG combination of Jacobian products)
 void launch_lincomb(const float* const* src, const float* coef, int n, float* out, long count, hipStream_t st);

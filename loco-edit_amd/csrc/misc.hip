@@ -580,36 +580,39 @@ void launch_ddim_step(const float* x, const float* eps, const float* noise, floa
 }
 
 __global__ void masked_axpby_kernel(const float* V, const float* dE, const uint8_t* mask, float cv, float ce,
-                                    float* U, long n, long total) {
+                                    float* U, long n, long total, const uint8_t* mask2, long split) {
+    // rows >= split use mask2 (two subspace solves with different masks sharing one probe batch)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long j = i % n;
-        float m = (!mask || mask[j]) ? 1.f : 0.f;
+        long row = i / n, j = i - row * n;
+        const uint8_t* mk = (mask2 && row >= split) ? mask2 : mask;
+        float m = (!mk || mk[j]) ? 1.f : 0.f;
         U[i] = m * ((V ? cv * V[i] : 0.f) + ce * dE[i]);      // V == nullptr: output and input sizes differ (raw network Jacobian)
     }
 }
 void launch_masked_axpby(const float* V, const float* dE, const uint8_t* mask, float cv, float ce, float* U, int k,
-                         long n, hipStream_t st) {
+                         long n, hipStream_t st, const uint8_t* mask2, long split) {
     long total = (long)k * n;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(masked_axpby_kernel, dim3(blocks), dim3(256), 0, st, V, dE, mask, cv, ce, U, n, total);
+    hipLaunchKernelGGL(masked_axpby_kernel, dim3(blocks), dim3(256), 0, st, V, dE, mask, cv, ce, U, n, total, mask2, split);
 }
 
 __global__ void cot_seed_kernel(const float* U, const uint8_t* mask, float cv, float ce, float* gE, float* gX0,
-                                long n, long total) {
+                                long n, long total, const uint8_t* mask2, long split) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long j = i % n;
-        float u = (!mask || mask[j]) ? U[i] : 0.f;
+        long row = i / n, j = i - row * n;
+        const uint8_t* mk = (mask2 && row >= split) ? mask2 : mask;
+        float u = (!mk || mk[j]) ? U[i] : 0.f;
         gE[i] = ce * u;
         if (gX0) gX0[i] = cv * u;
     }
 }
 void launch_cot_seed(const float* U, const uint8_t* mask, float cv, float ce, float* gE, float* gX0, int k, long n,
-                     hipStream_t st) {
+                     hipStream_t st, const uint8_t* mask2, long split) {
     long total = (long)k * n;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cot_seed_kernel, dim3(blocks), dim3(256), 0, st, U, mask, cv, ce, gE, gX0, n, total);
+    hipLaunchKernelGGL(cot_seed_kernel, dim3(blocks), dim3(256), 0, st, U, mask, cv, ce, gE, gX0, n, total, mask2, split);
 }
 
 __global__ void fill_random_kernel(float* p, long count, unsigned seed, float scale) {

@@ -96,7 +96,7 @@ def build_parser():
     p.add_argument('--synthetic_weights', type=int, default=None, help='seed of the deterministic weight synthesiser')
     p.add_argument('--max_batch', type=int, default=0,
                    help='largest image/probe batch resident on the GPU per pass; 0 = from the probe counts: '
-                        'clamp(max(pca_rank, pca_rank_null), 8, 32) for the unconditional models (about 1 GB of arena per '
+                        'clamp(pca_rank + pca_rank_null, 8, 32) for the unconditional models (about 1 GB of arena per '
                         'probe at 256x256; wider batches fill the deep levels: 64 probes run 9 %% faster at 32 than at 8), '
                         '8 for the text-to-image paths (several engine contexts)')
     p.add_argument('--unet_preset', type=str, default=None, choices=sorted(_UNET_PRESETS),
@@ -117,7 +117,8 @@ def parse_args(argv=None):
     args = build_parser().parse_args(argv)
     if args.max_batch <= 0:
         t2i = any(s in args.model_name for s in ('stable-diffusion', 'DeepFloyd', 'LCM'))
-        args.max_batch = 8 if t2i else min(32, max(8, args.pca_rank, args.pca_rank_null))
+        # the modify-space and null-space solves share their probe batches (solver.local_basis_pair): room for both
+        args.max_batch = 8 if t2i else min(32, max(8, args.pca_rank + args.pca_rank_null))
     if args.unet_preset:
         from . import config
         args.unet_config = getattr(config, _UNET_PRESETS[args.unet_preset])

@@ -73,6 +73,9 @@ class EditUncondDiffusion(object):
         self.vT_path = args.vT_path
         self.vT1_path = args.vT1_path
         self.sharder = ProbeSharder("world")
+        # the modify-space and null-space solves of one edit share their probe batches (solver.local_basis_pair);
+        # LOCO_PAIR_SOLVES=0 runs them one after the other as the reference does
+        self.pair_solves = os.environ.get("LOCO_PAIR_SOLVES", "1") != "0"
         self.EXP_NAME = "exp"
         self.args = args
 
@@ -284,7 +287,19 @@ class EditUncondDiffusion(object):
             vT_modify_path = os.path.join(save_dir, f'vT-modify-pca-rank-{pca_rank}.pt')
             vT_null_path = os.path.join(save_dir, f'vT-null-{pca_rank_null}.pt')
 
-            if self._exists(vT_modify_path):
+            vT_null = None
+            have_m, have_n = self._exists(vT_modify_path), self._exists(vT_null_path)
+            if null_space_projection and mask is not None and not have_m and not have_n and self.pair_solves:
+                # both bases are missing: one pass carries the probes of both solves (solver.local_basis_pair)
+                print('!!!RUN LOCAL PULLBACK FOR EDIR SPACE AND NULL SPACE (shared probe batches)!!!')
+                at = self.scheduler.alpha_at(t)
+                (u_modify, s_modify, vT_modify, self.last_n_iter), (u_null, s_null, vT_null, self.last_n_iter_null) = \
+                    solver.local_basis_pair(self.engine, xt.to(self.device, torch.float32), float(t), at, pca_rank, mask,
+                                            pca_rank_null, ~mask, noise=encoder_decoder_by_et, min_iter=10, max_iter=50,
+                                            convergence_threshold=1e-4, sharder=self.sharder)
+                self._save(vT_modify, vT_modify_path)
+                self._save(vT_null, vT_null_path)
+            elif have_m:
                 vT_modify = self._load(vT_modify_path, map_location=self.device).to(self.device).type(self.dtype)
             else:
                 print('!!!RUN LOCAL PULLBACK FOR EDIR SPACE!!!')
@@ -293,8 +308,9 @@ class EditUncondDiffusion(object):
                     min_iter=10, max_iter=50, convergence_threshold=1e-4, mask=mask, noise=encoder_decoder_by_et)
                 self._save(vT_modify, vT_modify_path)
 
-            vT_null = None
-            if null_space_projection and self._exists(vT_null_path):
+            if vT_null is not None:
+                pass
+            elif null_space_projection and self._exists(vT_null_path):
                 vT_null = self._load(vT_null_path, map_location=self.device).to(self.device).type(self.dtype)
             elif null_space_projection:
                 print('!!!RUN LOCAL PULLBACK FOR NULL SPACE!!!')

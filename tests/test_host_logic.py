@@ -375,6 +375,7 @@ def test_max_batch_follows_the_probe_counts():
     pa = define_argparser.parse_args
     assert pa(["--pca_rank", "50", "--pca_rank_null", "10"]).max_batch == 32        # the reference's defaults
     assert pa(["--pca_rank", "1", "--pca_rank_null", "5"]).max_batch == 8           # the shipped CelebA script
-    assert pa(["--pca_rank", "12"]).max_batch == 12
+    assert pa(["--pca_rank", "5", "--pca_rank_null", "5"]).max_batch == 10          # config 2: both solves in one pass
+    assert pa(["--pca_rank", "12", "--pca_rank_null", "1"]).max_batch == 13
     assert pa(["--model_name", "runwayml/stable-diffusion-v1-5", "--pca_rank", "50"]).max_batch == 8
     assert pa(["--max_batch", "4", "--pca_rank", "50"]).max_batch == 4
