@@ -145,10 +145,20 @@ def cpu_baseline(cfg, params, t, budget_s=30.0):
         oed.pullback(x, tt, 1, v0, min_iter=1, max_iter=1, mask=mask)
         t_iter1 = time.time() - t0
         scale = (3 * 5 + 1) / (3 * 1 + 1)              # reference cost model (3k+1)F, BASELINE.md section 2
-        t_iter5 = t_iter1 * scale
-        sample = (f"1 power iteration (jacfwd JVP + autograd VJP + svd) at k=1, 256x256, fp32: {t_iter1:.1f} s; "
-                  f"U-Net forward {t_fwd:.2f} s; EXTRAPOLATED to k=5 x {N_ITER} iterations by the (3k+1)F cost model")
-        measured, factor = t_iter1, scale * N_ITER
+        if t_iter1 * scale < budget_s:
+            # the workload's own iteration, k = 5 probes, timed directly: only the iteration count is scaled
+            v5 = torch.randn(cfg.n, K_PER_GPU, generator=torch.Generator().manual_seed(7))
+            t0 = time.time()
+            oed.pullback(x, tt, K_PER_GPU, v5, min_iter=1, max_iter=1, mask=mask)
+            t_iter5 = time.time() - t0
+            sample = (f"1 power iteration (jacfwd JVP + autograd VJP + svd) at k={K_PER_GPU}, 256x256, fp32, timed "
+                      f"directly: {t_iter5:.1f} s (k=1: {t_iter1:.1f} s, U-Net forward {t_fwd:.2f} s); x {N_ITER} iterations")
+            measured, factor = t_iter5, float(N_ITER)
+        else:
+            t_iter5 = t_iter1 * scale
+            sample = (f"1 power iteration (jacfwd JVP + autograd VJP + svd) at k=1, 256x256, fp32: {t_iter1:.1f} s; "
+                      f"U-Net forward {t_fwd:.2f} s; EXTRAPOLATED to k=5 x {N_ITER} iterations by the (3k+1)F cost model")
+            measured, factor = t_iter1, scale * N_ITER
     else:
         t_iter5 = t_fwd * (3 * 5 + 1)
         sample = (f"U-Net forward 256x256 fp32: {t_fwd:.2f} s (a full power iteration would exceed the {budget_s:.0f} s "
@@ -225,12 +235,33 @@ def e2e_phases(eng, cfg, sched_cls, solver, device):
     t0 = time.perf_counter()
     dec = chain(xb, fwd, 40, 99)                                         # 59 steps x 5 frames of ONE direction (eta = 0)
     sync(); out["decode_one_direction_s"] = time.perf_counter() - t0
+    # what run_edit_null_space_projection does (edit.py:2340-2364 decodes EVERY direction): the 5-frame walks of all five
+    # directions through the 59 steps as one 25-frame batch (engine batches above max_batch are cut by the caller)
+    xall = torch.cat([eng.edit_axpy(xt, vT[i].contiguous(), [-8.0, -4.0, 0.0, 4.0, 8.0]) for i in range(5)], dim=0)
+    mb = eng.max_batch
+
+    def chain_chunked(x, sched, i0, i1):
+        for i in range(i0, i1):
+            t = sched.timesteps[i]
+            a0, a1 = sched.alpha_at(t), sched.alpha_at(sched.timesteps_next[i])
+            x = torch.cat([eng.ddim_step(x[b0:b0 + mb].contiguous(), float(t), a0, a1, 0.0, None)
+                           for b0 in range(0, x.shape[0], mb)], dim=0) if x.shape[0] > mb else eng.ddim_step(x, float(t), a0, a1, 0.0, None)
+        return x
+    chain_chunked(xall, fwd, 40, 41)                                     # warm the 25-frame launch shapes
+    sync(); t0 = time.perf_counter()
+    dec_all = chain_chunked(xall, fwd, 40, 99)
+    sync(); out["decode_all_directions_s"] = time.perf_counter() - t0
     out = {k: round(v, 4) for k, v in out.items()}
     out["basis_plus_edit_s"] = round(out["two_solves_s"] + out["projection_edit_s"], 4)
     out["image_total_one_direction_s"] = round(sum(out[k] for k in ("inversion_s", "to_t_s", "two_solves_s",
                                                                      "projection_edit_s", "decode_one_direction_s")), 4)
-    out["note"] = ("synthetic weights; decode = 59 DDIM steps of the 5-frame +/- walk of one direction (the reference "
-                   "decodes every direction: x5 for a top-5 basis); finite output: " + str(bool(torch.isfinite(dec).all())))
+    out["image_total_s"] = round(sum(out[k] for k in ("inversion_s", "to_t_s", "two_solves_s", "projection_edit_s",
+                                                      "decode_all_directions_s")), 4)
+    out["decode_batch"] = f"{xall.shape[0]} frames, engine max_batch {mb}"
+    out["note"] = ("synthetic weights; image_total_s = the reference's flow for one image (inversion 98 evaluations, 40 to "
+                   "t, the modify + null solves with 12 iterations each, projection + edit walk, decode of ALL five "
+                   "directions = 59 steps x 25 frames, eta = 0); finite output: "
+                   + str(bool(torch.isfinite(dec).all() and torch.isfinite(dec_all).all())))
     return out
 
 
@@ -269,6 +300,18 @@ def main():
             dist.init_process_group(backend=backend)
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
+    if world > 1:
+        # a mis-bound launch must not report n_gpus = N: the group has N ranks and, under RCCL, N distinct GPUs
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+        ident = [None] * world
+        props = torch.cuda.get_device_properties(device)
+        dist.all_gather_object(ident, (os.uname().nodename, str(getattr(props, "uuid", "")) or f"idx{torch.cuda.current_device()}",
+                                       torch.cuda.current_device()))
+        if backend == "nccl":
+            assert len(set(ident)) == world, f"ranks share a GPU: {ident}"
+        n_distinct_gpus = len(set(ident))
+    else:
+        n_distinct_gpus = 1
     sched = YHCustomScheduler()
     sched.set_timesteps(100)
     t = float(sched.timesteps[40])
@@ -368,10 +411,10 @@ def main():
             cfg, k, keep = FFHQ_P2, 64, 20
         params = synth_params(cfg, seed=0)
         # probe batch resident per pass: the top-5 workload carries 5 (its e2e leg 5 + 5, the paired modify / null
-        # solves: room for 16); the 64-probe workload fills the deep levels better
+        # solves, and its decode leg the 25 frames of all five directions: room for 32); the 64-probe workload fills the deep levels better
         # with its whole shard in one pass (measured 2.87 / 2.67 / 2.62 s per solve at 8 / 16 / 32; 0.8 GB of arena per probe)
         k_rank = (k + world - 1) // world
-        mb = int(os.environ.get("LOCO_BENCH_MAX_BATCH", "0")) or (16 if name == "celeba_top5" else min(32, max(8, k_rank)))
+        mb = int(os.environ.get("LOCO_BENCH_MAX_BATCH", "0")) or (32 if name == "celeba_top5" else min(32, max(8, k_rank)))
         eng = LocoEngine(cfg, max_batch=mb, device=device)
         eng.load_state_dict(params)
         eng.set_precision(prec)
@@ -518,6 +561,8 @@ def main():
             extra["p2_k64"] = {
                 "value": round(20 / el, 4), "unit": "edit-directions/s (20 kept of 64 probes)", "ms_per_step": round(el * 1e3, 3),
                 "scaling": "strong", "n_gpus": world, "probes_per_gpu": kl, "n_iter": N_ITER,
+                # every rank evaluates the shared primal once per solve and its own share of the 2 x 64 x n_iter probe passes
+                "ideal_speedup_vs_1gpu": round((1 + 2 * 64 * N_ITER) / (1 + 2 * kl * N_ITER), 3),
                 "whole_step_TFLOPs_executed_per_gpu": round((1 + 2 * kl * N_ITER) * F2 / el / 1e12, 2),
                 "singular_values_head": [round(float(v), 4) for v in s3.tolist()[:5]],
                 "orthonormality_err": float(f"{float((vT3[:20].double() @ vT3[:20].double().T - torch.eye(20, device=device, dtype=torch.float64)).abs().max()):.2e}"),
@@ -562,6 +607,13 @@ def main():
                                             "reference flow with min_iter=10 adds one 2-float readback per iteration after the 11th)"},
             "singular_values": [round(float(v), 4) for v in s.tolist()[:5]],
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "extra_workloads": extra or None,
+            "distinct_gpus": n_distinct_gpus,
+            # the headline scales WEAKLY (5 probes per rank: a wider basis of the same image); the line the north-star
+            # ">= 6x at 8 GPUs" is about is the STRONG-scaling 64-probe workload of the same run:
+            "strong_scaling": ({"workload": "p2_k64 (FFHQ-P2 256^2, 64 probes sharded, keep 20)", "value": extra["p2_k64"]["value"],
+                                "unit": "edit-directions/s", "n_gpus": world, "ms_per_step": extra["p2_k64"]["ms_per_step"],
+                                "ideal_speedup_vs_1gpu": extra["p2_k64"]["ideal_speedup_vs_1gpu"]}
+                               if "p2_k64" in extra and "value" in extra.get("p2_k64", {}) else None),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

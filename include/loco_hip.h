@@ -191,21 +191,12 @@ int  loco_set_context(loco_ctx* ctx, const float* tokens, void* stream);
 int  loco_lincomb(loco_ctx* ctx, const float* const* src, const float* coef, int32_t n, float* out, int64_t count,
                   void* stream);
 
-/* Tuning hook: average ms of one convolution shape (random scratch data) over `iters` launches.
- * mode: 0 raw, 1 GN+SiLU, 2 GN, 3 tangent, 4 cotangent; tile: -1 auto or a variant id. */
-int  loco_bench_conv(loco_ctx* ctx, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t B, int32_t mode,
-                     int32_t taps, int32_t tile, int32_t iters, float* ms_avg, void* stream);
-
 /* Per-kernel HIP-event profile of the convolution launches (bench.py roofline
  * leg).  While enabled every conv launch is bracketed by two events on the
  * caller's stream; loco_profile_report synchronises, then writes one line per
  * kernel variant: "name launches total_ms total_flops" (algorithmic 2*MAC). */
 int  loco_profile_enable(loco_ctx* ctx, int32_t on);
 int  loco_profile_report(loco_ctx* ctx, char* buf, int64_t cap);
-
-/* Debug / test hook: copy an internal primal activation ("down.0.block.0" ...)
- * of the last forward/primal call into dst (device), returns element count or <0. */
-int64_t loco_debug_tensor(loco_ctx* ctx, const char* name, float* dst, int64_t cap, void* stream);
 
 #ifdef __cplusplus
 }

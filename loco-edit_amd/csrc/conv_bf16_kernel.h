@@ -777,6 +777,72 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
     // epilogue.  D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const long out_plane = (long)a.Hout * a.Wout;
     const bool full_co = (co0 + MT <= a.Cout);
+    if (full_co) {
+        // Whole cout tiles leave through LDS: in the accumulator layout a lane owns ONE pixel of 16 couts, i.e. 64 dword
+        // stores per lane and tile, and the tile's write-out is bound by store ISSUE, not by bandwidth (512 wave-stores of
+        // 256 bytes per workgroup).  Staged through the (now idle) operand buffers as S[cout][pixel], a lane reads back 4
+        // consecutive pixels of one cout and the tile leaves in 16-byte stores: a quarter of the vector-memory
+        // instructions for the same bytes, residual / accumulate reads likewise as 16-byte loads.  One round per
+        // accumulator row block h (WM x 32 couts x NT pixels <= 64 KB).
+        constexpr int SROWS = WM * 32, NQ = NT / 4, NTASK = (SROWS * NQ) / NTHR;
+        static_assert((SROWS * NQ) % NTHR == 0 && (NQ & (NQ - 1)) == 0, "epilogue task split");
+        float* const S = reinterpret_cast<float*>(smem_b);
+        const bool part = a.nsplit > 1;
+        float* const ob = part ? a.partial + (((long)split * a.B + b) * a.Cout) * out_plane : a.out + (long)b * a.out_bs;
+        const float* const rb = (!part && a.res) ? a.res + (long)b * a.res_bs : nullptr;
+        const float* const b2 = (!part && a.bias2) ? a.bias2 + (long)b * a.bias2_bs : nullptr;
+        const float* const b1 = part ? nullptr : a.bias;
+        const bool accu = !part && a.accumulate;
+        const int twsh = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
+#pragma unroll
+        for (int h = 0; h < TM; ++h) {
+            if (h > 0) {                                   // the previous round's read-back is done in every wave
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    S[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * NT + (wn * TN + j) * 32 + l31] = acc[h][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            f32x4 v[NTASK], rv[NTASK];
+            unsigned off[NTASK];                        // element offset inside one sample's tensor (< 2^31)
+            int cos_[NTASK];
+#pragma unroll
+            for (int q = 0; q < NTASK; ++q) {
+                const int t = q * NTHR + tid;
+                const int row = t / NQ, quad = t & (NQ - 1);
+                v[q] = *reinterpret_cast<const f32x4*>(&S[row * NT + quad * 4]);
+                const int co = co0 + ((row >> 5) * TM + h) * 32 + (row & 31);
+                const int p = quad * 4;
+                const int ty = p >> twsh, tx = p & (TW - 1);
+                cos_[q] = co;
+                off[q] = (unsigned)co * (unsigned)out_plane + (unsigned)((oy0 + ty) * a.Wout + ox0 + tx);
+            }
+            if (rb || accu) {
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+                    if (rb) t4 = *reinterpret_cast<const f32x4*>(rb + off[q]);
+                    if (accu) t4 += *reinterpret_cast<const f32x4*>(ob + off[q]);
+                    rv[q] = t4;
+                }
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) v[q] += rv[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NTASK; ++q) {
+                float add = 0.f;
+                if (b1) add += b1[cos_[q]];
+                if (b2) add += b2[cos_[q]];
+                v[q] += add;
+                __builtin_nontemporal_store(v[q], reinterpret_cast<f32x4*>(ob + off[q]));   // streamed once: keep L2 for the shared primal cache / weights
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         int p = (wn * TN + j) * 32 + l31;
@@ -857,6 +923,8 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     int halo_w = (TW - 1) * a.stride + KS, halo_h = (TH - 1) * a.stride + KS;
     const int nwb = (TAPS == 9 && STG != 2) ? 3 : 2;
     size_t lds = (size_t)nwb * KS * MT * rec_bytes<PR>() + 2 * ((size_t)halo_w * halo_h + NDUMMY) * halo_pitch<PR>();
+    const size_t stage_bytes = (size_t)WM * 32 * NT * 4;      // epilogue staging tile S[WM*32 couts][NT pixels]
+    if (lds < stage_bytes) lds = stage_bytes;
     dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
     auto kern = PR == PR_F16 ? &conv_mfma_f16<TAPS, WM, WN, TM, TN, MODE, STG>
                              : &conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;

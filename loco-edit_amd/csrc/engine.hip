@@ -21,6 +21,9 @@
 #include <vector>
 
 #include "../../include/loco_hip.h"
+#ifdef LOCO_DIAG
+#include "../../include/loco_hip_diag.h"
+#endif
 #include "kernels.h"
 
 using namespace loco;
@@ -2181,6 +2184,7 @@ int loco_lincomb(loco_ctx* c, const float* const* src, const float* coef, int32_
 }
 
 // Tuning hook: time one convolution shape on scratch data (random inputs), avg ms over `iters` launches.
+#ifdef LOCO_DIAG     /* include/loco_hip_diag.h: tuning / bring-up hooks, only in the diag build */
 int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t B, int32_t mode,
                     int32_t taps, int32_t tile, int32_t iters, float* ms_avg, void* stream) {
     if (!c) return -2;
@@ -2234,6 +2238,8 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     return 0;
 }
 
+#endif
+
 int loco_profile_enable(loco_ctx* c, int32_t on) {
     if (!c) return -2;
     c->prof_on = on != 0;
@@ -2269,6 +2275,7 @@ int loco_profile_report(loco_ctx* c, char* buf, int64_t cap) {
     return 0;
 }
 
+#ifdef LOCO_DIAG
 int64_t loco_debug_tensor(loco_ctx* c, const char* name, float* dst, int64_t cap, void* stream) {
     if (!c) return -2;
     std::string nm(name);
@@ -2296,5 +2303,7 @@ int64_t loco_debug_tensor(loco_ctx* c, const char* name, float* dst, int64_t cap
     c->err = "no such op: " + nm;
     return -3;
 }
+
+#endif
 
 }  // extern "C"

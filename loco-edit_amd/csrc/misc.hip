@@ -585,8 +585,9 @@ __global__ void masked_axpby_kernel(const float* V, const float* dE, const uint8
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long row = i / n, j = i - row * n;
         const uint8_t* mk = (mask2 && row >= split) ? mask2 : mask;
-        float m = (!mk || mk[j]) ? 1.f : 0.f;
-        U[i] = m * ((V ? cv * V[i] : 0.f) + ce * dE[i]);      // V == nullptr: output and input sizes differ (raw network Jacobian)
+        // a select, not a product with 0: a NaN / Inf outside the mask must not reach the Gram / eig of the whole block
+        const bool pass = !mk || mk[j];
+        U[i] = pass ? ((V ? cv * V[i] : 0.f) + ce * dE[i]) : 0.f;   // V == nullptr: output and input sizes differ (raw network Jacobian)
     }
 }
 void launch_masked_axpby(const float* V, const float* dE, const uint8_t* mask, float cv, float ce, float* U, int k,

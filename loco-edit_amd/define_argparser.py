@@ -109,7 +109,9 @@ def build_parser():
     p.add_argument('--cond_dim', type=int, default=16, help='T-LOCO stand-in: width of seeded prompt embeddings when no file is given')
     p.add_argument('--precision', type=str, default=None, choices=['f32', 'bf16x3', 'f16'],
                    help="conv arithmetic of the HIP engine: 'f32' exact fp32 MFMA (parity anchor), 'bf16x3' split-bf16 "
-                        "(fp32-faithful to ~2^-16, default), 'f16' single f16 MFMA with fp32 accumulate (2^-11 operands)")
+                        "(fp32-faithful to ~2^-16, default), 'f16' single f16 MFMA with fp32 accumulate (2^-11 operands; opt-in: "
+                        "operands are cast without range management, so tangent / cotangent entries below 6e-5 lose bits and "
+                        "above 65504 overflow -- pinned on synthetic weights only)")
     return p
 
 
@@ -117,8 +119,13 @@ def parse_args(argv=None):
     args = build_parser().parse_args(argv)
     if args.max_batch <= 0:
         t2i = any(s in args.model_name for s in ('stable-diffusion', 'DeepFloyd', 'LCM'))
-        # the modify-space and null-space solves share their probe batches (solver.local_basis_pair): room for both
-        args.max_batch = 8 if t2i else min(32, max(8, args.pca_rank + args.pca_rank_null))
+        # sized by what actually shares a pass: the probes of the modify-space and null-space solves when they run as a
+        # pair (solver.local_basis_pair; not with LOCO_PAIR_SOLVES=0, without projection or with a loaded basis), and the
+        # edited frames of all shown directions in the decode (vis_num_pc x (2 vis_num + 1) frames at most)
+        pair = (args.null_space_projection and not args.vT_path and os.environ.get("LOCO_PAIR_SOLVES", "1") != "0")
+        probes = args.pca_rank + (args.pca_rank_null if pair else 0)
+        frames = args.pca_rank * (2 * max(int(args.vis_num), 1) + 1)     # main.py passes vis_num_pc = pca_rank
+        args.max_batch = 8 if t2i else min(32, max(8, probes, frames))
     if args.unet_preset:
         from . import config
         args.unet_config = getattr(config, _UNET_PRESETS[args.unet_preset])

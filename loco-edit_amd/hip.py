@@ -19,15 +19,18 @@ from .config import UNetConfig
 _LIB_PATH = os.environ.get("LOCO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libloco_hip.so")
 _lib = None
 
+# diagnostics of include/loco_hip_diag.h: only in a -DLOCO_DIAG build (make -C loco-edit_amd/csrc diag)
+DIAG_SYMBOLS = ["loco_bench_conv", "loco_debug_tensor"]
+
 # every symbol include/loco_hip.h declares
 SYMBOLS = [
     "loco_version", "loco_device_count", "loco_create", "loco_destroy", "loco_last_error",
     "loco_load_param", "loco_params_missing", "loco_unet_forward", "loco_ddim_step", "loco_sched_step",
     "loco_pmp_primal", "loco_pmp_set_second_mask", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
-    "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop", "loco_debug_tensor",
+    "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision",
-    "loco_bench_conv", "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby",
+    "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby",
 ]
 
 
@@ -89,15 +92,16 @@ def load_library():
     lib.loco_timer_stop.argtypes = [vp, vp, C.POINTER(f32)]
     lib.loco_set_precision.argtypes = [vp, i32]
     lib.loco_get_precision.argtypes = [vp]
-    lib.loco_bench_conv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32), vp]
     lib.loco_set_cond.argtypes = [vp, vp, vp]
     lib.loco_set_context.argtypes = [vp, vp, vp]
     lib.loco_masked_axpby.argtypes = [vp, vp, vp, f32, f32, i32, vp, vp]
     lib.loco_lincomb.argtypes = [vp, C.POINTER(vp), C.POINTER(f32), i32, vp, i64, vp]
     lib.loco_profile_enable.argtypes = [vp, i32]
     lib.loco_profile_report.argtypes = [vp, C.c_char_p, i64]
-    lib.loco_debug_tensor.argtypes = [vp, C.c_char_p, vp, i64, vp]
-    lib.loco_debug_tensor.restype = i64
+    if hasattr(lib, "loco_bench_conv"):          # diag build only
+        lib.loco_bench_conv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32), vp]
+        lib.loco_debug_tensor.argtypes = [vp, C.c_char_p, vp, i64, vp]
+        lib.loco_debug_tensor.restype = i64
     _lib = lib
     return lib
 
@@ -368,7 +372,13 @@ class LocoEngine:
         m = self.lib.loco_get_precision(self._ctx)
         return {v: k for k, v in self.PRECISIONS.items()}[m]
 
+    def _need_diag(self, sym):
+        if not hasattr(self.lib, sym):
+            raise RuntimeError(f"{sym} is a diagnostic of include/loco_hip_diag.h: build `make -C loco-edit_amd/csrc diag` "
+                               "and set LOCO_HIP_LIB=<repo>/loco-edit_amd/libloco_hip_diag.so")
+
     def bench_conv(self, cin, cout, H, W, B, mode, taps=9, tile=-1, iters=20) -> float:
+        self._need_diag("loco_bench_conv")
         ms = C.c_float()
         self._check(self.lib.loco_bench_conv(self._ctx, cin, cout, H, W, B, mode, taps, tile, iters, C.byref(ms),
                                              _stream()), "loco_bench_conv")
@@ -389,6 +399,7 @@ class LocoEngine:
         return out
 
     def debug_tensor(self, name: str, numel: int) -> torch.Tensor:
+        self._need_diag("loco_debug_tensor")
         dst = torch.empty(numel, device=self.device, dtype=torch.float32)
         got = self.lib.loco_debug_tensor(self._ctx, name.encode(), _ptr(dst), numel, _stream())
         if got < 0:

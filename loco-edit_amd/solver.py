@@ -28,6 +28,7 @@ class JacobianOperator:
     def __init__(self, engine, x: torch.Tensor, t, at: float, mask: Optional[torch.Tensor], noise: bool = False):
         self.engine = engine
         self.n = engine.n
+        self.n_out = engine.n_out      # width of the rows of J V (= n for the pixel-space denoisers)
         self.masked = mask is not None
         engine.pmp_primal(x.contiguous(), float(t), at, mask, use_et=noise)
 
@@ -46,6 +47,11 @@ class JacobianOperator:
 
     def gather(self, U: torch.Tensor) -> torch.Tensor:  # dense [k,n] -> [k,L]
         return self.engine.mask_gather(U)
+
+
+def _n_out(op, V: torch.Tensor) -> int:
+    """Row width of J V for the operator ``op`` (the decoded image for the latent operator, else the input width)."""
+    return int(getattr(op, "n_out", V.shape[1]))
 
 
 def subspace_iteration(op, algebra, V0: torch.Tensor, min_iter: int = 10, max_iter: int = 100,
@@ -71,8 +77,9 @@ def subspace_iteration(op, algebra, V0: torch.Tensor, min_iter: int = 10, max_it
         if hi > lo:
             U_loc = op.jvp(V[lo:hi].contiguous())      # u_i = J v_i            (edit.py:2451-2455)
             A_loc = op.vjp(U_loc)                       # a_i = J^T u_i          (edit.py:2460-2480)
-        else:                                           # more ranks than probes: this rank only joins the gather
-            U_loc = A_loc = V[0:0].contiguous()
+        else:                                           # more ranks than probes: this rank only joins the gathers
+            A_loc = V[0:0].contiguous()                 # rows of J^T U have the input width ...
+            U_loc = V.new_empty(0, _n_out(op, V))       # ... rows of J V the OUTPUT width (latent operator: n_out != n)
         A = sharder.all_gather_rows(A_loc, k)           # the one collective per iteration
         U = U_loc
         V = A
@@ -169,7 +176,8 @@ def local_basis_pair(engine, x, t, at, rank_a: int, mask_a, rank_b: int, mask_b,
             U_loc = op.jvp(Vin[lo:hi].contiguous())
             A_loc = op.vjp(U_loc)
         else:
-            U_loc = A_loc = Vin[0:0].contiguous()
+            A_loc = Vin[0:0].contiguous()
+            U_loc = Vin.new_empty(0, _n_out(op, Vin))
         A = sharder.all_gather_rows(A_loc, k)
         off = 0
         for j in idx:

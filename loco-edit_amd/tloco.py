@@ -118,6 +118,7 @@ class CFGJacobianOperator:
         self.w = [(branches[name], w) for name, w in weights if w != 0.0]
         self.lead = self.w[0][0]
         self.n = self.lead.n
+        self.n_out = self.lead.n_out
         self.masked = mask is not None
         self.cv = 1.0 / float(np.sqrt(np.float32(at)))
         self.ce = -float(np.sqrt(np.float32(1.0) - np.float32(at))) / float(np.sqrt(np.float32(at)))
@@ -354,14 +355,35 @@ class EditDeepFloydIF(object):
     def x_space_guidance_direct(self, xt, t_idx, vk, single_edit_step):
         return self.engine.edit_axpy(xt.contiguous(), vk.contiguous().view(-1), [self.x_space_guidance_scale * single_edit_step])
 
+    # ------------------------------------------------------------------ multi-rank file discipline (as EditUncondDiffusion)
+    # Under torchrun every rank runs the same flow: whether a file exists is rank 0's decision (every rank takes the same
+    # branch or they hang in the next all-gather), and files are read by rank 0 and broadcast (the ranks need not share a
+    # file system, and a failed read raises on every rank together).
+    def _exists(self, path):
+        return self.sharder.agree(bool(path) and os.path.exists(path))
+
+    def _load(self, path, **kw):
+        if not self.sharder.active:
+            return torch.load(path, **kw)
+        obj, err = None, None
+        if self.sharder.is_main:
+            try:
+                obj = torch.load(path, map_location="cpu")
+            except Exception as ex:              # agreed below: every rank raises, none is left waiting in a collective
+                err = repr(ex)
+        obj, err = self.sharder.agree((obj, err))
+        if err is not None:
+            raise RuntimeError(f"rank 0 could not read {path}: {err}")
+        return obj
+
     # ------------------------------------------------------------------ drivers
     def _masks(self):
         mpath = os.path.join(self.result_folder, "mask/mask.pt")
-        if not os.path.exists(mpath):
+        if not self._exists(mpath):
             raise FileNotFoundError(f"{mpath} missing: stage-II super-resolution + SAM (edit.py:1768-1776) are outside this "
                                     "path; provide mask.pt (bool [N,res,res])")
         print("Loading masks......")
-        return torch.load(mpath)
+        return self._load(mpath)
 
     def _walk(self, original_xt, v_row, vis_num):
         """+/- walk of edit.py:1840-1860 in one kernel (frames x + j*scale*step*v)."""
@@ -398,8 +420,8 @@ class EditDeepFloydIF(object):
         vT_null = None
         if self.sharder.agree(all(os.path.exists(p) for p in paths.values())):
             print('!!!Load CALCULATED BASIS!!!')
-            vT_modify = torch.load(paths["vm"], map_location=self.device).type(self.dtype)
-            vT_null = torch.load(paths["vn"], map_location=self.device).type(self.dtype)
+            vT_modify = self._load(paths["vm"], map_location=self.device).to(self.device).type(self.dtype)
+            vT_null = self._load(paths["vn"], map_location=self.device).to(self.device).type(self.dtype)
         else:
             print('!!!RUN LOCAL PULLBACK!!!')
             u_modify, s_modify, vT_modify = self.local_encoder_decoder_pullback_xt(
@@ -446,7 +468,7 @@ class EditDeepFloydIF(object):
         save_dir = os.path.join(self.result_folder, "basis")
         os.makedirs(save_dir, exist_ok=True)
         if self.ablation_method == "null-space-proj":
-            if not self.sharder.agree(bool(self.vT_path) and os.path.exists(self.vT_path)):
+            if not self._exists(self.vT_path):
                 vT_modify = self.get_v_modify(xt, t, t_idx, F, E, N, mask=mask, mode=self.tilda_v_score_type, jacobian=jacobian)
                 vT_null = None
                 if null_space_projection:
@@ -465,7 +487,7 @@ class EditDeepFloydIF(object):
                         torch.save(vT[[pc_idx], :], os.path.join(save_dir, f'{self.EXP_NAME}-vT.pt'))
             else:
                 print('!!!LOAD VT FROM VT_PATH!!!')
-                vT = torch.load(self.vT_path).to(self.device, torch.float32)
+                vT = self._load(self.vT_path).to(self.device, torch.float32)
                 BASIS_NAME = f"load-basis-'{os.path.basename(self.vT_path)}'"
             original_xt = xt.clone()
             xb = None

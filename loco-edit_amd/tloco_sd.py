@@ -70,6 +70,7 @@ class LatentCFGJacobianOperator:
         self.lead = self.w[0][0]
         self.dec = decoder
         self.n = self.lead.n
+        self.n_out = decoder.n_out      # rows of J V live on the decoded image
         self.masked = mask is not None
         a32 = np.float32(at)
         self.s = float(np.float32(1.0) / (np.float32(LATENT_SCALE) * np.sqrt(a32)))
@@ -253,8 +254,8 @@ class EditStableDiffusion(EditDeepFloydIF):
         F, E, N = self.for_prompt_emb, self.edit_prompt_emb, self.null_prompt_emb
         vT_null = None
         if self.sharder.agree(all(os.path.exists(p) for p in paths.values())):
-            vT_modify = torch.load(paths["vm"], map_location=self.device).type(self.dtype)
-            vT_null = torch.load(paths["vn"], map_location=self.device).type(self.dtype)
+            vT_modify = self._load(paths["vm"], map_location=self.device).to(self.device).type(self.dtype)
+            vT_null = self._load(paths["vn"], map_location=self.device).to(self.device).type(self.dtype)
         else:
             print('!!!RUN LOCAL PULLBACK!!!')
             u_modify, vT_modify = modify_fn()

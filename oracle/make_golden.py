@@ -401,6 +401,9 @@ def main():
     ap.add_argument("--full", action="store_true", help="also the 256x256 CelebA-DDPM summaries (minutes of CPU)")
     ap.add_argument("--full-iters", type=int, default=2)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--iters", type=int, default=12,
+                    help="power iterations of the at-size solver families p2_solver / celeba256_null (the "
+                         "reference's minimum is 12, edit.py:2492 with min_iter=10)")
     a = ap.parse_args()
     import tempfile
     tmpdir = tempfile.mkdtemp(prefix="loco_golden_")
@@ -433,16 +436,17 @@ def main():
         o = {k: v for k, v in o.items() if v is not None}
         torch.save(o, os.path.join(GOLD, "p2_256.pt"))
     if a.only == "p2_solver":
-        print("FFHQ-P2 256x256 solver fixture: 16 probes, 3 iterations")
-        o = gen_for_config("p2_solver", FFHQ_P2, redit, YHS, PullBackDDPM, k=16, k_null=0, n_iter=3,
+        print(f"FFHQ-P2 256x256 solver fixture: 16 probes, {a.iters} iterations")
+        o = gen_for_config("p2_solver", FFHQ_P2, redit, YHS, PullBackDDPM, k=16, k_null=0, n_iter=a.iters,
                            mrect=(110, 130, 70, 110), tmpdir=tmpdir, full_tensors=False, pipeline=False,
                            oracle_solver=False)
         keep = ("cfg", "weights_seed", "x", "t", "mask", "v0_seed", "n_iter", "s_modify", "vT_modify_f16",
                 "vT_proj_seed", "vT_modify_proj")
         torch.save({k: o[k] for k in keep}, os.path.join(GOLD, "p2_solver.pt"))
     if a.only == "celeba256_null":
-        print("config 2 at size: null-space solve on the complement mask, 3 iterations + projection")
-        torch.save(gen_celeba256_null(redit, YHS, PullBackDDPM, tmpdir), os.path.join(GOLD, "celeba256_null.pt"))
+        print(f"config 2 at size: null-space solve on the complement mask, {a.iters} iterations + projection")
+        torch.save(gen_celeba256_null(redit, YHS, PullBackDDPM, tmpdir, n_iter=a.iters),
+                   os.path.join(GOLD, "celeba256_null.pt"))
     if a.only == "eta1":
         print("tiny eta=1 decode with injected noise")
         torch.save(gen_eta1_decode(redit, YHS, PullBackDDPM, tmpdir), os.path.join(GOLD, "tiny_eta1.pt"))

@@ -57,12 +57,13 @@ def ref_cond_unet(model, cond_w, cond_b):
     return call
 
 
-def main():
-    redit, YHS, extract, PullBackDDPM = mg.import_reference()
+def main(redit, cfg, out_name, mid=False):
+    """`mid`: BASELINE config 5's size class -- 64x64 pixels, four levels, attention at 32 / 16 / 8 (1024-token level
+    included) at a width the CPU reference finishes in minutes; CFG noise, get_x0 and the CFG-combined solver only."""
     from utils.utils import betas_for_alpha_bar, get_deepfloyd_if_scheduler
     import tloco_oracle as tl
     import loco_oracle as orc
-    from loco_edit_amd.config import TINY_ADM as cfg, synth_params
+    from loco_edit_amd.config import synth_params
     from loco_edit_amd.tloco import cond_params
     torch.set_num_threads(8)
     tmpdir = tempfile.mkdtemp(prefix="loco_golden_tloco_")
@@ -114,14 +115,15 @@ def main():
     x = torch.randn(1, cfg.in_channels, cfg.resolution, cfg.resolution, generator=gx)
     t = ed.scheduler.timesteps[int(ed.edit_t_idx)]
     out["x"], out["t"] = x, t.clone()
-    mask = mg.rect_mask(cfg, 12, 20, 8, 18)
+    r = cfg.resolution // 32
+    mask = mg.rect_mask(cfg, 12 * r, 20 * r, 8 * r, 18 * r)
     out["mask"] = mask
 
     # ---- 1. CFG noise, every mode (edit.py:1286-1373) on a batch of 2
     xb = torch.cat([x, x.flip(-1)], dim=0)
     out["eps_modes"] = {}
     with torch.no_grad():
-        for mode in tl.MODES:
+        for mode in (tl.MODES if not mid else ("null+(for-null)+(edit-null)",)):
             e_ref = ed._classifer_free_guidance(xb, t, for_e, edit_e, null_e, mode, True)
             mg.check(f"tloco/cfg[{mode}]", ot.cfg_noise(xb, t, for_e, edit_e, null_e, mode), e_ref)
             out["eps_modes"][mode] = e_ref
@@ -144,7 +146,9 @@ def main():
             return v0[:, :size[1]].clone()
         return real_randn(*size, **kw)
     out["solver"] = {}
-    for mode, n_iter, msk in (("null+(for-null)", 6, mask), ("null+(for-null)+(edit-null)", 3, ~mask), ("(for-edit)", 3, None)):
+    specs = ((("null+(for-null)", 6, mask), ("null+(for-null)+(edit-null)", 3, ~mask), ("(for-edit)", 3, None)) if not mid
+             else (("null+(for-null)+(edit-null)", 4, mask), ("null+(for-null)", 3, ~mask)))
+    for mode, n_iter, msk in specs:
         torch.randn = fake_randn
         try:
             with torch.no_grad():
@@ -160,6 +164,10 @@ def main():
         assert c.min() > 0.999
         out["solver"][mode] = {"n_iter": n_iter, "mask": msk, "u": u, "s": s, "vT": vT}
 
+    if mid:
+        torch.save(out, os.path.join(GOLD, out_name))
+        print("done ->", os.path.join(GOLD, out_name))
+        return
     # ---- 4. direction through the Jacobian (edit.py:1680-1717) and 5. direct directions (:1720-1741)
     v_grad = ed.get_delta_xt_via_grad(x, t, ed.edit_t_idx, for_e, edit_e, null_e, mask=mask,
                                       mode="null+(for-null)+(edit-null)").detach()
@@ -190,9 +198,18 @@ def main():
         print(f"  oracle vs reference [tloco/decode uint8] max |diff| {int(diff.max())}, differing pixels {int((diff > 0).sum())}")
         assert int(diff.max()) <= 1
         out.update(xT=xT, xt_edit=xt_e, t_edit=t_e.clone(), dec_in=xb2, dec_u8=img, dec_f32=odec)
-    torch.save(out, os.path.join(GOLD, "tloco_tiny.pt"))
-    print("done ->", os.path.join(GOLD, "tloco_tiny.pt"))
+    torch.save(out, os.path.join(GOLD, out_name))
+    print("done ->", os.path.join(GOLD, out_name))
 
 
 if __name__ == "__main__":
-    main()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", choices=["tiny", "mid"], default=None)
+    a = ap.parse_args()
+    redit_ = mg.import_reference()[0]
+    from loco_edit_amd.config import TINY_ADM, MID_IF64
+    if a.only in (None, "tiny"):
+        main(redit_, TINY_ADM, "tloco_tiny.pt")
+    if a.only in (None, "mid"):
+        main(redit_, MID_IF64, "tloco_mid.pt", mid=True)

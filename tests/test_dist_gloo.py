@@ -91,6 +91,62 @@ def test_sharded_equals_single():
     assert torch.allclose(U1, U2, rtol=1e-4, atol=1e-6)
 
 
+class _RectOp:
+    """Dense rectangular J [n_out, n] (the latent operator's shape: rows of J V are wider than the probes)."""
+
+    def __init__(self, n, n_out):
+        self.J = torch.randn(n_out, n, generator=torch.Generator().manual_seed(3)) / n ** 0.5
+        self.n, self.n_out = n, n_out
+
+    def jvp(self, V):
+        return V @ self.J.T
+
+    def vjp(self, U):
+        return U @ self.J
+
+    def gather(self, U):
+        return U
+
+
+def _run_rect(rank, world, port, k, q):
+    sys.path.insert(0, ROOT)
+    import loco_edit_amd  # noqa: F401
+    from loco_edit_amd.dist import ProbeSharder
+    from loco_edit_amd.solver import subspace_iteration
+    if world > 1:                     # (the single-process leg runs inside pytest: leave its thread count alone)
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    op = _RectOp(48, 112)
+    V0 = torch.linalg.qr(torch.randn(48, k, generator=torch.Generator().manual_seed(5)))[0].T.contiguous()
+    U, s, V, n = subspace_iteration(op, _CpuAlgebra(), V0, min_iter=3, max_iter=3, sharder=ProbeSharder("world"),
+                                    verbose=False)
+    if rank == 0:
+        q.put((U.tolist(), s.tolist(), V.tolist()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_more_ranks_than_probes_rectangular_operator():
+    """with world > k the probe-less ranks contribute EMPTY blocks to both gathers; the block of J V must have
+    the operator's output width (n_out != n for the latent operator), or the all-gather shapes disagree."""
+    ctx = mp.get_context("spawn")
+    q1 = ctx.Queue()
+    _run_rect(0, 1, 0, 1, q1)
+    U1, s1, V1 = (torch.tensor(v) for v in q1.get())
+    q2 = ctx.Queue()
+    procs = [ctx.Process(target=_run_rect, args=(r, 2, 29577, 1, q2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    U2, s2, V2 = (torch.tensor(v) for v in q2.get(timeout=120))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert U2.shape == (1, 112) and V2.shape == (1, 48)
+    assert torch.allclose(U1, U2, rtol=1e-5, atol=1e-7) and torch.allclose(V1, V2, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(s1, s2, rtol=1e-5)
+
+
 # ---------------------------------------------------------------------------
 # the CLI under torchrun (ADVICE r1): process group from the environment, rank 0's seed everywhere, rank 0 alone
 # writes, file-existence branches agreed, uneven probe shards

@@ -28,7 +28,7 @@ def cosrow(a, b):
 def _edit(g, tmp_path, prec, **kw):
     from loco_edit_amd.tloco import EditDeepFloydIF
     os.environ.pop("WORLD_SIZE", None)
-    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=TINY_ADM, synthetic_weights=0, ckpt_path="",
+    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=kw.get("cfg", TINY_ADM), synthetic_weights=0, ckpt_path="",
                      max_batch=8, precision=prec, dataset_name="Random", for_steps=100, use_yh_custom_scheduler=True,
                      guidance_scale=g["guidance_scale"], guidance_scale_edit=g["guidance_scale_edit"],
                      prompt_emb={"for": g["for_e"], "edit": g["edit_e"], "null": g["null_e"]}, for_prompt="a cat",
@@ -230,3 +230,92 @@ def test_pixel_space_tloco_with_text_cross_attention_vs_restatement(tmp_path):
                                                     mask=mask, mode="null+(for-null)", v0=v0.to(DEV), verbose=False)
     ou, os_, ovT = ot.pullback(x, t, F, E, N, 2, v0, min_iter=3, max_iter=3, mask=mask, mode="null+(for-null)")
     assert torch.allclose(s.cpu(), os_, rtol=1e-3) and cosrow(vT, ovT).min().item() > 0.999
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 at ITS size: 64x64 pixels, four levels, attention at 32 / 16 / 8 (the 1024-token level included)
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_config5_64x64_vs_reference_fixture(prec, golden, tmp_path):
+    """tests/golden/tloco_mid.pt: the reference's own `EditDeepFloydIF._classifer_free_guidance` / `get_x0` /
+    `local_encoder_decoder_pullback_xt` (edit.py:1286-1373, 1566-1676) at 64x64 on config 5's geometry at a third of
+    the width (MID_IF64: the size the CPU reference solves in minutes; oracle/make_golden_tloco.py --only mid)."""
+    from loco_edit_amd.config import MID_IF64
+    g = golden("tloco_mid")
+    ed = _edit(g, tmp_path, prec, cfg=MID_IF64)
+    tol = TOL[prec]
+    x, t = g["x"].to(DEV), g["t"]
+    F, E, N = g["for_e"], g["edit_e"], g["null_e"]
+    assert tuple(x.shape) == (1, 3, 64, 64) and ed.edit_t_idx == g["edit_t_idx"]
+    xb = torch.cat([g["x"], g["x"].flip(-1)], dim=0).to(DEV)
+    for mode, ref in g["eps_modes"].items():
+        assert rel(ed._classifer_free_guidance(xb, t, F, E, N, mode, True), ref) < 4 * tol, mode
+    assert rel(ed.get_x0(x, t, ed.edit_t_idx, F, E, N, mask=g["mask"]), g["x0_masked"]) < 4 * tol
+    assert len(g["solver"]) == 2
+    for mode, sv in g["solver"].items():
+        u, s, vT = ed.local_encoder_decoder_pullback_xt(x, t, ed.edit_t_idx, F, E, N, pca_rank=3, min_iter=sv["n_iter"],
+                                                        max_iter=sv["n_iter"], mask=sv["mask"], mode=mode,
+                                                        v0=g["v0"].to(DEV), verbose=False)
+        c = cosrow(vT, sv["vT"])
+        print(f"[{prec}] config-5 geometry, mode {mode}: |cos| {c.tolist()}, s {s.tolist()}")
+        assert ed.last_n_iter == sv["n_iter"] and torch.allclose(s.cpu(), sv["s"], rtol=1e-3), (mode, s.cpu(), sv["s"])
+        assert c.min().item() > 0.999 and cosrow(u.T, sv["u"].T).min().item() > 0.999, mode
+
+
+@pytest.mark.parametrize("preset", ["IF64_STANDIN", "IF64_XATTN_STANDIN"])
+def test_config5_full_width_operator_and_solver_at_size(preset, tmp_path):
+    """Config 5 at its stated size AND width (64x64, 192 x (1,2,3,4), 3 ResBlocks per level, attention at 32 / 16 / 8 with
+    64-channel heads, learned variance; with and without the T5-shaped 77 x 4096 cross-attention stages): no CPU
+    reference finishes at this width, so the checks are the size-independent ones -- adjointness <J V, U> = <V, J^T U>,
+    linearity, J V against a central finite difference of get_x0, and a 12-iteration top-5 solve whose rows are
+    orthonormal, whose s descends and equals ||J v_i|| computed by an independent product."""
+    import loco_edit_amd.config as C
+    from loco_edit_amd.tloco import EditDeepFloydIF
+    cfg = getattr(C, preset)
+    os.environ.pop("WORLD_SIZE", None)
+    gen = torch.Generator().manual_seed(31)
+    if cfg.context_dim:
+        pe = {k: torch.randn(1, cfg.context_len, cfg.context_dim, generator=gen) for k in ("for", "edit", "null")}
+    else:
+        pe = {k: torch.randn(1, 7, 16, generator=gen) for k in ("for", "edit", "null")}
+    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=cfg, synthetic_weights=0, ckpt_path="",
+                     max_batch=8, precision="f32", dataset_name="Random", for_steps=100, use_yh_custom_scheduler=True,
+                     guidance_scale=7.5, guidance_scale_edit=4.0, prompt_emb=pe, for_prompt="a", edit_prompt="b", edit_t=0.6,
+                     sampling_mode=False, tilda_v_score_type="null+(for-null)+(edit-null)", ablation_method="null-space-proj",
+                     mask_type="SAM", vT_path="", x_space_guidance_edit_step=1.0, x_space_guidance_scale=0.5,
+                     x_space_guidance_num_step=16, result_folder=str(tmp_path))
+    ed = EditDeepFloydIF(args)      # exact-fp32 arithmetic for the operator checks: the finite difference needs the digits
+    F, E, N = pe["for"], pe["edit"], pe["null"]
+    x = torch.randn(1, 3, 64, 64, generator=gen).to(DEV)
+    t = ed.scheduler.timesteps[ed.edit_t_idx]
+    mask = torch.zeros(3, 64, 64, dtype=torch.bool); mask[:, 24:40, 16:36] = True
+    mode = "null+(for-null)+(edit-null)"
+    ed._bind_all(F, E, N)
+    op = ed._operator(x, t, mask, mode)
+    V = torch.randn(3, cfg.n, generator=gen).to(DEV)
+    U = (torch.randn(3, cfg.n, generator=gen) * mask.reshape(1, -1)).to(DEV)
+    JV, JtU = op.jvp(V), op.vjp(U)
+    lhs, rhs = (JV * U).sum(dim=1), (V * JtU).sum(dim=1)
+    assert ((lhs - rhs).abs() / (JV.norm(dim=1) * U.norm(dim=1))).max().item() < 2e-4
+    assert float(JV[:, ~mask.reshape(-1).to(DEV)].abs().max()) == 0.0
+    comb = (2.0 * V[0] - 0.5 * V[1] + 0.25 * V[2])[None].contiguous()
+    assert rel(op.jvp(comb)[0], 2.0 * JV[0] - 0.5 * JV[1] + 0.25 * JV[2]) < 2e-4
+    jv_n = op.gather(op.jvp((V[0] / V[0].norm())[None].contiguous()))
+    v = (V[0] / V[0].norm()).view(1, 3, 64, 64)
+    errs = []
+    for h in (1e-2, 5e-3):                       # truncation error falls as h^2: the product is the limit of the difference
+        fd = (ed.get_x0(x + h * v, t, ed.edit_t_idx, F, E, N, mask=mask, mode=mode)
+              - ed.get_x0(x - h * v, t, ed.edit_t_idx, F, E, N, mask=mask, mode=mode)) / (2 * h)
+        errs.append(rel(jv_n, fd))
+    print(f"[{preset}] J v vs central differences: rel err {errs} at h = 1e-2, 5e-3")
+    assert errs[1] < 2e-2 and errs[1] < 0.6 * errs[0]
+    for eng in ed.branches.values():             # the solve in the default arithmetic
+        eng.set_precision("bf16x3")
+    v0 = torch.randn(cfg.n, 5, generator=gen).to(DEV)
+    u, s, vT = ed.local_encoder_decoder_pullback_xt(x, t, ed.edit_t_idx, F, E, N, pca_rank=5, min_iter=12, max_iter=12,
+                                                    mask=mask, mode=mode, v0=v0, verbose=False)
+    assert ed.last_n_iter == 12 and tuple(vT.shape) == (5, cfg.n) and tuple(u.shape) == (int(mask.sum()), 5)
+    vd = vT.double()
+    assert (vd @ vd.T - torch.eye(5, device=DEV, dtype=torch.float64)).abs().max().item() < 2e-6
+    assert bool((s[:-1] >= s[1:] * (1 - 1e-5)).all()) and bool(torch.isfinite(vT).all())
+    op = ed._operator(x, t, mask, mode)
+    assert torch.allclose(op.jvp(vT.contiguous()).norm(dim=1).cpu(), s.cpu(), rtol=2e-2)

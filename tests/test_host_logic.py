@@ -41,6 +41,13 @@ def test_abi_symbols_exported():
     for s in SYMBOLS:
         assert hasattr(lib, s), s
     assert b"gfx950" in lib.loco_version()
+    # the tuning / bring-up hooks are declared in their own header and are NOT exported by the shipped library
+    from loco_edit_amd.hip import DIAG_SYMBOLS
+    dh = open(os.path.join(ROOT, "include", "loco_hip_diag.h")).read()
+    assert set(re.findall(r"\b(loco_[a-z0-9_]+)\s*\(", dh)) == set(DIAG_SYMBOLS)
+    if "diag" not in os.path.basename(library_path()):
+        for s in DIAG_SYMBOLS:
+            assert not hasattr(lib, s), f"{s} leaked into the product library"
 
 
 def test_engine_refuses_without_gpu():
@@ -298,6 +305,26 @@ def test_celeba_mask_dataset_layout_and_mask_semantics(tmp_path):
         CelebAMaskDataset(str(tmp_path / "nope"))
 
 
+def test_celeba_mask_dataset_vs_reference_loader_fixture():
+    """The miniature CelebAMask-HQ tree under tests/golden/celeba_tree (synthetic files written by
+    oracle/make_golden_io.py) through our loader equals what the REFERENCE's own `CelebAMaskDataLoader.__getitem__` /
+    `getmask` (dataset/celeba_hq_dataloader.py:78-123) returned for it: same PIL resize, same [-1, 1] image tensor, same
+    bool [3, res, res] mask including the resampling fringe of the part borders."""
+    from loco_edit_amd.utils import CelebAMaskDataset
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "io_ref.pt"))
+    ds = CelebAMaskDataset(os.path.join(ROOT, "tests", "golden", "celeba_tree"), res=g["res"])
+    assert len(g["images"]) == 2 and len(g["masks"]) == 5
+    for idx, ref in g["images"].items():
+        assert torch.equal(ds[idx], ref)
+    for key, ref in g["masks"].items():
+        idx, sem = key.split(":")
+        mk = ds.getmask(int(idx), sem, list_sem=False)
+        assert mk.dtype == torch.bool and torch.equal(mk, ref)
+        assert 0 < int(ref.sum()) < ref.numel()
+    with pytest.raises(AssertionError):
+        ds.getmask(7, "hair")
+
+
 def test_folder_dataset_order_crop_and_range(tmp_path):
     """utils.py:588-672: FFHQ files sort by integer stem, AFHQ lexicographically; centre crop, resize, [-1,1]."""
     import numpy as np
@@ -369,13 +396,20 @@ def test_integration_md_binding_stub_matches_the_header():
     assert names == [f[0] for f in LocoCfg._fields_]
 
 
-def test_max_batch_follows_the_probe_counts():
-    """--max_batch 0 (default): the probe batch resident per pass is derived from pca_rank / pca_rank_null for the
+def test_max_batch_follows_the_probe_counts(monkeypatch):
+    """--max_batch 0 (default): the batch resident per pass is derived from what actually shares a pass -- the probes of
+    the modify + null solves when they run as a pair, the edited frames of all shown directions in the decode -- for the
     unconditional models (8..32) and stays 8 for the text-to-image paths; an explicit value wins."""
     pa = define_argparser.parse_args
+    monkeypatch.delenv("LOCO_PAIR_SOLVES", raising=False)
+    nsp = ["--null_space_projection", "True", "--vis_num", "2"]
     assert pa(["--pca_rank", "50", "--pca_rank_null", "10"]).max_batch == 32        # the reference's defaults
-    assert pa(["--pca_rank", "1", "--pca_rank_null", "5"]).max_batch == 8           # the shipped CelebA script
-    assert pa(["--pca_rank", "5", "--pca_rank_null", "5"]).max_batch == 10          # config 2: both solves in one pass
-    assert pa(["--pca_rank", "12", "--pca_rank_null", "1"]).max_batch == 13
+    assert pa(["--pca_rank", "1", "--pca_rank_null", "5"] + nsp).max_batch == 8     # the shipped CelebA script: 6 probes, 5 frames
+    assert pa(["--pca_rank", "5", "--pca_rank_null", "5"] + nsp).max_batch == 25    # config 2: 10 probes per pass, 25 frames
+    assert pa(["--pca_rank", "2", "--pca_rank_null", "9"] + nsp).max_batch == 11    # the pair of solves dominates
+    assert pa(["--pca_rank", "2", "--pca_rank_null", "9", "--vis_num", "2"]).max_batch == 10   # no projection: no null solve
+    monkeypatch.setenv("LOCO_PAIR_SOLVES", "0")
+    assert pa(["--pca_rank", "2", "--pca_rank_null", "9"] + nsp).max_batch == 10    # sequential solves: one rank at a time
+    monkeypatch.delenv("LOCO_PAIR_SOLVES")
     assert pa(["--model_name", "runwayml/stable-diffusion-v1-5", "--pca_rank", "50"]).max_batch == 8
     assert pa(["--max_batch", "4", "--pca_rank", "50"]).max_batch == 4
