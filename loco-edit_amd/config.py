@@ -103,6 +103,9 @@ TINY_ADM_XATTN = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blo
                             gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True, context_dim=16, context_len=7)
 TINY_ADM = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,),
                       gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True)
+# 64-channel heads over 1024 and 256 tokens on a network the CPU oracle differentiates in seconds (flash attention tests)
+FLASH_ADM = UNetConfig(resolution=32, ch=64, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(32, 16), gn_eps=1e-5,
+                       arch="adm", num_head_channels=64, learn_sigma=True)
 # config 5's geometry (64x64, four levels, attention at 32 / 16 / 8 incl. the 1024-token level, 64-channel heads, learned
 # variance) at a third of IF64_STANDIN's width: the size the CPU reference solves in minutes (tests/golden/tloco_mid.pt)
 MID_IF64 = UNetConfig(resolution=64, ch=64, ch_mult=(1, 2, 3, 4), num_res_blocks=2, attn_resolutions=(32, 16, 8),

@@ -49,6 +49,16 @@ int conv_bf16_tile_pixels(const ConvArgs& a) {
     return NTs[bf16_tile_of(a)];
 }
 
+int conv_bf16_tile_couts(const ConvArgs& a) {
+    static const int MTs[6] = {128, 128, 32, 64, 128, 128};
+    return MTs[bf16_tile_of(a)];
+}
+// the epilogue statistics exist on the LDS-staged path of whole cout tiles (conv_bf16_kernel.h) and need the finished
+// sums, i.e. no split-K
+bool conv_lowp_can_fuse_stats(const ConvArgs& a) {
+    return a.nsplit <= 1 && (a.Cout % conv_bf16_tile_couts(a)) == 0;
+}
+
 template <int PR>
 static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
     if (taps == 9) {

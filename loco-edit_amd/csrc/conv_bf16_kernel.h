@@ -840,6 +840,32 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 v[q] += add;
                 __builtin_nontemporal_store(v[q], reinterpret_cast<f32x4*>(ob + off[q]));   // streamed once: keep L2 for the shared primal cache / weights
             }
+            // Forward GroupNorm statistics of the finished tile for the norm that consumes this tensor (kernels.h
+            // ConvArgs::st_part): the NQ lanes of a task row hold one cout over the tile's NT pixels; sums about a pivot
+            // inside the row's data (its first value in this tile: no cancellation of sum x^2 - n mean^2 when |mean| >> std),
+            // butterfly over the row's lanes, one lane writes {mean, M2} of the row tile.  (The tangent / cotangent means
+            // were tried here too: they need the {S, xhat} records of the output tile, 8 more bytes per element read in the
+            // latency-exposed epilogue -- 9-26 us per launch against the 16-21 us of the standalone pass, not adopted.)
+            if (a.st_kind == ST_FWD && !part) {
+                const int ntile = (a.Hout * a.Wout) / NT;
+                float* const sp = a.st_part + (long)b * a.Cout * ntile * 2;
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    const float pivot = __shfl(v[q][0], lane & ~(NQ - 1) & 63, 64);
+                    const float d0 = v[q][0] - pivot, d1 = v[q][1] - pivot, d2 = v[q][2] - pivot, d3 = v[q][3] - pivot;
+                    float s1 = (d0 + d1) + (d2 + d3);
+                    float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+                    for (int m = 1; m < (NQ < 64 ? NQ : 64); m <<= 1) {
+                        s1 += __shfl_xor(s1, m, 64);
+                        s2 += __shfl_xor(s2, m, 64);
+                    }
+                    const float m = s1 * (1.0f / NT);
+                    const int t = q * NTHR + tid;
+                    if ((t & (NQ - 1)) == 0)
+                        *reinterpret_cast<f32x2*>(sp + ((long)cos_[q] * ntile + tile_id) * 2) = f32x2{pivot + m, s2 - s1 * m};
+                }
+            }
         }
         return;
     }

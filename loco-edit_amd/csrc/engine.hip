@@ -11,6 +11,7 @@
 // by the tangent and the cotangent pass of a probe batch.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdio>
@@ -39,7 +40,10 @@ using namespace loco;
 
 namespace {
 
-struct Tens { long off; int C, H, W; };
+struct Tens {
+    long off; int C, H, W;
+    int cons_op = -1, cons_norm = 0;   // op whose norm (1: n1, 2: nx) takes its statistics over exactly this tensor, or -1
+};
 
 struct ConvP {       // one convolution's parameters in kernel layouts
     float* wf = nullptr;    // forward  [Cin][taps][CoutP]
@@ -55,6 +59,7 @@ struct NormP {
     float* gamma = nullptr; float* beta = nullptr; int C = 0;
     long soff = 0;      // offset into a stats arena
     long sx_off = -1;   // offset (in float2) into the primal {S, xhat} cache, -1: none
+    bool ready = false; // statistics of the current pass were delivered with the producing conv (run_conv StatReq)
 };
 
 enum OpKind { OP_CONV_IN, OP_RES, OP_ATTN, OP_DOWN, OP_UP, OP_OUT, OP_CONV };   // OP_CONV: plain 3x3 conv, tensor -> tensor
@@ -112,6 +117,11 @@ struct loco_ctx {
     float *arenaP = nullptr, *arenaT = nullptr;
     float *statsP = nullptr, *statsT = nullptr;
     double* red = nullptr;         // reduction scratch (doubles)
+    float *stpart = nullptr, *stpart2 = nullptr;   // row partials of the statistics taken in conv epilogues (lane 0 / lane 1)
+    size_t stpart_floats = 0;
+    bool fuse_stats = true;        // LOCO_FUSE_STATS=0: every statistics pass as its own kernels (A/B timing)
+    bool flash_attn = true;        // LOCO_FLASH_ATTN=0: tangent / cotangent attention on the generic GEMM + softmax-Jacobian path
+    float* attn_delta = nullptr;   // [max_batch][heads][tokens] scratch of the flash cotangent
     float* partial = nullptr;      // split-K workspace
     size_t partial_floats = 0;
     float *tact = nullptr, *tproj = nullptr, *freq = nullptr;
@@ -962,8 +972,45 @@ void conv_defaults(ConvArgs& a) {
     a.stride = 1; a.pad = 1; a.nsplit = 1; a.mode = CM_NONE;
 }
 
+// sc / sh / mr / tst pointers of a norm inside a stats arena
+struct NS { float *sc, *sh, *mr, *tst, *tc; };
+NS nstats(const loco_ctx* c, float* base, const NormP& n) {
+    NS s;
+    s.sc = base + n.soff; s.sh = s.sc + n.C; s.mr = s.sh + n.C; s.tst = s.mr + 2 * c->cfg.gn_groups;
+    s.tc = s.tst + 2 * c->cfg.gn_groups;
+    return s;
+}
+
+// Statistics the NEXT consumer of a conv's output needs (GroupNorm forward statistics, or the tangent / cotangent group
+// means), handed to run_conv with the conv that finishes the tensor: taken in the conv epilogue (whole cout tiles), in the
+// split-K epilogue (reduce + statistics in one kernel), or -- where neither applies -- by the standalone kernels behind the
+// conv.  Either way they are complete when run_conv returns, and the norm is marked `ready` for its consumer.
+struct StatReq {
+    int kind = ST_NONE;                       // ST_FWD / ST_TAN / ST_COT
+    NormP* n = nullptr;
+    float* stats = nullptr;                   // stats arena receiving the result (FWD: this pass's; TAN / COT: statsT)
+    const float* prim = nullptr;              // primal of the conv's output tensor, B = 1 (TAN / COT)
+    const float* ss_scale = nullptr; const float* ss_shift = nullptr;   // FWD: scale-shift norm (ADM)
+};
+
+void stats_standalone(loco_ctx* c, const StatReq& rq, const float* x, long xbs, int B, int HW, int s0, hipStream_t st) {
+    const NormP& n = *rq.n;
+    const long SB = c->stats_per_sample;
+    const int G = c->cfg.gn_groups;
+    if (rq.kind == ST_FWD) {
+        NS s = nstats(c, rq.stats + (long)s0 * SB, n);
+        launch_gn_stats(x, xbs, B, n.C, HW, G, c->cfg.gn_eps, n.gamma, n.beta, s.mr, s.sc, s.sh, SB, c->red, st, rq.ss_scale,
+                        rq.ss_shift);
+    } else {
+        NS sp = nstats(c, c->statsP, n);
+        NS stt = nstats(c, rq.stats + (long)s0 * SB, n);
+        launch_gn_tstats(x, xbs, rq.prim, 0, B, n.C, HW, G, sp.sc, sp.sh, sp.mr, 0, 0, rq.kind == ST_TAN ? 0 : 1, stt.tst,
+                         stt.tc, SB, c->red, st);
+    }
+}
+
 // run a conv with automatic split-K selection
-void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
+void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq* rq = nullptr) {
     if (c->prec == 2) a.wb = a.wh;
     a.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B)
                             : conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
@@ -994,7 +1041,38 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
     }
     // one conv kernel (+ its split-K reduce), each timed as its own profile record so the per-kernel averages agree
     // with rocprofv3's
-    auto one = [&](const ConvArgs& x) {
+    const bool want = rq && rq->kind != ST_NONE && c->prec >= 1 && c->fuse_stats;
+    const int HWo = a.Hout * a.Wout, Gn = c->cfg.gn_groups;
+    const long SBs = c->stats_per_sample;
+    // statistics of samples [s0, s0 + x.B) of the launch `x`, by the cheapest route that applies
+    auto stats_of = [&](ConvArgs& x, int s0) -> int {      // 0: none asked; 1: in the conv epilogue; 2: in the split-K epilogue; 3: standalone
+        if (!rq || rq->kind == ST_NONE) return 0;
+        if (!want) return 3;
+        if (x.nsplit > 1) return (HWo % 4 == 0) ? 2 : 3;
+        const size_t need = (size_t)x.B * x.Cout * (HWo / conv_bf16_tile_pixels(x)) * 2;
+        if (rq->kind == ST_FWD && conv_lowp_can_fuse_stats(x) && need <= c->stpart_floats) {
+            x.st_part = c->stpart; x.st_kind = ST_FWD;
+            return 1;
+        }
+        return 3;
+    };
+    auto stats_after = [&](const ConvArgs& x, int s0, int how) {
+        if (how == 0 || how == 2) return;
+        const NormP& n = *rq->n;
+        if (how == 3) { stats_standalone(c, *rq, x.out, x.out_bs, x.B, HWo, s0, st); return; }
+        NS so = nstats(c, rq->stats + (long)s0 * SBs, n);
+        launch_gn_fused_finalize(x.st_part, HWo / conv_bf16_tile_pixels(x), x.B, n.C, HWo, Gn, c->cfg.gn_eps, n.gamma, n.beta,
+                                 so.mr, so.sc, so.sh, SBs, rq->ss_scale, rq->ss_shift, st);
+    };
+    auto reduce_with_stats = [&](const ConvArgs& x, int s0) {
+        const NormP& n = *rq->n;
+        NS sp = nstats(c, c->statsP, n);
+        NS so = nstats(c, rq->stats + (long)s0 * SBs, n);
+        launch_conv_splitk_reduce_stats(x, rq->kind, Gn, c->cfg.gn_eps, n.gamma, n.beta, so.mr, so.sc, so.sh, SBs, rq->ss_scale,
+                                        rq->ss_shift, rq->prim, sp.sc, sp.sh, sp.mr, so.tst, so.tc, SBs, c->red, st);
+    };
+    auto one = [&](ConvArgs& x, int s0) {
+        const int how = stats_of(x, s0);
         loco_ctx::ProfRec r, rr;
         if (c->prof_on) {
             r.name = conv_variant_name(x, taps, c->prec);
@@ -1014,11 +1092,13 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
                 rr.e0 = c->next_event(); rr.e1 = c->next_event();
                 (void)hipEventRecord(rr.e0, st);
             }
-            launch_conv_splitk_reduce(x, st);
+            if (how == 2) reduce_with_stats(x, s0); else launch_conv_splitk_reduce(x, st);
             if (c->prof_on) { (void)hipEventRecord(rr.e1, st); c->prof.push_back(rr); }
         }
+        stats_after(x, s0, how);
     };
-    if (!tail_probes) { one(a); return; }
+    if (rq && rq->kind != ST_NONE) rq->n->ready = true;
+    if (!tail_probes) { one(a, 0); return; }
     ConvArgs m = a, t = a;
     const int nb = a.B - tail_probes;
     m.B = nb;
@@ -1031,8 +1111,8 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st) {
     if (t.mr) t.mr += (long)nb * a.mr_bs;
     if (t.tst) t.tst += (long)nb * a.tst_bs;
     if (t.tc) t.tc += (long)nb * a.tc_bs;
-    one(m);
-    one(t);
+    one(m, 0);
+    one(t, nb);
 }
 
 inline void setw(ConvArgs& a, const ConvP& p, bool dgrad) {
@@ -1041,13 +1121,25 @@ inline void setw(ConvArgs& a, const ConvP& p, bool dgrad) {
     a.wh = dgrad ? (const void*)p.whd : (const void*)p.whf;
 }
 
-// sc / sh / mr / tst pointers of a norm inside a stats arena
-struct NS { float *sc, *sh, *mr, *tst, *tc; };
-NS nstats(const loco_ctx* c, float* base, const NormP& n) {
-    NS s;
-    s.sc = base + n.soff; s.sh = s.sc + n.C; s.mr = s.sh + n.C; s.tst = s.mr + 2 * c->cfg.gn_groups;
-    s.tc = s.tst + 2 * c->cfg.gn_groups;
-    return s;
+// the norm (if any) that takes its statistics over exactly tensor `tid`
+NormP* consumer_norm(loco_ctx* c, int tid) {
+    const Tens& t = c->tens[tid];
+    if (t.cons_op < 0) return nullptr;
+    Op& op = c->ops[t.cons_op];
+    return t.cons_norm == 2 ? &op.nx : &op.n1;
+}
+StatReq req_fwd(NormP* n, float* stats, const float* ss_scale = nullptr, const float* ss_shift = nullptr) {
+    StatReq r;
+    if (n) { r.kind = ST_FWD; r.n = n; r.stats = stats; r.ss_scale = ss_scale; r.ss_shift = ss_shift; }
+    return r;
+}
+StatReq req_lin(loco_ctx* c, int kind, NormP* n, const float* prim) {       // tangent / cotangent statistics into statsT
+    StatReq r;
+    if (n) { r.kind = kind; r.n = n; r.stats = c->statsT; r.prim = prim; }
+    return r;
+}
+void clear_ready(loco_ctx* c) {
+    for (auto& op : c->ops) op.n1.ready = op.n2.ready = op.nx.ready = false;
 }
 
 void gn_forward_stats(const Pass& p, const NormP& n, const float* x, long xbs, int HW) {
@@ -1092,14 +1184,14 @@ void xa_values(const XA& x, const float* K, const float* S, long s_bs, float* O,
     launch_gemm(g, x.st);
 }
 void xa_conv1x1(loco_ctx* c, const ConvP& w, bool dgrad, const float* in, long in_bs, float* out, long out_bs, int C, int H,
-                int W, int B, const float* res, long res_bs, bool with_bias, hipStream_t st) {
+                int W, int B, const float* res, long res_bs, bool with_bias, hipStream_t st, const StatReq* rq = nullptr) {
     ConvArgs a; conv_defaults(a);
     a.in = in; a.in_bs = in_bs; a.Cin = C; a.Hin = H; a.Win = W;
     setw(a, w, dgrad); a.pad = 0;
     if (with_bias) a.bias = w.bias;
     a.res = res; a.res_bs = res_bs;
     a.out = out; a.out_bs = out_bs; a.Cout = C; a.Hout = H; a.Wout = W; a.B = B;
-    run_conv(c, a, 1, st);
+    run_conv(c, a, 1, st, rq);
 }
 
 // ------------------------------ forward ------------------------------------
@@ -1108,6 +1200,8 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
     const loco_unet_cfg& cfg = c->cfg;
     Pass p{c, st, B, arena, stats};
     const long SB = c->stats_per_sample;
+    clear_ready(c);
+    auto next_fwd = [&](int tid) { return req_fwd(consumer_norm(c, tid), stats); };   // forward statistics for the consumer of `tid`
     if (cfg.arch != 2) {
         launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st, cfg.arch == 1,
                     c->has_cond ? c->cond_add : nullptr, t_ptr);
@@ -1123,7 +1217,8 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 setw(a, op.conv, false); a.bias = op.conv.bias;
                 a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 if (op.ksize == 1) a.pad = 0;
-                run_conv(c, a, op.ksize == 1 ? 1 : 9, st);
+                const StatReq rq = next_fwd(op.out);
+                run_conv(c, a, op.ksize == 1 ? 1 : 9, st, &rq);
                 break;
             }
             case OP_CONV: {
@@ -1132,13 +1227,15 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false); a.bias = op.conv.bias;
                 a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
-                run_conv(c, a, 9, st);
+                const StatReq rq = next_fwd(op.out);
+                run_conv(c, a, 9, st, &rq);
                 break;
             }
             case OP_RES: {
                 const Tens& ti = c->tens[op.in];
                 const int HWi = ti.H * ti.W;
-                gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HWi);
+                if (!op.n1.ready) gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HWi);
+                op.n1.ready = false;
                 NS s1 = nstats(c, stats, op.n1);
                 ConvArgs a; conv_defaults(a);
                 a.Cin = ti.C;
@@ -1160,12 +1257,11 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                     }
                 }
                 a.out = p.T(op.h1); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
-                run_conv(c, a, 9, st);
-                {
-                    NS s2 = nstats(c, stats, op.n2);
+                {   // conv1 also delivers norm2's statistics of its output (scale-shift folded in for the ADM blocks)
                     const float* ssc = op.scale_shift ? c->tproj + op.tproj_off : nullptr;
-                    launch_gn_stats(p.T(op.h1), p.bs(), B, op.n2.C, HW, cfg.gn_groups, cfg.gn_eps, op.n2.gamma,
-                                    op.n2.beta, s2.mr, s2.sc, s2.sh, SB, c->red, st, ssc, ssc ? ssc + to.C : nullptr);
+                    const StatReq rq2 = req_fwd(&op.n2, stats, ssc, ssc ? ssc + to.C : nullptr);
+                    run_conv(c, a, 9, st, &rq2);
+                    op.n2.ready = false;
                 }
                 NS s2 = nstats(c, stats, op.n2);
                 const float* xin = op.updown ? p.T(op.xu) : p.T(op.in);   // shortcut input after x_upd
@@ -1183,12 +1279,14 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 setw(b, op.c2, false); b.bias = op.c2.bias; b.res = res; b.res_bs = p.bs();
                 b.mode = CM_GN_SILU; b.sc = s2.sc; b.sh = s2.sh; b.scsh_bs = SB;
                 b.out = p.T(op.out); b.out_bs = p.bs(); b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
-                run_conv(c, b, 9, st);
+                const StatReq rq = next_fwd(op.out);
+                run_conv(c, b, 9, st, &rq);
                 break;
             }
             case OP_ATTN: {
                 const int C = to.C, T = HW, NH = op.heads, CH = C / NH;
-                gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HW);
+                if (!op.n1.ready) gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HW);
+                op.n1.ready = false;
                 NS s = nstats(c, stats, op.n1);
                 ConvArgs a; conv_defaults(a);
                 a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = C; a.Hin = to.H; a.Win = to.W;
@@ -1217,11 +1315,15 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 setw(pr, op.proj, false); pr.bias = op.proj.bias; pr.pad = 0;
                 pr.res = p.T(op.in); pr.res_bs = p.bs();
                 pr.out = p.T(op.has_x ? op.xmid : op.out); pr.out_bs = p.bs(); pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
-                run_conv(c, pr, 1, st);
+                {
+                    const StatReq rq = next_fwd(op.has_x ? op.xmid : op.out);
+                    run_conv(c, pr, 1, st, &rq);
+                }
                 if (op.has_x) {
                     if (!c->has_ctx) { c->err = "this architecture has cross-attention stages: call loco_set_context first"; return -1; }
                     const XA x = xa_of(c, op, B, st);
-                    gn_forward_stats(p, op.nx, p.T(op.xmid), p.bs(), HW);
+                    if (!op.nx.ready) gn_forward_stats(p, op.nx, p.T(op.xmid), p.bs(), HW);
+                    op.nx.ready = false;
                     NS sx = nstats(c, stats, op.nx);
                     ConvArgs qa; conv_defaults(qa);
                     qa.in = p.T(op.xmid); qa.in_bs = p.bs(); qa.Cin = C; qa.Hin = to.H; qa.Win = to.W;
@@ -1232,8 +1334,9 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                     xa_scores(x, p.T(op.xq), p.bs(), op.xK, p.T(op.xS), p.bs(), x.scale, true);
                     launch_softmax_rows(p.T(op.xS), (long)NH * T, x.Lp, st, B, p.bs());
                     xa_values(x, op.xV, p.T(op.xS), p.bs(), p.T(op.xo), p.bs());
+                    const StatReq rqx = next_fwd(op.out);
                     xa_conv1x1(c, op.xproj, false, p.T(op.xo), p.bs(), p.T(op.out), p.bs(), C, to.H, to.W, B,
-                               p.T(op.xmid), p.bs(), true, st);
+                               p.T(op.xmid), p.bs(), true, st, &rqx);
                 }
                 break;
             }
@@ -1244,12 +1347,14 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 setw(a, op.conv, false); a.bias = op.conv.bias;
                 if (op.kind == OP_DOWN) { a.stride = 2; a.pad = 0; } else { a.upsample = 1; }
                 a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
-                run_conv(c, a, 9, st);
+                const StatReq rq = next_fwd(op.out);
+                run_conv(c, a, 9, st, &rq);
                 break;
             }
             case OP_OUT: {
                 const Tens& ti = c->tens[op.in];
-                gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), ti.H * ti.W);
+                if (!op.n1.ready) gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), ti.H * ti.W);
+                op.n1.ready = false;
                 NS s = nstats(c, stats, op.n1);
                 ConvArgs a; conv_defaults(a);
                 a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
@@ -1290,6 +1395,9 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
     const long PS = c->per_sample;
     auto TP = [&](int id) { return c->arenaP + c->tens[id].off; };   // primal
     auto TT = [&](int id) { return c->arenaT + c->tens[id].off; };   // tangent
+    clear_ready(c);
+    // tangent group means for the norm that consumes tensor `tid`, delivered with the conv that finishes it
+    auto next_tan = [&](int tid) { return req_lin(c, ST_TAN, consumer_norm(c, tid), TP(tid)); };
     for (auto& op : c->ops) {
         const Tens& to = c->tens[op.out];
         const int HW = to.H * to.W;
@@ -1300,7 +1408,8 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 setw(a, op.conv, false);
                 a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 if (op.ksize == 1) a.pad = 0;
-                run_conv(c, a, op.ksize == 1 ? 1 : 9, st);
+                const StatReq rq = next_tan(op.out);
+                run_conv(c, a, op.ksize == 1 ? 1 : 9, st, &rq);
                 break;
             }
             case OP_CONV: {
@@ -1309,13 +1418,15 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false);
                 a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
-                run_conv(c, a, 9, st);
+                const StatReq rq = next_tan(op.out);
+                run_conv(c, a, 9, st, &rq);
                 break;
             }
             case OP_RES: {
                 const Tens& ti = c->tens[op.in];
                 const int HWi = ti.H * ti.W;
-                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HWi, B, st);
+                if (!op.n1.ready) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HWi, B, st);
+                op.n1.ready = false;
                 ConvArgs a; conv_defaults(a);
                 a.Cin = ti.C;
                 setw(a, op.c1, false);
@@ -1336,8 +1447,11 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                     }
                 }
                 a.out = TT(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
-                run_conv(c, a, 9, st);
-                tangent_stats(c, op.n2, TT(op.h1), PS, TP(op.h1), HW, B, st);
+                {
+                    const StatReq rq2 = req_lin(c, ST_TAN, &op.n2, TP(op.h1));       // norm2's group means with conv1
+                    run_conv(c, a, 9, st, &rq2);
+                    op.n2.ready = false;
+                }
                 const float* xin = op.updown ? TT(op.xu) : TT(op.in);
                 const float* res = xin;
                 if (op.has_nin) {
@@ -1353,12 +1467,14 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 setw(b, op.c2, false); b.res = res; b.res_bs = PS;
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.out = TT(op.out); b.out_bs = PS; b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
-                run_conv(c, b, 9, st);
+                const StatReq rq = next_tan(op.out);
+                run_conv(c, b, 9, st, &rq);
                 break;
             }
             case OP_ATTN: {
                 const int C = to.C, T = HW, NH = op.heads, CH = C / NH;
-                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
+                if (!op.n1.ready) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
+                op.n1.ready = false;
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 launch_gn_apply(1, TT(op.in), PS, TP(op.in), 0, nullptr, 0, TT(op.hn), PS, 0, B, C, HW,
@@ -1371,6 +1487,14 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 const long HS = 3L * CH * T, SS = (long)T * T;
                 float* q = TP(op.qkv); float* k = q + (long)CH * T; float* v = k + (long)CH * T;
                 float* dq = TT(op.qkv); float* dk = dq + (long)CH * T; float* dv = dk + (long)CH * T;
+                const bool flash = c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH);
+                if (flash) {        // do from dq, dk, dv and the primal P / o in one kernel, no [T x T] tangent (attn_flash.hip)
+                    AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+                    fa.T = T; fa.NH = NH; fa.B = B; fa.scale = 1.0f / std::sqrt((float)CH);
+                    fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = TP(op.S); fa.o = TP(op.o);
+                    fa.dq = dq; fa.dk = dk; fa.dv = dv; fa.bs_d = PS; fa.out = TT(op.o); fa.bs_out = PS;
+                    launch_attn_flash_tangent(fa, st);
+                }
                 GemmArgs g; std::memset(&g, 0, sizeof(g));
                 g.A = dq; g.sam = 1; g.sak = T; g.sab = PS; g.sah = HS;
                 g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = HS;
@@ -1381,25 +1505,33 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 // beta = 1 measured faster (616 vs 639 ms per tloco_if64 step)
                 const bool kcat = T <= 256;
                 if (kcat) { g.A2 = q; g.sab2 = 0; g.Bm2 = dk; g.sbb2 = PS; }
+                if (!flash) {
                 attn_gemm(c, g, st);
                 if (!kcat) { g.A = q; g.sab = 0; g.Bm = dk; g.sbb = PS; g.beta = 1.f; attn_gemm(c, g, st); }
                 launch_softmax_jac(TT(op.S), TP(op.S), (long)NH * T, T, (long)NH * T, 1.0f / std::sqrt((float)CH), st, B, PS);
+                }
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
                 h.A = dv; h.sam = T; h.sak = 1; h.sab = PS; h.sah = HS;
                 h.Bm = TP(op.S); h.sbk = 1; h.sbn = T; h.sbb = 0; h.sbh = SS;
                 h.C = TT(op.o); h.scm = T; h.scn = 1; h.scb = PS; h.sch = (long)CH * T;
                 h.M = CH; h.N = T; h.K = T; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
                 if (kcat) { h.A2 = v; h.sab2 = 0; h.Bm2 = TT(op.S); h.sbb2 = PS; }
+                if (!flash) {
                 attn_gemm(c, h, st);
                 if (!kcat) { h.A = v; h.sab = 0; h.Bm = TT(op.S); h.sbb = PS; h.beta = 1.f; attn_gemm(c, h, st); }
+                }
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = TT(op.o); pr.in_bs = PS; pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, false); pr.pad = 0; pr.res = TT(op.in); pr.res_bs = PS;
                 pr.out = TT(op.has_x ? op.xmid : op.out); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
-                run_conv(c, pr, 1, st);
+                {
+                    const StatReq rq = next_tan(op.has_x ? op.xmid : op.out);
+                    run_conv(c, pr, 1, st, &rq);
+                }
                 if (op.has_x) {
                     const XA x = xa_of(c, op, B, st);
-                    tangent_stats(c, op.nx, TT(op.xmid), PS, TP(op.xmid), HW, B, st);
+                    if (!op.nx.ready) tangent_stats(c, op.nx, TT(op.xmid), PS, TP(op.xmid), HW, B, st);
+                    op.nx.ready = false;
                     NS spx = nstats(c, c->statsP, op.nx);
                     NS stx = nstats(c, c->statsT, op.nx);
                     launch_gn_apply(1, TT(op.xmid), PS, TP(op.xmid), 0, nullptr, 0, TT(op.xhn), PS, 0, B, C, HW,
@@ -1408,7 +1540,8 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                     xa_scores(x, TT(op.xq), PS, op.xK, TT(op.xS), PS, 1.f, false);                  // dS = dq^T K
                     launch_softmax_jac(TT(op.xS), TP(op.xS), (long)NH * T, x.Lp, (long)NH * T, x.scale, st, B, PS);
                     xa_values(x, op.xV, TT(op.xS), PS, TT(op.xo), PS);                              // do = V dP^T
-                    xa_conv1x1(c, op.xproj, false, TT(op.xo), PS, TT(op.out), PS, C, to.H, to.W, B, TT(op.xmid), PS, false, st);
+                    const StatReq rqx = next_tan(op.out);
+                    xa_conv1x1(c, op.xproj, false, TT(op.xo), PS, TT(op.out), PS, C, to.H, to.W, B, TT(op.xmid), PS, false, st, &rqx);
                 }
                 break;
             }
@@ -1419,12 +1552,14 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 setw(a, op.conv, false);
                 if (op.kind == OP_DOWN) { a.stride = 2; a.pad = 0; } else { a.upsample = 1; }
                 a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
-                run_conv(c, a, 9, st);
+                const StatReq rq = next_tan(op.out);
+                run_conv(c, a, 9, st, &rq);
                 break;
             }
             case OP_OUT: {
                 const Tens& ti = c->tens[op.in];
-                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), ti.H * ti.W, B, st);
+                if (!op.n1.ready) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), ti.H * ti.W, B, st);
+                op.n1.ready = false;
                 ConvArgs a; conv_defaults(a);
                 a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false);
@@ -1454,6 +1589,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
     const int G = cfg.gn_groups;
     auto TP = [&](int id) { return c->arenaP + c->tens[id].off; };
     auto TG = [&](int id) { return c->arenaT + c->tens[id].off; };   // cotangent of tensor id
+    clear_ready(c);
     for (int oi = (int)c->ops.size() - 1; oi >= 0; --oi) {
         Op& op = c->ops[oi];
         const Tens& to = c->tens[op.out];
@@ -1465,8 +1601,11 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 a.in = ge; a.in_bs = c->n_out; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
                 setw(a, op.conv, true);
                 a.out = TG(op.a1); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
-                run_conv(c, a, 9, st);
-                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), ti.H * ti.W, B, 1, st);
+                {
+                    const StatReq rq = req_lin(c, ST_COT, &op.n1, TP(op.in));        // the norm's cotangent means with the conv
+                    run_conv(c, a, 9, st, &rq);
+                    op.n1.ready = false;
+                }
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 0, B, ti.C, ti.H * ti.W, G,
@@ -1500,8 +1639,11 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
                 setw(a, op.c2, true);
                 a.out = TG(op.h1); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
-                run_conv(c, a, 9, st);
-                cot_stats(c, op.n2, TG(op.h1), PS, TP(op.h1), HW, B, 1, st);
+                {
+                    const StatReq rq2 = req_lin(c, ST_COT, &op.n2, TP(op.h1));
+                    run_conv(c, a, 9, st, &rq2);
+                    op.n2.ready = false;
+                }
                 // dgrad conv1 of the norm2/silu cotangent of g_a2 (fused in the staging), at conv1's resolution
                 ConvArgs b; conv_defaults(b);
                 b.in = TG(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
@@ -1511,7 +1653,8 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 b.out_bs = PS; b.Cout = ti.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
                 if (op.updown == 0) {
                     b.out = TG(op.a1);
-                    run_conv(c, b, 9, st);
+                    const StatReq rq1 = req_lin(c, ST_COT, &op.n1, TP(op.in));
+                    run_conv(c, b, 9, st, &rq1);
                 } else if (op.updown == 1) {
                     b.out = TG(op.ap);                                     // cotangent of the pooled activation
                     run_conv(c, b, 9, st);
@@ -1521,7 +1664,8 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                     run_conv(c, b, 9, st);
                     launch_pool2x2_sum(TG(op.xu), PS, TG(op.a1), PS, 0, B, ti.C, ti.H, ti.W, st);           // nearest^T
                 }
-                cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), HWi, B, 1, st);
+                if (!op.n1.ready) cot_stats(c, op.n1, TG(op.a1), PS, TP(op.in), HWi, B, 1, st);
+                op.n1.ready = false;
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 int acc = op.in_is_skip ? 1 : 0;
@@ -1577,32 +1721,42 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 setw(pr, op.proj, true); pr.pad = 0;
                 pr.out = TG(op.o); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
                 run_conv(c, pr, 1, st);
+                const bool flash = c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH);
+                if (flash) {        // g_q, g_k, g_v from g_o and the primal q / k / v / P / o, no [T x T] cotangent (attn_flash.hip)
+                    AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+                    fa.T = T; fa.NH = NH; fa.B = B; fa.scale = 1.0f / std::sqrt((float)CH);
+                    fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = TP(op.S); fa.o = TP(op.o);
+                    fa.go = TG(op.o); fa.bs_go = PS; fa.gq = gq; fa.gk = gk; fa.gv = gv; fa.bs_g = PS; fa.delta = c->attn_delta;
+                    launch_attn_flash_cotangent(fa, st);
+                }
                 // g_v[c][j] = sum_i g_o[c][i] P[i][j]
                 GemmArgs g; std::memset(&g, 0, sizeof(g));
                 g.A = TG(op.o); g.sam = T; g.sak = 1; g.sab = PS; g.sah = OS;
                 g.Bm = TP(op.S); g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = SS;
                 g.C = gv; g.scm = T; g.scn = 1; g.scb = PS; g.sch = HS;
                 g.M = CH; g.N = T; g.K = T; g.batch = B; g.batch2 = NH; g.alpha = 1.f; g.beta = 0.f;
-                attn_gemm(c, g, st);
+                if (!flash) attn_gemm(c, g, st);
                 // g_P[i][j] = sum_c g_o[c][i] v[c][j]
                 GemmArgs h; std::memset(&h, 0, sizeof(h));
                 h.A = TG(op.o); h.sam = 1; h.sak = T; h.sab = PS; h.sah = OS;
                 h.Bm = v; h.sbk = T; h.sbn = 1; h.sbb = 0; h.sbh = HS;
                 h.C = TG(op.S); h.scm = T; h.scn = 1; h.scb = PS; h.sch = SS;
                 h.M = T; h.N = T; h.K = CH; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
+                if (!flash) {
                 attn_gemm(c, h, st);
                 launch_softmax_jac(TG(op.S), TP(op.S), (long)NH * T, T, (long)NH * T, 1.0f / std::sqrt((float)CH), st, B, PS);
+                }
                 // g_q[c][i] = sum_j k[c][j] g_S[i][j]
                 GemmArgs gq_; std::memset(&gq_, 0, sizeof(gq_));
                 gq_.A = k; gq_.sam = T; gq_.sak = 1; gq_.sab = 0; gq_.sah = HS;
                 gq_.Bm = TG(op.S); gq_.sbk = 1; gq_.sbn = T; gq_.sbb = PS; gq_.sbh = SS;
                 gq_.C = gq; gq_.scm = T; gq_.scn = 1; gq_.scb = PS; gq_.sch = HS;
                 gq_.M = CH; gq_.N = T; gq_.K = T; gq_.batch = B; gq_.batch2 = NH; gq_.alpha = 1.f; gq_.beta = 0.f;
-                attn_gemm(c, gq_, st);
+                if (!flash) attn_gemm(c, gq_, st);
                 // g_k[c][j] = sum_i q[c][i] g_S[i][j]
                 GemmArgs gk_ = gq_;
                 gk_.A = q; gk_.Bm = TG(op.S); gk_.sbk = T; gk_.sbn = 1; gk_.C = gk;
-                attn_gemm(c, gk_, st);
+                if (!flash) attn_gemm(c, gk_, st);
                 // g_hn = Wqkv^T g_qkv
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.qkv); a.in_bs = PS; a.Cin = 3 * C; a.Hin = to.H; a.Win = to.W;
@@ -1649,10 +1803,10 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
 // arena and its own reduction / split-K scratch; the host enqueues lane 0 completely, then lane 1.
 namespace {
 struct LaneSwap {
-    loco_ctx* c; float *arenaT, *statsT, *partial, *eps_buf, *ge, *gx0; double* red; size_t partial_floats;
+    loco_ctx* c; float *arenaT, *statsT, *partial, *eps_buf, *ge, *gx0, *stpart; double* red; size_t partial_floats;
     LaneSwap(loco_ctx* c_, int s0) : c(c_) {
         arenaT = c->arenaT; statsT = c->statsT; partial = c->partial; eps_buf = c->eps_buf; ge = c->ge; gx0 = c->gx0;
-        red = c->red; partial_floats = c->partial_floats;
+        red = c->red; partial_floats = c->partial_floats; stpart = c->stpart; c->stpart = c->stpart2;
         c->arenaT += (long)s0 * c->per_sample; c->statsT += (long)s0 * c->stats_per_sample;
         c->eps_buf += (long)s0 * c->n_out; c->ge += (long)s0 * c->n_out; c->gx0 += (long)s0 * c->n_in;
         c->partial += partial_floats / 2; c->partial_floats = partial_floats / 2;
@@ -1660,7 +1814,7 @@ struct LaneSwap {
     }
     ~LaneSwap() {
         c->arenaT = arenaT; c->statsT = statsT; c->partial = partial; c->eps_buf = eps_buf; c->ge = ge; c->gx0 = gx0;
-        c->red = red; c->partial_floats = partial_floats;
+        c->red = red; c->partial_floats = partial_floats; c->stpart = stpart;
     }
 };
 template <typename F>
@@ -1721,6 +1875,14 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
     if (build_program(c)) return -2;
     for (auto& op : c->ops)
         if (op.kind == OP_RES && op.updown && op.has_nin) { c->err = "resampling ResBlock with a channel change is not supported"; return -2; }
+    // which norm takes its statistics over exactly which tensor: the conv that finishes that tensor delivers them
+    for (size_t i = 0; i < c->ops.size(); ++i) {
+        const Op& op = c->ops[i];
+        if ((op.kind == OP_RES || op.kind == OP_ATTN || op.kind == OP_OUT) && op.in >= 0) {
+            c->tens[op.in].cons_op = (int)i; c->tens[op.in].cons_norm = 1;
+        }
+        if (op.kind == OP_ATTN && op.has_x) { c->tens[op.xmid].cons_op = (int)i; c->tens[op.xmid].cons_norm = 2; }
+    }
     declare_all(c);
     const size_t MB = (size_t)cfg->max_batch;
     {   // 64-float guard bands: the vector halo loads of the convs may touch 1 float before / 3 after a tensor
@@ -1730,6 +1892,20 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
     }
     if (dalloc(c, &c->statsP, MB * c->stats_per_sample) || dalloc(c, &c->statsT, MB * c->stats_per_sample)) return -1;
     if (dalloc(c, &c->red, RED_BYTES) || dalloc(c, &c->red2, RED_BYTES)) return -1;
+    {   // row partials of the epilogue statistics: [B][C][pixel tiles >= HW / 64][2] of the largest tensor
+        long big = 0;
+        for (const Tens& t : c->tens) big = std::max(big, (long)t.C * t.H * t.W);
+        c->stpart_floats = MB * (size_t)(big / 64 + 1) * 2;
+        if (dalloc(c, &c->stpart, c->stpart_floats) || dalloc(c, &c->stpart2, c->stpart_floats)) return -1;
+        const char* e = getenv("LOCO_FUSE_STATS");
+        c->fuse_stats = !(e && atoi(e) == 0);
+        const char* fa = getenv("LOCO_FLASH_ATTN");
+        c->flash_attn = !(fa && atoi(fa) == 0);
+        long dmax = 1;
+        for (const Op& op : c->ops)
+            if (op.kind == OP_ATTN) dmax = std::max(dmax, (long)op.heads * c->tens[op.in].H * c->tens[op.in].W);
+        if (dalloc(c, &c->attn_delta, MB * (size_t)dmax)) return -1;
+    }
     c->partial_floats = (size_t)64 << 20;   // 256 MB split-K workspace
     if (dalloc(c, &c->partial, c->partial_floats)) return -1;
     if (dalloc(c, &c->xin_buf, MB * c->n_in) || dalloc(c, &c->t_dev, 4)) return -1;

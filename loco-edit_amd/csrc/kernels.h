@@ -16,6 +16,14 @@ enum ConvMode : int {
     CM_COT_SILU = 4,  // a = rstd*(gamma*silu'(y)*d - m1 - xh*m2)    (cotangent of norm->swish, fused into next dgrad)
 };
 
+// GroupNorm statistics of a conv's OUTPUT tensor for the norm that consumes it (engine.hip StatReq):
+//   ST_FWD: mean / rstd -> mr, sc, sh           ST_TAN: m1 = mean(d), m2 = mean(xhat d) -> tst, tc
+//   ST_COT: the same means of z = gamma silu'(y) d (cotangent through norm -> SiLU)
+// Split-K convs take them in their split-K epilogue (launch_conv_splitk_reduce_stats: one kernel instead of reduce +
+// statistics); un-split low-precision convs with whole cout tiles take the FORWARD ones in the conv epilogue as {mean, M2}
+// per (cout row, pixel tile) in ConvArgs::st_part, merged by launch_gn_fused_finalize.
+enum StatKind : int { ST_NONE = 0, ST_FWD = 1, ST_TAN = 2, ST_COT = 3 };
+
 struct ConvArgs {
     // input activation (or tangent / cotangent) tensor
     const float* in; long in_bs; int Cin, Hin, Win;
@@ -50,6 +58,8 @@ struct ConvArgs {
     int nsplit;      // split-K factor (>1: raw partials go to `partial`, epilogue by conv_splitk_reduce)
     float* partial;
     int B;
+    // forward-statistics sink (st_kind == ST_FWD): {mean, M2} per (cout row, pixel tile), [B][Cout][pixel tiles][2]
+    float* st_part; int st_kind;
 };
 
 // the conv kernel only; when a.nsplit > 1 the caller follows with launch_conv_splitk_reduce (run_conv does)
@@ -57,6 +67,9 @@ void launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st);
 void launch_conv_f16(const ConvArgs& a, int taps, hipStream_t st);     // a.wb = the f16 weight records
 void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st);
+// can a launch with these arguments feed a.st_part from its epilogue?  (whole cout tiles of the chosen variant, no split-K)
+bool conv_lowp_can_fuse_stats(const ConvArgs& a);
+int conv_bf16_tile_couts(const ConvArgs& a);
 int conv_pick_tile(int Cout, int HW);
 extern int g_bf16_tile_override;
 void launch_fill_random(float* p, long count, unsigned seed, float scale, hipStream_t st);
@@ -93,6 +106,24 @@ void launch_gemm(const GemmArgs& g, hipStream_t st);              // exact fp32 
 void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t st);       // split-bf16 operands on the bf16 matrix pipe
 bool gemm_prefers_bf16x3(const GemmArgs& g);                      // long contraction, matrix-rate bound on the f32 MFMA
 
+// ---- tangent / cotangent of multi-head self-attention without per-probe [T x T] matrices (attn_flash.hip) ----
+// All tensors [channel][token] with the engine's strides; q / k / v (and their tangents / cotangents) of head h start
+// hs floats apart, o (and do / g_o) CH * T floats apart.  Primal q, k, v, P = softmax(scale q^T k) [NH][T][T], o = v P^T: B = 1.
+struct AttnFlashArgs {
+    int T, NH, B; float scale;
+    const float *q, *k, *v; long hs;
+    const float* P;
+    const float* o;
+    const float *dq, *dk, *dv; long bs_d;     // tangent inputs per probe
+    float* out; long bs_out;                  // tangent result do per probe
+    const float* go; long bs_go;              // cotangent input g_o per probe
+    float *gq, *gk, *gv; long bs_g;           // cotangent results per probe
+    float* delta;                             // scratch [B][NH][T]: delta_i = <g_o_i, o_i>
+};
+bool attn_flash_supported(int T, int CH);     // heads of 64 channels, token counts that are multiples of 128
+void launch_attn_flash_tangent(const AttnFlashArgs& a, hipStream_t st);
+void launch_attn_flash_cotangent(const AttnFlashArgs& a, hipStream_t st);
+
 // ---- GroupNorm statistics -------------------------------------------------
 // x: [B][C][HW] with batch stride bs; groups of cpg channels (contiguous cpg*HW floats)
 // writes mr[b][g] = {mean, rstd}, sc[b][c] = gamma*rstd, sh[b][c] = beta - mean*rstd*gamma
@@ -100,6 +131,17 @@ void launch_gn_stats(const float* x, long bs, int B, int C, int HW, int G, float
                      const float* gamma, const float* beta,
                      float* mr, float* sc, float* sh, long stats_bs, double* scratch, hipStream_t st,
                      const float* ss_scale = nullptr, const float* ss_shift = nullptr);
+// row-tile partials of a conv epilogue (ConvArgs::st_part, [B][C][ntile]{mean, M2}) -> the arrays of launch_gn_stats
+void launch_gn_fused_finalize(const float* part, int ntile, int B, int C, int HW, int G, float eps, const float* gamma,
+                              const float* beta, float* mr, float* sc, float* sh, long stats_bs, const float* ss_scale,
+                              const float* ss_shift, hipStream_t st);
+// split-K epilogue (sum of the K-slabs + bias / bias2 / residual / accumulate, as launch_conv_splitk_reduce) that also takes
+// the statistics of the finished tensor and finalises them: replaces the reduce AND the statistics launch behind a split-K conv
+void launch_conv_splitk_reduce_stats(const ConvArgs& a, int kind, int G, float eps, const float* gamma, const float* beta,
+                                     float* mr, float* sc, float* sh, long stats_bs, const float* ss_scale,
+                                     const float* ss_shift, const float* prim, const float* sc_prim, const float* sh_prim,
+                                     const float* mr_prim, float* tst, float* tc, long tst_bs, double* scratch,
+                                     hipStream_t st);
 // tangent / cotangent group statistics:
 //   kind 0 (tangent):            z = d
 //   kind 1 (cotangent, silu):    z = gamma * silu'(y) * d

@@ -6,6 +6,8 @@
 
 namespace loco {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -242,6 +244,223 @@ void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int 
     long BG = (long)B * G;
     hipLaunchKernelGGL(gn_tstats_finalize, dim3((unsigned)((BG + 255) / 256)), dim3(256), 0, st, scratch, ns, BG,
                        G, 1.0 / (double)len, tst, tc, tst_bs, cpg, mr, pbs_g, kind);
+}
+
+// ---------------------------------------------------------------------------
+// Forward statistics taken in a conv epilogue (ConvArgs::st_part): part[b][c][tile] = {mean, M2} of equally sized row
+// tiles.  One wave per (b, g) merges the cpg x ntile entries of its group in double (mean = average of the means,
+// M2 = sum M2 + n_t sum (mean_t - mean)^2) and writes what gn_finalize_kernel writes.
+__global__ __launch_bounds__(64) void gn_fused_finalize_kernel(const float* part, int ntile, int C, int G, double inv_n,
+                                                               float eps, const float* gamma, const float* beta,
+                                                               float* mr, float* sc, float* sh, long sbs,
+                                                               const float* ss_scale, const float* ss_shift) {
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / G;
+    const float2* p = reinterpret_cast<const float2*>(part) + ((long)b * C + (long)g * cpg) * ntile;
+    const int cnt = cpg * ntile;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += 64) {
+        float2 v = p[i];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    s1 = __shfl(wave_sum(s1), 0, 64);
+    s2 = __shfl(wave_sum(s2), 0, 64);
+    const double mean = s1 / (double)cnt, n_t = 1.0 / (inv_n * (double)cnt);
+    double dev = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += 64) {
+        const double d = (double)p[i].x - mean;
+        dev += d * d;
+    }
+    dev = __shfl(wave_sum(dev), 0, 64);
+    double var = (s2 + n_t * dev) * inv_n;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        mr[(long)b * sbs + g * 2] = meanf;
+        mr[(long)b * sbs + g * 2 + 1] = rstd;
+    }
+    for (int k = threadIdx.x; k < cpg; k += 64) {
+        const int c = g * cpg + k;
+        const float gm = gamma[c];
+        float a = gm * rstd, o = beta[c] - meanf * rstd * gm;
+        if (ss_scale) {
+            const float f = 1.0f + ss_scale[c];
+            a *= f;
+            o = o * f + ss_shift[c];
+        }
+        sc[(long)b * sbs + c] = a;
+        sh[(long)b * sbs + c] = o;
+    }
+}
+
+void launch_gn_fused_finalize(const float* part, int ntile, int B, int C, int HW, int G, float eps, const float* gamma,
+                              const float* beta, float* mr, float* sc, float* sh, long stats_bs, const float* ss_scale,
+                              const float* ss_shift, hipStream_t st) {
+    const double inv_n = 1.0 / ((double)(C / G) * HW);
+    hipLaunchKernelGGL(gn_fused_finalize_kernel, dim3(G, B), dim3(64), 0, st, part, ntile, C, G, inv_n, eps, gamma, beta, mr,
+                       sc, sh, stats_bs, ss_scale, ss_shift);
+}
+
+// ---------------------------------------------------------------------------
+// Split-K epilogue + statistics.  grid = (ns, G, B): a block sums the K-slabs of its slice of one (sample, group), applies
+// bias / bias2 / residual / accumulate, writes the tensor and takes the statistics of what it wrote.  One slice (the small
+// tensors split-K exists for): finalised here; several: slice sums to `scratch`, finalised by the kernels the standalone
+// statistics use (gn_finalize_kernel from {n, mean, M2}, gn_tstats_finalize from {sum z, sum xhat z}).
+template <int KIND>
+__global__ __launch_bounds__(1024) void splitk_reduce_stats_kernel(ConvArgs a, int G, float eps, const float* gamma,
+                                                                  const float* beta, float* mr, float* sc, float* sh, long sbs,
+                                                                  const float* ss_scale, const float* ss_shift,
+                                                                  const float* prim, const float* sc_p, const float* sh_p,
+                                                                  const float* mr_p, float* tst, float* tc, long tbs,
+                                                                  double* scratch) {
+    __shared__ double sm[16];
+    const int s = blockIdx.x, nsl = gridDim.x, g = blockIdx.y, b = blockIdx.z;
+    const int HW = a.Hout * a.Wout, cpg = a.Cout / G;
+    const long step = (long)blockDim.x * 4;
+    const long len = (long)cpg * HW, per_b = (long)a.Cout * HW, total = per_b * a.B;
+    const long base = (long)g * len;                                    // offset of the group inside one sample
+    long per = ((len / 4 + nsl - 1) / nsl) * 4;
+    long beg = (long)s * per, end = beg + per < len ? beg + per : len;
+    if (beg > end) beg = end;
+    float mean_p = 0.f, rstd_p = 1.f;
+    if (KIND != ST_FWD) { mean_p = mr_p[2 * g]; rstd_p = mr_p[2 * g + 1]; }
+    double t1 = 0.0, t2 = 0.0;
+    for (long i = beg + threadIdx.x * 4; i < end; i += step) {
+        const long e = base + i;                                        // element inside the sample
+        const int c = (int)(e / HW);
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        const float* pp = a.partial + (long)b * per_b + e;
+        int k = 0;
+        for (; k + 4 <= a.nsplit; k += 4) {                             // four slab loads in flight per step
+            const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(pp + (long)k * total);
+            const f32x4_t p1 = *reinterpret_cast<const f32x4_t*>(pp + (long)(k + 1) * total);
+            const f32x4_t p2 = *reinterpret_cast<const f32x4_t*>(pp + (long)(k + 2) * total);
+            const f32x4_t p3 = *reinterpret_cast<const f32x4_t*>(pp + (long)(k + 3) * total);
+            v += (p0 + p1) + (p2 + p3);
+        }
+        for (; k < a.nsplit; ++k) v += *reinterpret_cast<const f32x4_t*>(pp + (long)k * total);
+        float add = 0.f;
+        if (a.bias) add += a.bias[c];
+        if (a.bias2) add += a.bias2[(long)b * a.bias2_bs + c];
+        v += add;
+        if (a.res) v += *reinterpret_cast<const f32x4_t*>(a.res + (long)b * a.res_bs + e);
+        float* o = a.out + (long)b * a.out_bs + e;
+        if (a.accumulate) v += *reinterpret_cast<const f32x4_t*>(o);
+        *reinterpret_cast<f32x4_t*>(o) = v;
+        float a1, a2;
+        if (KIND == ST_FWD) {
+            a1 = (v[0] + v[1]) + (v[2] + v[3]);
+            a2 = 0.f;                                  // M2 in a second pass about the slice mean (below)
+        } else {
+            const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(prim + e);
+            const float scc = sc_p[c], shc = sh_p[c];
+            a1 = 0.f; a2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[j] - mean_p) * rstd_p;
+                float z = v[j];
+                if (KIND == ST_COT) z *= (scc / rstd_p) * dsilu(fmaf(scc, xv[j], shc));
+                a1 += z;
+                a2 += xh * z;
+            }
+        }
+        t1 += (double)a1;
+        t2 += (double)a2;
+    }
+    t1 = block_sum(t1, sm);
+    if (KIND == ST_FWD) {
+        // two-pass variance as the standalone kernel: the slice was just written by these same threads, read it back
+        const double n = (double)(end - beg);
+        const float mu = n > 0 ? (float)(t1 / n) : 0.f;
+        double m2 = 0.0;
+        for (long i = beg + threadIdx.x * 4; i < end; i += step) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(a.out + (long)b * a.out_bs + base + i);
+            const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
+            m2 += (double)((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        }
+        const double dm = (n > 0 ? t1 / n : 0.0) - (double)mu;
+        t2 = block_sum(m2, sm) - n * dm * dm;          // M2 about the exact slice mean
+    } else {
+        t2 = block_sum(t2, sm);
+    }
+    if (nsl > 1) {
+        if (threadIdx.x == 0) {
+            if (KIND == ST_FWD) {            // {n, mean, M2} of the slice for gn_finalize_kernel's Chan merge
+                double* o = scratch + (((long)b * G + g) * nsl + s) * 3;
+                const double n = (double)(end - beg), mu = n > 0 ? t1 / n : 0.0;
+                o[0] = n; o[1] = mu; o[2] = t2;
+            } else {
+                double* o = scratch + (((long)b * G + g) * nsl + s) * 2;
+                o[0] = t1; o[1] = t2;
+            }
+        }
+        return;
+    }
+    const double inv_n = 1.0 / (double)len;
+    if (KIND == ST_FWD) {
+        const double mean = t1 * inv_n;
+        double var = t2 * inv_n;
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (threadIdx.x == 0) {
+            mr[(long)b * sbs + g * 2] = meanf;
+            mr[(long)b * sbs + g * 2 + 1] = rstd;
+        }
+        if (threadIdx.x < cpg) {
+            const int c = g * cpg + threadIdx.x;
+            const float gm = gamma[c];
+            float aa = gm * rstd, oo = beta[c] - meanf * rstd * gm;
+            if (ss_scale) {
+                const float f = 1.0f + ss_scale[c];
+                aa *= f;
+                oo = oo * f + ss_shift[c];
+            }
+            sc[(long)b * sbs + c] = aa;
+            sh[(long)b * sbs + c] = oo;
+        }
+    } else {
+        const float m1 = (float)(t1 * inv_n), m2 = (float)(t2 * inv_n);
+        if (threadIdx.x == 0) {
+            tst[(long)b * tbs + 2 * g] = m1;
+            tst[(long)b * tbs + 2 * g + 1] = m2;
+        }
+        if (tc && threadIdx.x < cpg) {
+            const float f = KIND == ST_TAN ? 1.0f : rstd_p;
+            float* t = tc + (long)b * tbs + 2 * ((long)g * cpg + threadIdx.x);
+            t[0] = f * m1;
+            t[1] = f * m2;
+        }
+    }
+}
+
+void launch_conv_splitk_reduce_stats(const ConvArgs& a, int kind, int G, float eps, const float* gamma, const float* beta,
+                                     float* mr, float* sc, float* sh, long stats_bs, const float* ss_scale,
+                                     const float* ss_shift, const float* prim, const float* sc_prim, const float* sh_prim,
+                                     const float* mr_prim, float* tst, float* tc, long tst_bs, double* scratch,
+                                     hipStream_t st) {
+    const int HW = a.Hout * a.Wout, cpg = a.Cout / G;
+    const long len = (long)cpg * HW;
+    const int ns = gn_nsplit(len, a.B * G);
+    dim3 grid(ns, G, a.B);
+    // threads: one 16-byte piece each where the slice is small (the 8x8 .. 32x32 tensors split-K exists for), 1024 at most
+    long pieces = (len / ns + 3) / 4;
+    int nthr = (int)((pieces + 63) / 64) * 64;
+    if (nthr < 64) nthr = 64;
+    if (nthr > 1024) nthr = 1024;
+    if (nthr < cpg) nthr = ((cpg + 63) / 64) * 64;
+#define RS(K) hipLaunchKernelGGL(splitk_reduce_stats_kernel<K>, grid, dim3(nthr), 0, st, a, G, eps, gamma, beta, mr, sc, sh, \
+                                 stats_bs, ss_scale, ss_shift, prim, sc_prim, sh_prim, mr_prim, tst, tc, tst_bs, scratch)
+    if (kind == ST_FWD) RS(ST_FWD); else if (kind == ST_TAN) RS(ST_TAN); else RS(ST_COT);
+#undef RS
+    if (ns == 1) return;
+    if (kind == ST_FWD) {
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 63) / 64, a.B), dim3(64), 0, st, scratch, ns, G, a.Cout, eps, gamma,
+                           beta, mr, sc, sh, stats_bs, ss_scale, ss_shift);
+    } else {
+        const long BG = (long)a.B * G;
+        hipLaunchKernelGGL(gn_tstats_finalize, dim3((unsigned)((BG + 255) / 256)), dim3(256), 0, st, scratch, ns, BG, G,
+                           1.0 / (double)len, tst, tc, tst_bs, cpg, mr_prim, 0L, kind == ST_TAN ? 0 : 1);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -349,7 +349,7 @@ def test_text_cross_attention_stages_vs_restatement(prec):
     A = eng.pmp_vjp(Uc.to(DEV))
     assert rel(A, Aref) < 5 * tol
     lhs, rhs = (U.double().cpu() * Uc.double()).sum(), (V.double() * A.double().cpu()).sum()
-    assert abs(lhs - rhs) / abs(lhs) < 1e-4
+    assert abs(lhs - rhs) / abs(lhs) < (1e-4 if prec == "f32" else 5e-4)    # each product is good to TOL[prec] of its norm
     e1 = eng.unet_forward(z.to(DEV), float(t))
     eng.set_context((0.5 * ctx).to(DEV).contiguous())
     with pytest.raises(RuntimeError):

@@ -790,6 +790,101 @@ def test_config2_null_space_solve_and_projection_at_size(prec, engines, golden):
     assert torch.isfinite(x).all() and (x[0] - x[4]).abs().max().item() > 1e-3
 
 
+def _fused_cfgs():
+    from loco_edit_amd.config import TINY_ADM_XATTN, TINY_DECODER, TINY_LATENT_XATTN
+    return [TINY_DDPM, MID_DDPM, TINY_ADM, CELEBA_DDPM, TINY_ADM_XATTN, TINY_LATENT_XATTN, TINY_DECODER]
+
+
+@pytest.mark.parametrize("cfg", _fused_cfgs(), ids=["tiny", "mid", "tiny_adm", "celeba256", "tiny_adm_xattn", "tiny_latent_xattn",
+                                                    "tiny_decoder"])
+def test_statistics_fused_into_epilogues_equal_the_standalone_kernels(cfg, monkeypatch):
+    """The GroupNorm statistics a conv's consumer needs (forward mean / rstd, tangent and cotangent group means) are taken
+    in the split-K epilogue (one kernel instead of reduce + statistics) or, the forward ones of un-split convs, in the
+    conv epilogue (engine.hip run_conv / StatReq); LOCO_FUSE_STATS=0 runs every one of them as its own kernels.  Same
+    engine arithmetic either way, different summation order; a batch of 1 (DDIM chain shapes: split-K nearly everywhere)
+    and of 5 (tail-probe split), both low-precision arithmetics."""
+    from loco_edit_amd.hip import LocoEngine
+    s_ = _sched()
+    t = float(s_.timesteps[40]); at = float(s_.alpha_at(s_.timesteps[40]))
+    gen = torch.Generator().manual_seed(3)
+    R, Ro = cfg.resolution, cfg.out_resolution
+    xs = torch.randn(5, cfg.in_channels, R, R, generator=gen).to(DEV)
+    mask = torch.zeros(cfg.out_ch, Ro, Ro, dtype=torch.bool); mask[:, Ro // 3:Ro // 2, Ro // 4:Ro // 2] = True
+    V = torch.randn(5, cfg.n, generator=gen).to(DEV)
+    ctx = torch.randn(cfg.context_len, cfg.context_dim, generator=gen).to(DEV) if cfg.context_dim else None
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LOCO_FUSE_STATS", mode)
+        eng = LocoEngine(cfg, max_batch=8, device=torch.device(DEV))
+        eng.load_state_dict(synth_params(cfg, 0))
+        if ctx is not None:
+            eng.set_context(ctx)
+        res = []
+        for prec in ("bf16x3", "f16"):
+            eng.set_precision(prec)
+            res.append(eng.unet_forward(xs[:1].contiguous(), t))
+            res.append(eng.unet_forward(xs, t))
+            eng.pmp_primal(xs[:1].contiguous(), t, at, mask.to(DEV), use_et=(cfg.arch == "dec"))
+            U = eng.pmp_jvp(V)
+            res.append(U)
+            res.append(eng.pmp_vjp(U))
+            U1 = eng.pmp_jvp(V[:1].contiguous())
+            res.append(U1)
+            res.append(eng.pmp_vjp(U1))
+        out[mode] = [r.cpu() for r in res]
+        del eng
+        torch.cuda.empty_cache()
+    # a different summation order perturbs the statistics in their last bits; that flips a fraction of the operand
+    # roundings downstream, so the outputs differ by a fraction of the arithmetic's own distance to fp32 (bf16x3: 1.5e-5,
+    # f16: ~1e-3), not by fp32 rounding
+    errs = [rel(a, b) for a, b in zip(out["1"], out["0"])]
+    print("fused vs standalone statistics, rel-L2 per output:", [f"{e:.1e}" for e in errs])
+    assert all(bool(torch.isfinite(a).all()) for a in out["1"])
+    assert max(errs[:6]) < 3e-5 and max(errs[6:]) < 3e-3, errs
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f16"])
+def test_flash_attention_tangent_and_cotangent(prec, monkeypatch):
+    """The tangent and cotangent of the multi-head attention blocks without per-probe [T x T] matrices (attn_flash.hip:
+    64-channel heads, 1024 and 256 tokens here) against (1) autodiff of the CPU restatement of the reference network
+    (guided_diffusion/unet.py:330-356 under jvp / grad) and (2) the generic GEMM + softmax-Jacobian path of the same engine
+    (LOCO_FLASH_ATTN=0); adjointness of the pair."""
+    from loco_edit_amd.config import FLASH_ADM as cfg
+    from loco_edit_amd.hip import LocoEngine
+    params = synth_params(cfg, 0)
+    p = orc.to_torch(params)
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(1, 3, 32, 32, generator=gen)
+    t = torch.tensor(603.0)
+    V = torch.randn(3, cfg.n, generator=gen)
+    Uc = torch.randn(3, cfg.n, generator=gen)
+    f = lambda x_: orc.unet_forward_adm(p, cfg, x_, t)
+    JV = torch.stack([torch.func.jvp(f, (x,), (v.view_as(x),))[1].reshape(-1) for v in V])
+    xx = x.clone().requires_grad_(True)
+    out = f(xx).reshape(-1)
+    Aref = torch.stack([torch.autograd.grad((out * u).sum(), xx, retain_graph=True)[0].reshape(-1) for u in Uc])
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LOCO_FLASH_ATTN", mode)
+        eng = LocoEngine(cfg, max_batch=4, device=torch.device(DEV))
+        eng.load_state_dict(params)
+        eng.set_precision(prec)
+        eng.pmp_primal(x.to(DEV), float(t), 0.5, None, use_et=True)
+        U = eng.pmp_jvp(V.to(DEV))
+        A = eng.pmp_vjp(Uc.to(DEV))
+        res[mode] = (U.cpu(), A.cpu())
+        del eng
+    tol = 5e-4 if prec == "bf16x3" else 2e-2
+    e = [rel(res["1"][0], JV), rel(res["1"][1], Aref), rel(res["1"][0], res["0"][0]), rel(res["1"][1], res["0"][1]),
+         rel(res["0"][0], JV), rel(res["0"][1], Aref)]
+    print(f"[{prec}] flash J V / J^T U vs autodiff {e[0]:.1e} / {e[1]:.1e}; vs generic path {e[2]:.1e} / {e[3]:.1e}; "
+          f"generic vs autodiff {e[4]:.1e} / {e[5]:.1e}")
+    assert e[0] < tol and e[1] < tol
+    assert e[0] < 2 * e[4] + 1e-5 and e[1] < 2 * e[5] + 1e-5         # no worse than the path it replaces
+    lhs, rhs = (res["1"][0].double() * Uc.double()).sum(), (V.double() * res["1"][1].double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < tol
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """The boundary is a C ABI, not a Python extension: tests/c/loco_abi_smoke.c (C11, no torch, no C++) is compiled
     against include/loco_hip.h + libloco_hip.so, creates a context, loads the parameters from host memory, and runs
