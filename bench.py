@@ -461,10 +461,17 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and a.workload == "celeba_top5":
             try:
+                import hashlib
+                from loco_edit_amd.hip import library_path
                 tj = json.load(open(tpath))
-                traffic = tj.get(name)
-                traffic_src = tj.get("_source", "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                                "command, stored (not re-measured by this run)")
+                sha = hashlib.sha256(open(library_path(), "rb").read()).hexdigest()
+                if tj.get("_lib_sha256") == sha:
+                    traffic = tj.get(name)
+                    traffic_src = tj.get("_source", "") + (" -- stored by profiles/collect.sh for exactly this library build "
+                                                            "(sha256 match), not re-measured by this run")
+                else:
+                    traffic_src = ("profiles/traffic.json was measured on another build of libloco_hip.so (sha256 mismatch): not "
+                                   "reported; re-run profiles/collect.sh")
             except Exception:
                 traffic = None
         executed = w.get("branches", 1) * (1 + 2 * k_local * N_ITER) * F      # the primal runs once per solve and branch
@@ -517,6 +524,15 @@ def main():
                                                 "ms_per_step": round(el * 1e3, 3), "dtype": DTYPE_NOTE[prec],
                                                 "parity": parity_vs_fixture(s2, vT2, "celeba256")}
             eng.set_precision(a.precision)
+            # the same solve with the probe groups of a pass on two HIP streams (loco_set_streams): statistics / apply kernels
+            # of one group beside the convolutions of the other.  An extra line, not the headline: kernels that overlap
+            # have no per-kernel duration, so the roofline above is taken on one stream
+            eng.set_streams(2)
+            el, (_, s2, vT2, _) = timed(w["step"], 2, 1)
+            eng.set_streams(1)
+            extra["celeba_top5_two_streams"] = {"value": round(keep / (el / 2), 4), "unit": "edit-directions/s",
+                                                "ms_per_step": round(el / 2 * 1e3, 3), "dtype": DTYPE_NOTE[a.precision],
+                                                "parity": parity_vs_fixture(s2, vT2, "celeba256")}
         # BASELINE config 5 next to the headline: T-LOCO null-space basis on the IF-shaped stand-in, 2 CFG branches
         w3 = make_workload("tloco_if64", a.precision)
         el, (_, s5, vT5, _) = timed(w3["step"], 1, 1)

@@ -169,6 +169,12 @@ int  loco_timer_stop(loco_ctx* ctx, void* stream, float* ms);
  * fp32 tensors in HBM).  Env LOCO_PRECISION=f32|bf16x3|f16 sets the initial mode.
  * Invalidates the cached primal. */
 int  loco_set_precision(loco_ctx* ctx, int32_t mode);
+/* Probe groups of one tangent / cotangent pass on n = 1 (default) or 2 HIP streams: the probes of a batch are independent,
+ * so with n = 2 a batch of >= 4 is cut in two groups enqueued on two streams (the bandwidth-bound statistics / apply
+ * kernels of one group run beside the convolutions of the other; results identical).  Env LOCO_STREAMS sets the initial
+ * value.  Per-kernel durations measured while two streams overlap are not kernel properties: bench.py keeps n = 1 for
+ * the headline and its roofline, and reports n = 2 as an extra line. */
+int  loco_set_streams(loco_ctx* ctx, int32_t n);
 int  loco_get_precision(loco_ctx* ctx);
 
 /* Conditional denoisers (T-LOCO, reference edit.py:1286-1373 `self.unet(x, t, encoder_hidden_states=...)`): a

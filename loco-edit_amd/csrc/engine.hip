@@ -2416,6 +2416,12 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
 
 #endif
 
+int loco_set_streams(loco_ctx* c, int32_t n) {
+    if (!c || (n != 1 && n != 2)) return -2;
+    c->n_streams = n;
+    return 0;
+}
+
 int loco_profile_enable(loco_ctx* c, int32_t on) {
     if (!c) return -2;
     c->prof_on = on != 0;

@@ -29,7 +29,7 @@ SYMBOLS = [
     "loco_pmp_primal", "loco_pmp_set_second_mask", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop",
-    "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision",
+    "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision", "loco_set_streams",
     "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby",
 ]
 
@@ -92,6 +92,7 @@ def load_library():
     lib.loco_timer_stop.argtypes = [vp, vp, C.POINTER(f32)]
     lib.loco_set_precision.argtypes = [vp, i32]
     lib.loco_get_precision.argtypes = [vp]
+    lib.loco_set_streams.argtypes = [vp, i32]
     lib.loco_set_cond.argtypes = [vp, vp, vp]
     lib.loco_set_context.argtypes = [vp, vp, vp]
     lib.loco_masked_axpby.argtypes = [vp, vp, vp, f32, f32, i32, vp, vp]
@@ -367,6 +368,10 @@ class LocoEngine:
         """'f32' = exact fp32 MFMA (parity anchor); 'bf16x3' = split-bf16 MFMA (fp32-faithful to ~2^-16);
         'f16' = one f16 MFMA per product (11-bit operands, fp32 accumulate)."""
         self._check(self.lib.loco_set_precision(self._ctx, self.PRECISIONS[mode]), "loco_set_precision")
+
+    def set_streams(self, n: int):
+        """Probe groups of a tangent / cotangent pass on 1 (default) or 2 HIP streams (identical results)."""
+        self._check(self.lib.loco_set_streams(self._ctx, int(n)), "loco_set_streams")
 
     def get_precision(self) -> str:
         m = self.lib.loco_get_precision(self._ctx)

@@ -7,9 +7,12 @@ LDS-DMA, so their FETCH bytes are DOUBLED; the per-pixel variants (7th parameter
 dword loads, for which the raw counter matched the analytical byte count within 3 % in round 1 (DESIGN.md
 section 4) and is left as is.  WRITE_SIZE is exact for these stores.
 
-    python profiles/make_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write r01
+The result carries the sha256 of the libloco_hip.so it was measured on (`_lib_sha256`): bench.py only reports
+`roofline.traffic` from a traffic.json whose hash matches the library it is running (a stale file yields null).
+
+    python profiles/make_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write r03 [output dir, default profiles/]
 """
-import collections, csv, glob, json, os, re, sys
+import collections, csv, glob, hashlib, json, os, re, sys
 
 def load(d, cn):
     f = (glob.glob(os.path.join(d, "*counter_collection.csv")) + glob.glob(os.path.join(d, "*", "*counter_collection.csv")))[0]
@@ -27,6 +30,7 @@ def norm(name):
     return f"{m.group(1)}<{','.join(m.group(2).replace(' ', '').split(',')[:6])}>"
 
 fd, wd, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+outdir = sys.argv[4] if len(sys.argv) > 4 else os.path.dirname(os.path.abspath(__file__))
 F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 out, rows = {}, []
 def fetch_corr(name):
@@ -46,8 +50,14 @@ for k in F:
             o["launches"] = tot
         else:
             out[n] = {"bytes": f + w, "launches": len(F[k])}
-here = os.path.dirname(os.path.abspath(__file__))
-json.dump({k: round(v["bytes"]) for k, v in out.items()}, open(os.path.join(here, "traffic.json"), "w"), indent=1)
+here = outdir
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "loco-edit_amd", "libloco_hip.so")
+res = {k: round(v["bytes"]) for k, v in out.items()}
+res["_lib_sha256"] = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+res["_source"] = (f"profiles/{tag}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of `bench.py --steps 1 "
+                  "--warmup 0`, mean bytes per launch of each conv variant; FETCH doubled for the variants that stream with "
+                  "16-byte loads / LDS-DMA (gfx950 counts those at half), WRITE exact for 16-byte streaming stores")
+json.dump(res, open(os.path.join(here, "traffic.json"), "w"), indent=1)
 with open(os.path.join(here, f"{tag}_pmc_traffic_per_kernel.csv"), "w") as fh:
     fh.write("kernel,launches,fetch_bytes_per_launch_corrected,write_bytes_per_launch\n")
     for k, n, f, w in sorted(rows, key=lambda r: -r[1] * (r[2] + r[3])):
