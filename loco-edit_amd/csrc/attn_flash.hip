@@ -50,31 +50,50 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
-// token-major records of X[c][t] (row stride T): tokens t0 .. t0+ntok-1, 64 channels -> dst[(chunk16 * ntok + tok) * RP]
+// token-major records of X[c][t] (row stride T): tokens t0 .. t0+ntok-1, 64 channels -> dst[(chunk16 * ntok + tok) * RP].
+// Load and store halves are separate so the streamed block t+1 is in flight (registers) while block t multiplies.
+template <int NTOK> struct TokRegs { float v[(NTOK * 8) / 256][8]; };
 template <int NTOK>
-__device__ __forceinline__ void stage_tokens(const float* X, int T, int t0, unsigned char* dst, int tid) {
+__device__ __forceinline__ void load_tokens(TokRegs<NTOK>& R, const float* X, int T, int t0, int tid) {
 #pragma unroll
     for (int it = 0; it < (NTOK * 8) / 256; ++it) {
         const int e = tid + it * 256;
         const int tok = e % NTOK, oct = e / NTOK;              // lanes run over tokens: coalesced 4-byte loads
-        float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = X[(long)(oct * 8 + k) * T + t0 + tok];
+        for (int k = 0; k < 8; ++k) R.v[it][k] = X[(long)(oct * 8 + k) * T + t0 + tok];
+    }
+}
+template <int NTOK>
+__device__ __forceinline__ void store_tokens(const TokRegs<NTOK>& R, unsigned char* dst, int tid) {
+#pragma unroll
+    for (int it = 0; it < (NTOK * 8) / 256; ++it) {
+        const int e = tid + it * 256;
+        const int tok = e % NTOK, oct = e / NTOK;
         uint4 hi, lo;
-        split8(v, hi, lo);
+        split8(R.v[it], hi, lo);
         unsigned char* r = dst + ((oct >> 1) * NTOK + tok) * RP + (oct & 1) * 16;
         *reinterpret_cast<uint4*>(r) = hi;
         *reinterpret_cast<uint4*>(r + 32) = lo;
     }
 }
+template <int NTOK>
+__device__ __forceinline__ void stage_tokens(const float* X, int T, int t0, unsigned char* dst, int tid) {
+    TokRegs<NTOK> R;
+    load_tokens<NTOK>(R, X, T, t0, tid);
+    store_tokens<NTOK>(R, dst, tid);
+}
 // channel-major records of X[c][t]: 64 channels x tokens t0 .. t0+63 in 4 blocks of 16, the 16 tokens of a record in the
 // D-fragment order j = (t&3) + 8(t>>2) + 4*khalf (slot = khalf*8 + t) -> dst[(jb * 64 + c) * RP]
-__device__ __forceinline__ void stage_channels(const float* X, int T, int t0, unsigned char* dst, int tid) {
+struct ChRegs { f32x4a a[4]; };
+__device__ __forceinline__ void load_channels(ChRegs& R, const float* X, int T, int t0, int tid) {
     const int c = tid >> 2, jb = tid & 3;                      // 4 lanes cover 64 consecutive floats of one row
     const f32x4a* p = reinterpret_cast<const f32x4a*>(X + (long)c * T + t0 + jb * 16);
-    const f32x4a a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];   // tokens 0-3, 4-7, 8-11, 12-15
-    const float k0[8] = {a0[0], a0[1], a0[2], a0[3], a2[0], a2[1], a2[2], a2[3]};   // khalf 0: 0-3, 8-11
-    const float k1[8] = {a1[0], a1[1], a1[2], a1[3], a3[0], a3[1], a3[2], a3[3]};   // khalf 1: 4-7, 12-15
+    R.a[0] = p[0]; R.a[1] = p[1]; R.a[2] = p[2]; R.a[3] = p[3];   // tokens 0-3, 4-7, 8-11, 12-15
+}
+__device__ __forceinline__ void store_channels(const ChRegs& R, unsigned char* dst, int tid) {
+    const int c = tid >> 2, jb = tid & 3;
+    const float k0[8] = {R.a[0][0], R.a[0][1], R.a[0][2], R.a[0][3], R.a[2][0], R.a[2][1], R.a[2][2], R.a[2][3]};   // khalf 0: 0-3, 8-11
+    const float k1[8] = {R.a[1][0], R.a[1][1], R.a[1][2], R.a[1][3], R.a[3][0], R.a[3][1], R.a[3][2], R.a[3][3]};   // khalf 1: 4-7, 12-15
     uint4 h0, l0, h1, l1;
     split8(k0, h0, l0);
     split8(k1, h1, l1);
@@ -115,7 +134,7 @@ __device__ __forceinline__ Frag frag_of(const f32x16& d, int b) {
 enum : int { M_TAN = 0, M_COTQ = 1, M_COTK = 2 };
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn_flash_kernel(AttnFlashArgs a) {
+__global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const RA = lds;                 // token-major operands of the streamed block (GEMM 1)
     unsigned char* const RB = lds + REGION;        // channel-major operands of the streamed block (GEMM 2)
@@ -162,22 +181,31 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(AttnFlashArgs a) {
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; if (MODE == M_COTK) acc2[i][r] = 0.f; }
     float rsum = 0.f;                               // TAN: r_i partial of this lane (its khalf's rows)
 
+    // streamed operands of a block: loaded into registers one block ahead, converted into LDS records at the top of the block
+    TokRegs<NBLK> ta, tb;
+    ChRegs ca, cb;
+    float dreg = 0.f;
+    auto fetch = [&](int t0) {
+        if (MODE == M_TAN) {
+            load_tokens<NBLK>(ta, k, T, t0, tid); load_tokens<NBLK>(tb, dk, T, t0, tid);
+            load_channels(ca, v, T, t0, tid); load_channels(cb, dv, T, t0, tid);
+        } else if (MODE == M_COTQ) {
+            load_tokens<NBLK>(ta, v, T, t0, tid);
+            load_channels(ca, k, T, t0, tid);
+        } else {
+            load_tokens<NBLK>(ta, go, T, t0, tid);
+            load_channels(ca, go, T, t0, tid); load_channels(cb, q, T, t0, tid);
+            if (tid < NBLK) dreg = a.delta[((long)b * a.NH + h) * T + t0 + tid];
+        }
+    };
+    fetch(0);
     for (int t0 = 0; t0 < T; t0 += NBLK) {
         __syncthreads();                            // the previous block's fragment reads (and the prologue's) are done
-        if (MODE == M_TAN) {
-            stage_tokens<NBLK>(k, T, t0, RA, tid);
-            stage_tokens<NBLK>(dk + 0, T, t0, RA + 4 * NBLK * RP, tid);
-            stage_channels(v, T, t0, RB, tid);
-            stage_channels(dv, T, t0, RB + 4 * NBLK * RP, tid);
-        } else if (MODE == M_COTQ) {
-            stage_tokens<NBLK>(v, T, t0, RA, tid);
-            stage_channels(k, T, t0, RB, tid);
-        } else {
-            stage_tokens<NBLK>(go, T, t0, RA, tid);
-            stage_channels(go, T, t0, RB, tid);
-            stage_channels(q, T, t0, RB + 4 * NBLK * RP, tid);
-            if (tid < NBLK) DL[tid] = a.delta[((long)b * a.NH + h) * T + t0 + tid];
-        }
+        store_tokens<NBLK>(ta, RA, tid);
+        store_channels(ca, RB, tid);
+        if (MODE == M_TAN) { store_tokens<NBLK>(tb, RA + 4 * NBLK * RP, tid); store_channels(cb, RB + 4 * NBLK * RP, tid); }
+        if (MODE == M_COTK) { store_channels(cb, RB + 4 * NBLK * RP, tid); if (tid < NBLK) DL[tid] = dreg; }
+        if (t0 + NBLK < T) fetch(t0 + NBLK);        // in flight under this block's MFMAs
         // primal probabilities of the tile in the D-fragment layout (rows = streamed tokens, column = own token)
         f32x16 pt[2];
 #pragma unroll
