@@ -60,6 +60,21 @@ typedef struct loco_unet_cfg {
      * edit.py:636-674 / 1286-1373; the reference's cross-attention lives in un-vendored diffusers blocks) */
     int32_t context_dim;
     int32_t context_len;
+    /* arch 1 variants of the same guided-diffusion skeleton (unet.py constructor switches).  The latent-diffusion /
+     * Stable Diffusion v1 denoiser is arch 1 with scale_shift_norm = 0, resblock_updown = 0, num_heads = 8,
+     * transformer_depth = 1, context_dim = 768 (859 520 964 parameters at 320 x (1,2,4,4)):
+     *   scale_shift_norm  1: GN(h) * (1 + scale) + shift (unet.py:250-254, P2)   0: GN(h + emb_out) (unet.py:255-257)
+     *   resblock_updown   1: ResBlock(up/down=True) between levels (P2)            0: Downsample / Upsample with a 3x3 conv
+     *                        (stride 2 padding 1 / nearest x2 + conv; unet.py:83-142)
+     *   num_heads         > 0: that many heads in every attention (head width = C / num_heads); else num_head_channels
+     *   transformer_depth 0: AttentionBlock (unet.py:261-307) [+ the cross-attention stage when context_dim > 0]
+     *                     1: SpatialTransformer of latent-diffusion (GroupNorm eps 1e-6 -> 1x1 proj_in -> LayerNorm ->
+     *                        self-attention, LayerNorm -> cross-attention over the loco_set_context states, LayerNorm ->
+     *                        GEGLU feed-forward, residuals -> 1x1 proj_out -> + input); needs context_dim > 0 */
+    int32_t scale_shift_norm;
+    int32_t resblock_updown;
+    int32_t num_heads;
+    int32_t transformer_depth;
 } loco_unet_cfg;
 
 /* Library / device probes (no ctx). */

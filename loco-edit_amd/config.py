@@ -42,6 +42,15 @@ class UNetConfig:
     # (queries from the image tokens, keys / values from the context_len x context_dim encoder states of the prompt)
     context_dim: int = 0
     context_len: int = 0
+    # adm, the latent-diffusion (Stable Diffusion v1) U-Net = the same guided-diffusion skeleton with
+    # `use_scale_shift_norm=False` (unet.py:255-257: h + emb_out), `resblock_updown=False` (Downsample / Upsample with a
+    # 3x3 conv, unet.py:83-142), `num_heads` fixed per block instead of a head width, and a SpatialTransformer
+    # (GroupNorm -> 1x1 proj_in -> [LayerNorm -> self-attention, LayerNorm -> cross-attention over the prompt states,
+    # LayerNorm -> GEGLU feed-forward, each with its residual] -> 1x1 proj_out -> + input) where ADM has its AttentionBlock
+    scale_shift_norm: bool = True
+    resblock_updown: bool = True
+    num_heads: int = -1
+    transformer_depth: int = 0
 
     @property
     def temb_ch(self) -> int:
@@ -106,6 +115,14 @@ TINY_ADM = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1,
 # 64-channel heads over 1024 and 256 tokens on a network the CPU oracle differentiates in seconds (flash attention tests)
 FLASH_ADM = UNetConfig(resolution=32, ch=64, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(32, 16), gn_eps=1e-5,
                        arch="adm", num_head_channels=64, learn_sigma=True)
+# Stable Diffusion v1.x denoiser (latent-diffusion UNetModel: 320 x (1,2,4,4), 2 ResBlocks per level, SpatialTransformer
+# with 8 heads at the 64 / 32 / 16 latent resolutions and in the middle block, 77 x 768 CLIP states) and a small instance
+SD15_UNET = UNetConfig(resolution=64, in_channels=4, out_ch=4, ch=320, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
+                       attn_resolutions=(64, 32, 16), gn_eps=1e-5, arch="adm", learn_sigma=False, context_dim=768,
+                       context_len=77, scale_shift_norm=False, resblock_updown=False, num_heads=8, transformer_depth=1)
+TINY_LDM = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=32, ch_mult=(1, 2), num_res_blocks=1,
+                      attn_resolutions=(16, 8), gn_eps=1e-5, arch="adm", learn_sigma=False, context_dim=16, context_len=7,
+                      scale_shift_norm=False, resblock_updown=False, num_heads=4, transformer_depth=1)
 # config 5's geometry (64x64, four levels, attention at 32 / 16 / 8 incl. the 1024-token level, 64-channel heads, learned
 # variance) at a third of IF64_STANDIN's width: the size the CPU reference solves in minutes (tests/golden/tloco_mid.pt)
 MID_IF64 = UNetConfig(resolution=64, ch=64, ch_mult=(1, 2, 3, 4), num_res_blocks=2, attn_resolutions=(32, 16, 8),
@@ -121,16 +138,38 @@ def adm_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     mc, ted = cfg.ch, cfg.ch * 4
     out_channels = cfg.out_ch * (2 if cfg.learn_sigma else 1)
 
+    ecout = 2 if cfg.scale_shift_norm else 1
+
     def res(name, cin, cout):
         shapes[name + ".in_layers.0.weight"] = (cin,); shapes[name + ".in_layers.0.bias"] = (cin,)
         shapes[name + ".in_layers.2.weight"] = (cout, cin, 3, 3); shapes[name + ".in_layers.2.bias"] = (cout,)
-        shapes[name + ".emb_layers.1.weight"] = (2 * cout, ted); shapes[name + ".emb_layers.1.bias"] = (2 * cout,)
+        shapes[name + ".emb_layers.1.weight"] = (ecout * cout, ted); shapes[name + ".emb_layers.1.bias"] = (ecout * cout,)
         shapes[name + ".out_layers.0.weight"] = (cout,); shapes[name + ".out_layers.0.bias"] = (cout,)
         shapes[name + ".out_layers.3.weight"] = (cout, cout, 3, 3); shapes[name + ".out_layers.3.bias"] = (cout,)
         if cin != cout:
             shapes[name + ".skip_connection.weight"] = (cout, cin, 1, 1); shapes[name + ".skip_connection.bias"] = (cout,)
 
+    def xfmr(name, c):
+        """SpatialTransformer of latent-diffusion (ldm/modules/attention.py), depth 1."""
+        D = cfg.context_dim
+        shapes[name + ".norm.weight"] = (c,); shapes[name + ".norm.bias"] = (c,)
+        shapes[name + ".proj_in.weight"] = (c, c, 1, 1); shapes[name + ".proj_in.bias"] = (c,)
+        b = name + ".transformer_blocks.0"
+        for n in ("norm1", "norm2", "norm3"):
+            shapes[f"{b}.{n}.weight"] = (c,); shapes[f"{b}.{n}.bias"] = (c,)
+        for n in ("to_q", "to_k", "to_v"):
+            shapes[f"{b}.attn1.{n}.weight"] = (c, c)
+        shapes[f"{b}.attn1.to_out.0.weight"] = (c, c); shapes[f"{b}.attn1.to_out.0.bias"] = (c,)
+        shapes[f"{b}.attn2.to_q.weight"] = (c, c)
+        shapes[f"{b}.attn2.to_k.weight"] = (c, D); shapes[f"{b}.attn2.to_v.weight"] = (c, D)
+        shapes[f"{b}.attn2.to_out.0.weight"] = (c, c); shapes[f"{b}.attn2.to_out.0.bias"] = (c,)
+        shapes[f"{b}.ff.net.0.proj.weight"] = (8 * c, c); shapes[f"{b}.ff.net.0.proj.bias"] = (8 * c,)
+        shapes[f"{b}.ff.net.2.weight"] = (c, 4 * c); shapes[f"{b}.ff.net.2.bias"] = (c,)
+        shapes[name + ".proj_out.weight"] = (c, c, 1, 1); shapes[name + ".proj_out.bias"] = (c,)
+
     def attn(name, c):
+        if cfg.transformer_depth > 0:
+            return xfmr(name, c)
         shapes[name + ".norm.weight"] = (c,); shapes[name + ".norm.bias"] = (c,)
         shapes[name + ".qkv.weight"] = (3 * c, c, 1); shapes[name + ".qkv.bias"] = (3 * c,)
         shapes[name + ".proj_out.weight"] = (c, c, 1); shapes[name + ".proj_out.bias"] = (c,)
@@ -157,7 +196,10 @@ def adm_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
                 attn(f"input_blocks.{ib}.1", ch)
             chans.append(ch); ib += 1
         if lvl != len(cfg.ch_mult) - 1:
-            res(f"input_blocks.{ib}.0", ch, ch)      # ResBlock(down=True)
+            if cfg.resblock_updown:
+                res(f"input_blocks.{ib}.0", ch, ch)      # ResBlock(down=True)
+            else:                                        # Downsample(ch, use_conv=True): conv3 stride 2 pad 1, unet.py:113-142
+                shapes[f"input_blocks.{ib}.0.op.weight"] = (ch, ch, 3, 3); shapes[f"input_blocks.{ib}.0.op.bias"] = (ch,)
             chans.append(ch); ib += 1
             res_px //= 2
     res("middle_block.0", ch, ch); attn("middle_block.1", ch); res("middle_block.2", ch, ch)
@@ -171,7 +213,10 @@ def adm_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
             if res_px in cfg.attn_resolutions:
                 attn(f"output_blocks.{ob}.{j}", ch); j += 1
             if lvl and i == cfg.num_res_blocks:
-                res(f"output_blocks.{ob}.{j}", ch, ch)   # ResBlock(up=True)
+                if cfg.resblock_updown:
+                    res(f"output_blocks.{ob}.{j}", ch, ch)   # ResBlock(up=True)
+                else:                                        # Upsample(ch, use_conv=True): nearest x2 + conv3, unet.py:83-110
+                    shapes[f"output_blocks.{ob}.{j}.conv.weight"] = (ch, ch, 3, 3); shapes[f"output_blocks.{ob}.{j}.conv.bias"] = (ch,)
                 res_px *= 2
             ob += 1
     shapes["out.0.weight"] = (ch,); shapes["out.0.bias"] = (ch,)

@@ -60,9 +60,13 @@ struct NormP {
     long soff = 0;      // offset into a stats arena
     long sx_off = -1;   // offset (in float2) into the primal {S, xhat} cache, -1: none
     bool ready = false; // statistics of the current pass were delivered with the producing conv (run_conv StatReq)
+    float eps = 0.f;    // 0: cfg.gn_eps; the SpatialTransformer's GroupNorm has its own (1e-6)
 };
+inline float eps_of(const loco_ctx* c, const NormP& n);
 
-enum OpKind { OP_CONV_IN, OP_RES, OP_ATTN, OP_DOWN, OP_UP, OP_OUT, OP_CONV };   // OP_CONV: plain 3x3 conv, tensor -> tensor
+enum OpKind { OP_CONV_IN, OP_RES, OP_ATTN, OP_DOWN, OP_UP, OP_OUT, OP_CONV, OP_XFMR };   // OP_CONV: plain 3x3 conv, tensor -> tensor
+// OP_XFMR tensors (latent-diffusion SpatialTransformer, depth 1), all [C][T] unless noted
+enum XT { X_G0, X_H0, X_A1, X_QKV, X_S, X_O, X_H1, X_A2, X_XQ, X_XS, X_XO, X_H2, X_A3, X_F, X_GG, X_H3, X_LN1, X_LN2, X_LN3, X_NT };
 
 struct Op {
     OpKind kind;
@@ -92,6 +96,11 @@ struct Op {
     ConvP c1, c2, nin, qkvc, proj, conv;     // conv: CONV_IN / DOWN / UP / OUT
     NormP n1, n2;                 // RES norm1/norm2, ATTN norm (n1), OUT norm_out (n1)
     long tproj_off = 0;           // RES: offset into the concatenated temb projections
+    bool sym_down = false;        // DOWN: conv3 stride 2 with symmetric padding 1 (guided-diffusion Downsample) instead of (0,1,0,1)
+    // XFMR: tensors, the three LayerNorms, the linear maps (as 1x1 convs over [C][T])
+    int xt[X_NT] = {};
+    float *lng[3] = {nullptr, nullptr, nullptr}, *lnb[3] = {nullptr, nullptr, nullptr};
+    ConvP pj_in, to_out1, to_out2, ff1, ff2, pj_out;   // qkvc = fused [to_q; to_k; to_v] of attn1 (per-head rows), xqc = attn2.to_q
 };
 
 struct HostParam { std::vector<float> data; std::vector<int64_t> shape; bool loaded = false; };
@@ -216,6 +225,7 @@ int new_tensor(loco_ctx* c, int C, int H, int W, long off = -1) {
     c->tens.push_back(t);
     return (int)c->tens.size() - 1;
 }
+inline float eps_of(const loco_ctx* c, const NormP& n) { return n.eps > 0.f ? n.eps : c->cfg.gn_eps; }
 NormP new_norm(loco_ctx* c, int C) {
     NormP n;
     n.C = C;
@@ -417,10 +427,10 @@ int build_program_adm(loco_ctx* c) {
     c->n_in = cfg.in_channels * R * R;
     c->n_out = cfg.out_ch * R * R;
     c->ctx_Lp = cfg.context_dim > 0 ? ((cfg.context_len + 63) / 64) * 64 : 0;
-    auto heads_of = [&](int C) { return cfg.num_head_channels > 0 ? C / cfg.num_head_channels : 1; };
+    auto heads_of = [&](int C) { return cfg.num_heads > 0 ? cfg.num_heads : (cfg.num_head_channels > 0 ? C / cfg.num_head_channels : 1); };
     auto add_res = [&](const std::string& name, int in_t, int out_t, int updown, bool in_is_skip) {
         Op r; r.kind = OP_RES; r.name = name; r.in = in_t; r.out = out_t; r.updown = updown;
-        r.scale_shift = true; r.in_is_skip = in_is_skip;
+        r.scale_shift = cfg.scale_shift_norm != 0; r.in_is_skip = in_is_skip;
         const Tens ti = c->tens[in_t];
         const Tens to = c->tens[out_t];
         r.has_nin = (ti.C != to.C);
@@ -433,7 +443,26 @@ int build_program_adm(loco_ctx* c) {
         r.pn_n2 = name + ".out_layers.0"; r.pn_c2 = name + ".out_layers.3"; r.pn_skip = name + ".skip_connection";
         c->ops.push_back(r);
     };
+    auto add_xfmr = [&](const std::string& name, int in_t, int out_t) {
+        Op a; a.kind = OP_XFMR; a.name = name; a.in = in_t; a.out = out_t;
+        const Tens t = c->tens[in_t];
+        const int T = t.H * t.W, C = t.C;
+        a.heads = heads_of(C);
+        a.has_x = true;
+        auto ct = [&](int ch) { return new_tensor(c, ch, t.H, t.W); };
+        a.xt[X_G0] = ct(C); a.xt[X_H0] = ct(C); a.xt[X_A1] = ct(C); a.xt[X_QKV] = ct(3 * C);
+        a.xt[X_S] = new_tensor(c, a.heads, T, T); a.xt[X_O] = ct(C); a.xt[X_H1] = ct(C); a.xt[X_A2] = ct(C);
+        a.xt[X_XQ] = ct(C); a.xt[X_XS] = new_tensor(c, a.heads, T, c->ctx_Lp); a.xt[X_XO] = ct(C); a.xt[X_H2] = ct(C);
+        a.xt[X_A3] = ct(C); a.xt[X_F] = ct(8 * C); a.xt[X_GG] = ct(4 * C); a.xt[X_H3] = ct(C);
+        a.xt[X_LN1] = new_tensor(c, 2, 1, T); a.xt[X_LN2] = new_tensor(c, 2, 1, T); a.xt[X_LN3] = new_tensor(c, 2, 1, T);
+        // the attention helpers address the block through the ATTN field names
+        a.qkv = a.xt[X_QKV]; a.S = a.xt[X_S]; a.o = a.xt[X_O]; a.xq = a.xt[X_XQ]; a.xS = a.xt[X_XS]; a.xo = a.xt[X_XO];
+        a.n1 = new_norm(c, C); a.n1.eps = 1e-6f;
+        a.pn_n1 = name + ".norm";
+        c->ops.push_back(a);
+    };
     auto add_attn = [&](const std::string& name, int in_t, int out_t) {
+        if (cfg.transformer_depth > 0) { add_xfmr(name, in_t, out_t); return; }
         Op a; a.kind = OP_ATTN; a.name = name; a.in = in_t; a.out = out_t;
         const Tens t = c->tens[in_t];
         int T = t.H * t.W;
@@ -505,7 +534,13 @@ int build_program_adm(loco_ctx* c) {
         }
         if (l != nlev - 1) {
             std::string nm = "input_blocks." + std::to_string(ib);
-            add_res(nm + ".0", cur, skip_t[si], 1, true);
+            if (cfg.resblock_updown) {
+                add_res(nm + ".0", cur, skip_t[si], 1, true);
+            } else {        // Downsample(use_conv=True): conv3 stride 2 padding 1 (unet.py:113-142)
+                Op d; d.kind = OP_DOWN; d.name = nm + ".0.op"; d.pn_conv = d.name; d.in = cur; d.in_is_skip = true;
+                d.out = skip_t[si]; d.sym_down = true;
+                c->ops.push_back(d);
+            }
             cur = skip_t[si++]; ++ib; res /= 2;
         }
     }
@@ -537,7 +572,14 @@ int build_program_adm(loco_ctx* c) {
                     last = a_out;
                 }
                 if (has_up) {
-                    add_res(nm + "." + std::to_string(sub++), last, hprev_t[j + 1], 2, false);
+                    if (cfg.resblock_updown) {
+                        add_res(nm + "." + std::to_string(sub++), last, hprev_t[j + 1], 2, false);
+                    } else {    // Upsample(use_conv=True): nearest x2 + conv3 (unet.py:83-110)
+                        Op u; u.kind = OP_UP; u.name = nm + "." + std::to_string(sub++) + ".conv"; u.pn_conv = u.name;
+                        u.in = last; u.out = hprev_t[j + 1];
+                        u.up = new_tensor(c, cout, res * 2, res * 2);
+                        c->ops.push_back(u);
+                    }
                     last = hprev_t[j + 1];
                     res *= 2;
                 }
@@ -729,6 +771,23 @@ void declare_all(loco_ctx* c) {
                 declare_conv(c, op.pn_conv, C, C, 3);
                 break;
             }
+            case OP_XFMR: {      // latent-diffusion SpatialTransformer, depth 1 (ldm/modules/attention.py parameter names)
+                const int C = c->tens[op.in].C, D = cfg.context_dim;
+                const std::string b = op.name + ".transformer_blocks.0";
+                declare_norm(c, op.pn_n1, C);
+                declare_conv(c, op.name + ".proj_in", C, C, 1);
+                for (const char* n : {".norm1", ".norm2", ".norm3"}) declare_norm(c, b + n, C);
+                for (const char* n : {".attn1.to_q", ".attn1.to_k", ".attn1.to_v"}) declare_param(c, b + n + ".weight", {C, C});
+                declare_lin(c, b + ".attn1.to_out.0", C, C);
+                declare_param(c, b + ".attn2.to_q.weight", {C, C});
+                declare_param(c, b + ".attn2.to_k.weight", {C, D});
+                declare_param(c, b + ".attn2.to_v.weight", {C, D});
+                declare_lin(c, b + ".attn2.to_out.0", C, C);
+                declare_lin(c, b + ".ff.net.0.proj", C, 8 * C);
+                declare_lin(c, b + ".ff.net.2", 4 * C, C);
+                declare_conv(c, op.name + ".proj_out", C, C, 1);
+                break;
+            }
             case OP_OUT:
                 declare_norm(c, op.pn_n1, c->tens[op.in].C);
                 declare_conv(c, op.pn_conv, c->tens[op.in].C, cfg.out_ch * (cfg.learn_sigma ? 2 : 1), 3);
@@ -802,8 +861,8 @@ static std::vector<float> build_records_f16(int nin, int nout, int taps, F get) 
 // weights [cout][cin][k][k] -> forward [cin][taps][coutP], dgrad [cout][taps][cinP] with flipped taps
 int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::vector<const HostParam*>& bs,
               ConvP* out, int row_limit = -1) {
-    int cin = (int)ws[0]->shape[1], k = (int)ws[0]->shape[2];
-    int taps = ws[0]->shape.size() == 3 ? k : k * k;      // Conv1d (k=1) or Conv2d
+    int cin = (int)ws[0]->shape[1], k = ws[0]->shape.size() > 2 ? (int)ws[0]->shape[2] : 1;
+    int taps = ws[0]->shape.size() == 4 ? k * k : k;      // Conv2d, Conv1d (k=1) or Linear
     int cout = 0;
     for (auto* w : ws) cout += (int)w->shape[0];
     if (row_limit > 0 && ws.size() == 1 && row_limit < cout) cout = row_limit;   // eps half of a learn_sigma head
@@ -912,6 +971,39 @@ int finalize_params(loco_ctx* c) {
                 break;
             }
             case OP_DOWN: case OP_UP: if (make_conv1(c, op.pn_conv, &op.conv)) return -1; break;
+            case OP_XFMR: {
+                const int C = c->tens[op.in].C, NH = op.heads, CH = C / NH;
+                const std::string b = op.name + ".transformer_blocks.0";
+                HostParam zb; zb.shape = {8 * C}; zb.data.assign((size_t)8 * C, 0.f);       // bias of the bias-free maps
+                auto nobias = [&](const std::string& w, ConvP* out) { return make_conv(c, {&c->params[w + ".weight"]}, {&zb}, out); };
+                if (make_norm(c, op.pn_n1, &op.n1) || make_conv1(c, op.name + ".proj_in", &op.pj_in) ||
+                    make_conv1(c, op.name + ".proj_out", &op.pj_out)) return -1;
+                const char* lnn[3] = {".norm1", ".norm2", ".norm3"};
+                for (int i = 0; i < 3; ++i)
+                    if (upload(c, &op.lng[i], c->params[b + lnn[i] + ".weight"].data) ||
+                        upload(c, &op.lnb[i], c->params[b + lnn[i] + ".bias"].data)) return -1;
+                {   // attn1: to_q / to_k / to_v fused into one [3C][C] map whose rows follow the per-head [q_h | k_h | v_h] layout
+                    // the attention products address (head h of 'b n (h d)' = channels h*d .. h*d+d-1)
+                    HostParam w; w.shape = {3 * C, C}; w.data.resize((size_t)3 * C * C);
+                    const char* nm[3] = {".attn1.to_q.weight", ".attn1.to_k.weight", ".attn1.to_v.weight"};
+                    for (int which = 0; which < 3; ++which) {
+                        const std::vector<float>& src = c->params[b + nm[which]].data;
+                        for (int h = 0; h < NH; ++h)
+                            for (int j = 0; j < CH; ++j)
+                                std::memcpy(&w.data[((size_t)(h * 3 + which) * CH + j) * C], &src[(size_t)(h * CH + j) * C], (size_t)C * 4);
+                    }
+                    if (make_conv(c, {&w}, {&zb}, &op.qkvc)) return -1;
+                }
+                if (make_conv1(c, b + ".attn1.to_out.0", &op.to_out1) || nobias(b + ".attn2.to_q", &op.xqc) ||
+                    make_conv1(c, b + ".attn2.to_out.0", &op.to_out2) || make_conv1(c, b + ".ff.net.0.proj", &op.ff1) ||
+                    make_conv1(c, b + ".ff.net.2", &op.ff2)) return -1;
+                std::vector<float> z0((size_t)C, 0.f);
+                if (upload(c, &op.xkw, c->params[b + ".attn2.to_k.weight"].data) || upload(c, &op.xkb, z0) ||
+                    upload(c, &op.xvw, c->params[b + ".attn2.to_v.weight"].data) || upload(c, &op.xvb, z0)) return -1;
+                const size_t kv = (size_t)C * c->ctx_Lp;
+                if (dalloc(c, &op.xK, kv) || dalloc(c, &op.xV, kv)) return -1;
+                break;
+            }
             case OP_OUT:
                 if (make_norm(c, op.pn_n1, &op.n1) || make_conv1(c, op.pn_conv, &op.conv, cfg.out_ch)) return -1;
                 break;
@@ -931,6 +1023,12 @@ int finalize_params(loco_ctx* c) {
                 convf(op.c1, to.H, to.W); convf(op.c2, to.H, to.W);
                 if (op.has_nin) convf(op.nin, to.H, to.W);
                 break;
+            case OP_XFMR: {
+                for (const ConvP* p : {&op.pj_in, &op.qkvc, &op.to_out1, &op.xqc, &op.to_out2, &op.ff1, &op.ff2, &op.pj_out}) convf(*p, to.H, to.W);
+                double T = (double)to.H * to.W;
+                fl += 2.0 * 2.0 * T * T * to.C + 2.0 * 2.0 * T * c->cfg.context_len * to.C;
+                break;
+            }
             case OP_ATTN: {
                 convf(op.qkvc, to.H, to.W); convf(op.proj, to.H, to.W);
                 double T = (double)to.H * to.W;
@@ -999,7 +1097,7 @@ void stats_standalone(loco_ctx* c, const StatReq& rq, const float* x, long xbs, 
     const int G = c->cfg.gn_groups;
     if (rq.kind == ST_FWD) {
         NS s = nstats(c, rq.stats + (long)s0 * SB, n);
-        launch_gn_stats(x, xbs, B, n.C, HW, G, c->cfg.gn_eps, n.gamma, n.beta, s.mr, s.sc, s.sh, SB, c->red, st, rq.ss_scale,
+        launch_gn_stats(x, xbs, B, n.C, HW, G, eps_of(c, n), n.gamma, n.beta, s.mr, s.sc, s.sh, SB, c->red, st, rq.ss_scale,
                         rq.ss_shift);
     } else {
         NS sp = nstats(c, c->statsP, n);
@@ -1061,14 +1159,14 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
         const NormP& n = *rq->n;
         if (how == 3) { stats_standalone(c, *rq, x.out, x.out_bs, x.B, HWo, s0, st); return; }
         NS so = nstats(c, rq->stats + (long)s0 * SBs, n);
-        launch_gn_fused_finalize(x.st_part, HWo / conv_bf16_tile_pixels(x), x.B, n.C, HWo, Gn, c->cfg.gn_eps, n.gamma, n.beta,
+        launch_gn_fused_finalize(x.st_part, HWo / conv_bf16_tile_pixels(x), x.B, n.C, HWo, Gn, eps_of(c, n), n.gamma, n.beta,
                                  so.mr, so.sc, so.sh, SBs, rq->ss_scale, rq->ss_shift, st);
     };
     auto reduce_with_stats = [&](const ConvArgs& x, int s0) {
         const NormP& n = *rq->n;
         NS sp = nstats(c, c->statsP, n);
         NS so = nstats(c, rq->stats + (long)s0 * SBs, n);
-        launch_conv_splitk_reduce_stats(x, rq->kind, Gn, c->cfg.gn_eps, n.gamma, n.beta, so.mr, so.sc, so.sh, SBs, rq->ss_scale,
+        launch_conv_splitk_reduce_stats(x, rq->kind, Gn, eps_of(c, n), n.gamma, n.beta, so.mr, so.sc, so.sh, SBs, rq->ss_scale,
                                         rq->ss_shift, rq->prim, sp.sc, sp.sh, sp.mr, so.tst, so.tc, SBs, c->red, st);
     };
     auto one = [&](ConvArgs& x, int s0) {
@@ -1144,7 +1242,7 @@ void clear_ready(loco_ctx* c) {
 
 void gn_forward_stats(const Pass& p, const NormP& n, const float* x, long xbs, int HW) {
     NS s = nstats(p.c, p.stats, n);
-    launch_gn_stats(x, xbs, p.B, n.C, HW, p.c->cfg.gn_groups, p.c->cfg.gn_eps, n.gamma, n.beta, s.mr, s.sc, s.sh,
+    launch_gn_stats(x, xbs, p.B, n.C, HW, p.c->cfg.gn_groups, eps_of(p.c, n), n.gamma, n.beta, s.mr, s.sc, s.sh,
                     p.c->stats_per_sample, p.c->red, p.st);
 }
 
@@ -1191,6 +1289,114 @@ void xa_conv1x1(loco_ctx* c, const ConvP& w, bool dgrad, const float* in, long i
     if (with_bias) a.bias = w.bias;
     a.res = res; a.res_bs = res_bs;
     a.out = out; a.out_bs = out_bs; a.Cout = C; a.Hout = H; a.Wout = W; a.B = B;
+    run_conv(c, a, 1, st, rq);
+}
+
+// ------------------------------ self-attention core of a SpatialTransformer block ------------------------------
+// Between the fused q/k/v map (per-head rows [q_h | k_h | v_h] of `op.qkv`) and the attended values `op.o`; the same
+// strided products and row kernels as the AttentionBlock (and its flash tangent / cotangent where the head width allows).
+struct SA { loco_ctx* c; const Op* op; int B, T, NH, CH; hipStream_t st; };
+void sa_forward(const SA& s, float* ar) {
+    loco_ctx* c = s.c;
+    const long PS = c->per_sample, HS = 3L * s.CH * s.T, SS = (long)s.T * s.T;
+    float* q = ar + c->tens[s.op->qkv].off; float* k = q + (long)s.CH * s.T; float* v = k + (long)s.CH * s.T;
+    float* S = ar + c->tens[s.op->S].off; float* o = ar + c->tens[s.op->o].off;
+    GemmArgs g; std::memset(&g, 0, sizeof(g));
+    g.A = q; g.sam = 1; g.sak = s.T; g.sab = PS; g.sah = HS;
+    g.Bm = k; g.sbk = s.T; g.sbn = 1; g.sbb = PS; g.sbh = HS;
+    g.C = S; g.scm = s.T; g.scn = 1; g.scb = PS; g.sch = SS;
+    g.M = s.T; g.N = s.T; g.K = s.CH; g.batch = s.B; g.batch2 = s.NH; g.alpha = 1.0f / std::sqrt((float)s.CH); g.beta = 0.f;
+    attn_gemm(c, g, s.st);
+    launch_softmax_rows(S, (long)s.NH * s.T, s.T, s.st, s.B, PS);
+    GemmArgs h; std::memset(&h, 0, sizeof(h));
+    h.A = v; h.sam = s.T; h.sak = 1; h.sab = PS; h.sah = HS;
+    h.Bm = S; h.sbk = 1; h.sbn = s.T; h.sbb = PS; h.sbh = SS;
+    h.C = o; h.scm = s.T; h.scn = 1; h.scb = PS; h.sch = (long)s.CH * s.T;
+    h.M = s.CH; h.N = s.T; h.K = s.T; h.batch = s.B; h.batch2 = s.NH; h.alpha = 1.f; h.beta = 0.f;
+    attn_gemm(c, h, s.st);
+}
+void sa_tangent(const SA& s) {       // dq, dk, dv in arenaT(qkv) -> do in arenaT(o); primal in arenaP (B = 1)
+    loco_ctx* c = s.c;
+    const int T = s.T, CH = s.CH, NH = s.NH, B = s.B;
+    const long PS = c->per_sample, HS = 3L * CH * T, SS = (long)T * T;
+    float* q = c->arenaP + c->tens[s.op->qkv].off; float* k = q + (long)CH * T; float* v = k + (long)CH * T;
+    float* dq = c->arenaT + c->tens[s.op->qkv].off; float* dk = dq + (long)CH * T; float* dv = dk + (long)CH * T;
+    float* SP = c->arenaP + c->tens[s.op->S].off; float* ST = c->arenaT + c->tens[s.op->S].off;
+    float* oP = c->arenaP + c->tens[s.op->o].off; float* oT = c->arenaT + c->tens[s.op->o].off;
+    const float scale = 1.0f / std::sqrt((float)CH);
+    if (c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH)) {
+        AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+        fa.T = T; fa.NH = NH; fa.B = B; fa.scale = scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = SP; fa.o = oP;
+        fa.dq = dq; fa.dk = dk; fa.dv = dv; fa.bs_d = PS; fa.out = oT; fa.bs_out = PS;
+        launch_attn_flash_tangent(fa, s.st);
+        return;
+    }
+    GemmArgs g; std::memset(&g, 0, sizeof(g));
+    g.A = dq; g.sam = 1; g.sak = T; g.sab = PS; g.sah = HS;
+    g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = HS;
+    g.C = ST; g.scm = T; g.scn = 1; g.scb = PS; g.sch = SS;
+    g.M = T; g.N = T; g.K = CH; g.batch = B; g.batch2 = NH; g.alpha = 1.f; g.beta = 0.f;
+    attn_gemm(c, g, s.st);
+    g.A = q; g.sab = 0; g.Bm = dk; g.sbb = PS; g.beta = 1.f;
+    attn_gemm(c, g, s.st);
+    launch_softmax_jac(ST, SP, (long)NH * T, T, (long)NH * T, scale, s.st, B, PS);
+    GemmArgs h; std::memset(&h, 0, sizeof(h));
+    h.A = dv; h.sam = T; h.sak = 1; h.sab = PS; h.sah = HS;
+    h.Bm = SP; h.sbk = 1; h.sbn = T; h.sbb = 0; h.sbh = SS;
+    h.C = oT; h.scm = T; h.scn = 1; h.scb = PS; h.sch = (long)CH * T;
+    h.M = CH; h.N = T; h.K = T; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
+    attn_gemm(c, h, s.st);
+    h.A = v; h.sab = 0; h.Bm = ST; h.sbb = PS; h.beta = 1.f;
+    attn_gemm(c, h, s.st);
+}
+void sa_cotangent(const SA& s) {     // g_o in arenaT(o) -> g_q, g_k, g_v in arenaT(qkv)
+    loco_ctx* c = s.c;
+    const int T = s.T, CH = s.CH, NH = s.NH, B = s.B;
+    const long PS = c->per_sample, HS = 3L * CH * T, SS = (long)T * T, OS = (long)CH * T;
+    float* q = c->arenaP + c->tens[s.op->qkv].off; float* k = q + (long)CH * T; float* v = k + (long)CH * T;
+    float* gq = c->arenaT + c->tens[s.op->qkv].off; float* gk = gq + (long)CH * T; float* gv = gk + (long)CH * T;
+    float* SP = c->arenaP + c->tens[s.op->S].off; float* SG = c->arenaT + c->tens[s.op->S].off;
+    float* oP = c->arenaP + c->tens[s.op->o].off; float* oG = c->arenaT + c->tens[s.op->o].off;
+    const float scale = 1.0f / std::sqrt((float)CH);
+    if (c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH)) {
+        AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+        fa.T = T; fa.NH = NH; fa.B = B; fa.scale = scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = SP; fa.o = oP;
+        fa.go = oG; fa.bs_go = PS; fa.gq = gq; fa.gk = gk; fa.gv = gv; fa.bs_g = PS; fa.delta = c->attn_delta;
+        launch_attn_flash_cotangent(fa, s.st);
+        return;
+    }
+    GemmArgs g; std::memset(&g, 0, sizeof(g));                      // g_v[c][j] = sum_i g_o[c][i] P[i][j]
+    g.A = oG; g.sam = T; g.sak = 1; g.sab = PS; g.sah = OS;
+    g.Bm = SP; g.sbk = T; g.sbn = 1; g.sbb = 0; g.sbh = SS;
+    g.C = gv; g.scm = T; g.scn = 1; g.scb = PS; g.sch = HS;
+    g.M = CH; g.N = T; g.K = T; g.batch = B; g.batch2 = NH; g.alpha = 1.f; g.beta = 0.f;
+    attn_gemm(c, g, s.st);
+    GemmArgs h; std::memset(&h, 0, sizeof(h));                      // g_P[i][j] = sum_c g_o[c][i] v[c][j]
+    h.A = oG; h.sam = 1; h.sak = T; h.sab = PS; h.sah = OS;
+    h.Bm = v; h.sbk = T; h.sbn = 1; h.sbb = 0; h.sbh = HS;
+    h.C = SG; h.scm = T; h.scn = 1; h.scb = PS; h.sch = SS;
+    h.M = T; h.N = T; h.K = CH; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
+    attn_gemm(c, h, s.st);
+    launch_softmax_jac(SG, SP, (long)NH * T, T, (long)NH * T, scale, s.st, B, PS);
+    GemmArgs a; std::memset(&a, 0, sizeof(a));                      // g_q[c][i] = sum_j k[c][j] g_S[i][j]
+    a.A = k; a.sam = T; a.sak = 1; a.sab = 0; a.sah = HS;
+    a.Bm = SG; a.sbk = 1; a.sbn = T; a.sbb = PS; a.sbh = SS;
+    a.C = gq; a.scm = T; a.scn = 1; a.scb = PS; a.sch = HS;
+    a.M = CH; a.N = T; a.K = T; a.batch = B; a.batch2 = NH; a.alpha = 1.f; a.beta = 0.f;
+    attn_gemm(c, a, s.st);
+    GemmArgs b = a;                                                 // g_k[c][j] = sum_i q[c][i] g_S[i][j]
+    b.A = q; b.Bm = SG; b.sbk = T; b.sbn = 1; b.C = gk;
+    attn_gemm(c, b, s.st);
+}
+// y[Cout][T] (+ bias, + residual) = W x[Cin][T] as a 1x1 conv; dgrad: the transposed map
+void lin1x1(loco_ctx* c, const ConvP& w, bool dgrad, const float* in, long in_bs, int Cin, float* out, long out_bs, int Cout,
+            int H, int W, int B, const float* res, long res_bs, bool with_bias, hipStream_t st, const StatReq* rq = nullptr) {
+    ConvArgs a; conv_defaults(a);
+    a.in = in; a.in_bs = in_bs; a.Cin = Cin; a.Hin = H; a.Win = W;
+    setw(a, w, dgrad); a.pad = 0;
+    if (with_bias) a.bias = w.bias;
+    a.res = res; a.res_bs = res_bs;
+    a.out = out; a.out_bs = out_bs; a.Cout = Cout; a.Hout = H; a.Wout = W; a.B = B;
     run_conv(c, a, 1, st, rq);
 }
 
@@ -1340,12 +1546,51 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 }
                 break;
             }
+            case OP_XFMR: {      // latent-diffusion SpatialTransformer (oracle/loco_oracle.py _ldm_spatial_transformer)
+                if (!c->has_ctx) { c->err = "this architecture has cross-attention stages: call loco_set_context first"; return -1; }
+                const int C = to.C, T = HW, NH = op.heads, H = to.H, W = to.W;
+                const long PSb = p.bs();
+                auto X = [&](int i) { return p.T(op.xt[i]); };
+                gn_forward_stats(p, op.n1, p.T(op.in), PSb, HW);
+                NS s = nstats(c, stats, op.n1);
+                {   // h0 = proj_in(GN(x))
+                    ConvArgs a; conv_defaults(a);
+                    a.in = p.T(op.in); a.in_bs = PSb; a.Cin = C; a.Hin = H; a.Win = W;
+                    setw(a, op.pj_in, false); a.bias = op.pj_in.bias; a.pad = 0;
+                    a.mode = CM_GN; a.sc = s.sc; a.sh = s.sh; a.scsh_bs = SB;
+                    a.out = X(X_H0); a.out_bs = PSb; a.Cout = C; a.Hout = H; a.Wout = W; a.B = B;
+                    run_conv(c, a, 1, st);
+                }
+                const SA sa{c, &op, B, T, NH, C / NH, st};
+                const XA xa = xa_of(c, op, B, st);
+                // x = x + attn1(LN1(x))
+                launch_ln_fwd(X(X_H0), PSb, B, C, T, op.lng[0], op.lnb[0], 1e-5f, X(X_A1), PSb, X(X_LN1), PSb, st);
+                lin1x1(c, op.qkvc, false, X(X_A1), PSb, C, X(X_QKV), PSb, 3 * C, H, W, B, nullptr, 0, false, st);
+                sa_forward(sa, arena);
+                lin1x1(c, op.to_out1, false, X(X_O), PSb, C, X(X_H1), PSb, C, H, W, B, X(X_H0), PSb, true, st);
+                // x = x + attn2(LN2(x), context)
+                launch_ln_fwd(X(X_H1), PSb, B, C, T, op.lng[1], op.lnb[1], 1e-5f, X(X_A2), PSb, X(X_LN2), PSb, st);
+                lin1x1(c, op.xqc, false, X(X_A2), PSb, C, X(X_XQ), PSb, C, H, W, B, nullptr, 0, false, st);
+                xa_scores(xa, X(X_XQ), PSb, op.xK, X(X_XS), PSb, xa.scale, true);
+                launch_softmax_rows(X(X_XS), (long)NH * T, xa.Lp, st, B, PSb);
+                xa_values(xa, op.xV, X(X_XS), PSb, X(X_XO), PSb);
+                lin1x1(c, op.to_out2, false, X(X_XO), PSb, C, X(X_H2), PSb, C, H, W, B, X(X_H1), PSb, true, st);
+                // x = x + Linear(GEGLU(LN3(x)))
+                launch_ln_fwd(X(X_H2), PSb, B, C, T, op.lng[2], op.lnb[2], 1e-5f, X(X_A3), PSb, X(X_LN3), PSb, st);
+                lin1x1(c, op.ff1, false, X(X_A3), PSb, C, X(X_F), PSb, 8 * C, H, W, B, nullptr, 0, true, st);
+                launch_geglu(0, X(X_F), PSb, nullptr, B, 4L * C * T, X(X_GG), PSb, st);
+                lin1x1(c, op.ff2, false, X(X_GG), PSb, 4 * C, X(X_H3), PSb, C, H, W, B, X(X_H2), PSb, true, st);
+                // out = input + proj_out(x)
+                const StatReq rq = next_fwd(op.out);
+                lin1x1(c, op.pj_out, false, X(X_H3), PSb, C, p.T(op.out), PSb, C, H, W, B, p.T(op.in), PSb, true, st, &rq);
+                break;
+            }
             case OP_DOWN: case OP_UP: {
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
                 a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false); a.bias = op.conv.bias;
-                if (op.kind == OP_DOWN) { a.stride = 2; a.pad = 0; } else { a.upsample = 1; }
+                if (op.kind == OP_DOWN) { a.stride = 2; a.pad = op.sym_down ? 1 : 0; } else { a.upsample = 1; }
                 a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 const StatReq rq = next_fwd(op.out);
                 run_conv(c, a, 9, st, &rq);
@@ -1545,12 +1790,42 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 }
                 break;
             }
+            case OP_XFMR: {
+                const int C = to.C, T = HW, NH = op.heads, H = to.H, W = to.W;
+                auto XP = [&](int i) { return TP(op.xt[i]); };
+                auto XT_ = [&](int i) { return TT(op.xt[i]); };
+                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
+                NS sp = nstats(c, c->statsP, op.n1);
+                NS stt = nstats(c, c->statsT, op.n1);
+                launch_gn_apply(1, TT(op.in), PS, TP(op.in), 0, nullptr, 0, XT_(X_G0), PS, 0, B, C, HW,
+                                cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                lin1x1(c, op.pj_in, false, XT_(X_G0), PS, C, XT_(X_H0), PS, C, H, W, B, nullptr, 0, false, st);
+                const SA sa{c, &op, B, T, NH, C / NH, st};
+                const XA xa = xa_of(c, op, B, st);
+                launch_ln_tan(XT_(X_H0), PS, XP(X_H0), XP(X_LN1), B, C, T, op.lng[0], XT_(X_A1), PS, st);
+                lin1x1(c, op.qkvc, false, XT_(X_A1), PS, C, XT_(X_QKV), PS, 3 * C, H, W, B, nullptr, 0, false, st);
+                sa_tangent(sa);
+                lin1x1(c, op.to_out1, false, XT_(X_O), PS, C, XT_(X_H1), PS, C, H, W, B, XT_(X_H0), PS, false, st);
+                launch_ln_tan(XT_(X_H1), PS, XP(X_H1), XP(X_LN2), B, C, T, op.lng[1], XT_(X_A2), PS, st);
+                lin1x1(c, op.xqc, false, XT_(X_A2), PS, C, XT_(X_XQ), PS, C, H, W, B, nullptr, 0, false, st);
+                xa_scores(xa, XT_(X_XQ), PS, op.xK, XT_(X_XS), PS, 1.f, false);                   // dS = dq^T K
+                launch_softmax_jac(XT_(X_XS), XP(X_XS), (long)NH * T, xa.Lp, (long)NH * T, xa.scale, st, B, PS);
+                xa_values(xa, op.xV, XT_(X_XS), PS, XT_(X_XO), PS);                              // do = V dP^T
+                lin1x1(c, op.to_out2, false, XT_(X_XO), PS, C, XT_(X_H2), PS, C, H, W, B, XT_(X_H1), PS, false, st);
+                launch_ln_tan(XT_(X_H2), PS, XP(X_H2), XP(X_LN3), B, C, T, op.lng[2], XT_(X_A3), PS, st);
+                lin1x1(c, op.ff1, false, XT_(X_A3), PS, C, XT_(X_F), PS, 8 * C, H, W, B, nullptr, 0, false, st);
+                launch_geglu(1, XT_(X_F), PS, XP(X_F), B, 4L * C * T, XT_(X_GG), PS, st);
+                lin1x1(c, op.ff2, false, XT_(X_GG), PS, 4 * C, XT_(X_H3), PS, C, H, W, B, XT_(X_H2), PS, false, st);
+                const StatReq rq = next_tan(op.out);
+                lin1x1(c, op.pj_out, false, XT_(X_H3), PS, C, TT(op.out), PS, C, H, W, B, TT(op.in), PS, false, st, &rq);
+                break;
+            }
             case OP_DOWN: case OP_UP: {
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
                 a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false);
-                if (op.kind == OP_DOWN) { a.stride = 2; a.pad = 0; } else { a.upsample = 1; }
+                if (op.kind == OP_DOWN) { a.stride = 2; a.pad = op.sym_down ? 1 : 0; } else { a.upsample = 1; }
                 a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
                 const StatReq rq = next_tan(op.out);
                 run_conv(c, a, 9, st, &rq);
@@ -1626,7 +1901,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
                 a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
-                setw(a, op.conv, true); a.zins = 1; a.pad = 2; a.accumulate = op.in_is_skip ? 1 : 0;
+                setw(a, op.conv, true); a.zins = 1; a.pad = op.sym_down ? 1 : 2; a.accumulate = op.in_is_skip ? 1 : 0;
                 a.out = TG(op.in); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
                 run_conv(c, a, 9, st);
                 break;
@@ -1767,6 +2042,39 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 launch_gn_apply(3, TG(op.hn), PS, TP(op.in), 0, TG(so), PS, TG(op.in), PS,
+                                op.in_is_skip ? 1 : 0, B, C, HW, G, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                break;
+            }
+            case OP_XFMR: {      // transposes of the forward chain, last map first
+                const int C = to.C, T = HW, NH = op.heads, H = to.H, W = to.W;
+                auto XP = [&](int i) { return TP(op.xt[i]); };
+                auto XG = [&](int i) { return TG(op.xt[i]); };
+                const SA sa{c, &op, B, T, NH, C / NH, st};
+                const XA xa = xa_of(c, op, B, st);
+                lin1x1(c, op.pj_out, true, TG(op.out), PS, C, XG(X_H3), PS, C, H, W, B, nullptr, 0, false, st);          // g_h3
+                // feed-forward: h3 = h2 + ff2(geglu(ff1(LN3(h2))))
+                lin1x1(c, op.ff2, true, XG(X_H3), PS, C, XG(X_GG), PS, 4 * C, H, W, B, nullptr, 0, false, st);
+                launch_geglu(2, XG(X_GG), PS, XP(X_F), B, 4L * C * T, XG(X_F), PS, st);
+                lin1x1(c, op.ff1, true, XG(X_F), PS, 8 * C, XG(X_A3), PS, C, H, W, B, nullptr, 0, false, st);
+                launch_ln_cot(XG(X_A3), PS, XP(X_H2), XP(X_LN3), B, C, T, op.lng[2], XG(X_H3), PS, XG(X_H2), PS, st);  // g_h2
+                // cross-attention: h2 = h1 + to_out2(V P^T), q = to_q(LN2(h1))
+                lin1x1(c, op.to_out2, true, XG(X_H2), PS, C, XG(X_XO), PS, C, H, W, B, nullptr, 0, false, st);
+                xa_scores(xa, XG(X_XO), PS, op.xV, XG(X_XS), PS, 1.f, false);                     // g_P = g_o^T V
+                launch_softmax_jac(XG(X_XS), XP(X_XS), (long)NH * T, xa.Lp, (long)NH * T, xa.scale, st, B, PS);
+                xa_values(xa, op.xK, XG(X_XS), PS, XG(X_XQ), PS);                                // g_q = K g_S^T
+                lin1x1(c, op.xqc, true, XG(X_XQ), PS, C, XG(X_A2), PS, C, H, W, B, nullptr, 0, false, st);
+                launch_ln_cot(XG(X_A2), PS, XP(X_H1), XP(X_LN2), B, C, T, op.lng[1], XG(X_H2), PS, XG(X_H1), PS, st);  // g_h1
+                // self-attention: h1 = h0 + to_out1(attn(qkv(LN1(h0))))
+                lin1x1(c, op.to_out1, true, XG(X_H1), PS, C, XG(X_O), PS, C, H, W, B, nullptr, 0, false, st);
+                sa_cotangent(sa);
+                lin1x1(c, op.qkvc, true, XG(X_QKV), PS, 3 * C, XG(X_A1), PS, C, H, W, B, nullptr, 0, false, st);
+                launch_ln_cot(XG(X_A1), PS, XP(X_H0), XP(X_LN1), B, C, T, op.lng[0], XG(X_H1), PS, XG(X_H0), PS, st);  // g_h0
+                // proj_in of GN(x), and the residual  out = x + ...
+                lin1x1(c, op.pj_in, true, XG(X_H0), PS, C, XG(X_G0), PS, C, H, W, B, nullptr, 0, false, st);
+                cot_stats(c, op.n1, XG(X_G0), PS, TP(op.in), HW, B, 2, st);
+                NS sp = nstats(c, c->statsP, op.n1);
+                NS stt = nstats(c, c->statsT, op.n1);
+                launch_gn_apply(3, XG(X_G0), PS, TP(op.in), 0, TG(op.out), PS, TG(op.in), PS,
                                 op.in_is_skip ? 1 : 0, B, C, HW, G, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
                 break;
             }
@@ -2321,7 +2629,7 @@ int loco_set_context(loco_ctx* c, const float* tokens, void* stream) {
         if (upload(c, &c->ctx_colbias, cb)) return -1;
     }
     for (auto& op : c->ops) {
-        if (op.kind != OP_ATTN || !op.has_x) continue;
+        if (!((op.kind == OP_ATTN && op.has_x) || op.kind == OP_XFMR)) continue;
         const int C = c->tens[op.in].C;
         for (int w = 0; w < 2; ++w) {
             float* dst = w ? op.xV : op.xK;

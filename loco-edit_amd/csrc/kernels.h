@@ -124,6 +124,19 @@ bool attn_flash_supported(int T, int CH);     // heads of 64 channels, token cou
 void launch_attn_flash_tangent(const AttnFlashArgs& a, hipStream_t st);
 void launch_attn_flash_cotangent(const AttnFlashArgs& a, hipStream_t st);
 
+// ---- token-wise pieces of the latent-diffusion SpatialTransformer (xfmr.hip); tensors [channel][token] ----
+// LayerNorm over the C channels of each token; stats = [2][T] {mean, rstd} per sample
+void launch_ln_fwd(const float* x, long xbs, int B, int C, int T, const float* gamma, const float* beta, float eps, float* y,
+                   long ybs, float* stats, long sbs, hipStream_t st);
+void launch_ln_tan(const float* dx, long dbs, const float* xprim, const float* sprim, int B, int C, int T, const float* gamma,
+                   float* dy, long ybs, hipStream_t st);
+// gx = base + rstd (gamma gy - mean_c(gamma gy) - xhat mean_c(xhat gamma gy))      (base may be null)
+void launch_ln_cot(const float* gy, long gbs, const float* xprim, const float* sprim, int B, int C, int T, const float* gamma,
+                   const float* base, long base_bs, float* gx, long xbs, hipStream_t st);
+// GEGLU on f = [value | gate] (2 * n4 floats per sample): kind 0 forward, 1 tangent (in = df), 2 cotangent (in = g of the output)
+void launch_geglu(int kind, const float* in, long in_bs, const float* fprim, int B, long n4, float* out, long out_bs,
+                  hipStream_t st);
+
 // ---- GroupNorm statistics -------------------------------------------------
 // x: [B][C][HW] with batch stride bs; groups of cpg channels (contiguous cpg*HW floats)
 // writes mr[b][g] = {mean, rstd}, sc[b][c] = gamma*rstd, sh[b][c] = beta - mean*rstd*gamma

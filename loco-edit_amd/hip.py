@@ -42,6 +42,8 @@ class LocoCfg(C.Structure):
         ("gn_eps", C.c_float), ("max_batch", C.c_int32),
         ("arch", C.c_int32), ("num_head_channels", C.c_int32), ("learn_sigma", C.c_int32),
         ("context_dim", C.c_int32), ("context_len", C.c_int32),
+        ("scale_shift_norm", C.c_int32), ("resblock_updown", C.c_int32), ("num_heads", C.c_int32),
+        ("transformer_depth", C.c_int32),
     ]
 
 
@@ -149,6 +151,8 @@ class LocoEngine:
         c.arch = {"ddpm": 0, "adm": 1, "dec": 2}[cfg.arch]
         c.num_head_channels, c.learn_sigma = cfg.num_head_channels, int(cfg.learn_sigma)
         c.context_dim, c.context_len = cfg.context_dim, cfg.context_len
+        c.scale_shift_norm, c.resblock_updown = int(cfg.scale_shift_norm), int(cfg.resblock_updown)
+        c.num_heads, c.transformer_depth = cfg.num_heads, cfg.transformer_depth
         self._ctx = C.c_void_p()
         rc = self.lib.loco_create(C.byref(c), C.byref(self._ctx))
         if rc != 0:

@@ -196,8 +196,11 @@ def _adm_resblock(p, name, x, emb, cfg, up=False, down=False):
         x = F.avg_pool2d(x, 2, 2)
     h = F.conv2d(h, p[name + ".in_layers.2.weight"], p[name + ".in_layers.2.bias"], padding=1)
     emb_out = F.linear(F.silu(emb), p[name + ".emb_layers.1.weight"], p[name + ".emb_layers.1.bias"])[:, :, None, None]
-    scale, shift = torch.chunk(emb_out, 2, dim=1)
-    h = _adm_gn(p, name + ".out_layers.0", h, cfg) * (1 + scale) + shift     # :250-254
+    if getattr(cfg, "scale_shift_norm", True):
+        scale, shift = torch.chunk(emb_out, 2, dim=1)
+        h = _adm_gn(p, name + ".out_layers.0", h, cfg) * (1 + scale) + shift     # :250-254
+    else:                                                                        # :255-257
+        h = _adm_gn(p, name + ".out_layers.0", h + emb_out, cfg)
     h = F.conv2d(F.silu(h), p[name + ".out_layers.3.weight"], p[name + ".out_layers.3.bias"], padding=1)
     if (name + ".skip_connection.weight") in p:
         x = F.conv2d(x, p[name + ".skip_connection.weight"], p[name + ".skip_connection.bias"])
@@ -219,6 +222,43 @@ def _adm_attn(p, name, x, cfg):
     a = torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, hh * ww)
     h = F.conv1d(a, p[name + ".proj_out.weight"], p[name + ".proj_out.bias"])
     return (xr + h).reshape(b, c, hh, ww)
+
+
+def _ldm_spatial_transformer(p, name, x, context, cfg):
+    """SpatialTransformer of latent-diffusion / Stable Diffusion v1 (ldm/modules/attention.py: SpatialTransformer,
+    BasicTransformerBlock, CrossAttention, FeedForward / GEGLU; un-vendored by the reference, which reaches it through
+    diffusers' UNet2DConditionModel -- the same arithmetic under other parameter names), depth 1:
+    GroupNorm(32, eps 1e-6) -> 1x1 proj_in -> tokens [B, HW, C] -> x + attn1(LN(x)); x + attn2(LN(x), context);
+    x + Linear(GEGLU(LN(x))) -> 1x1 proj_out -> + input.  Heads = cfg.num_heads, scale = head_dim^-1/2, to_q/k/v without
+    bias, LayerNorm eps 1e-5, GEGLU: proj to 8C, value * gelu(gate) (erf form)."""
+    b, c, hh, ww = x.shape
+    nh = cfg.num_heads
+    d = c // nh
+    h = F.group_norm(x, cfg.gn_groups, p[name + ".norm.weight"], p[name + ".norm.bias"], 1e-6)
+    h = F.conv2d(h, p[name + ".proj_in.weight"], p[name + ".proj_in.bias"])
+    h = h.reshape(b, c, hh * ww).transpose(1, 2)                                       # [B, T, C]
+    tb = name + ".transformer_blocks.0"
+
+    def ln(n, z):
+        return F.layer_norm(z, (c,), p[f"{tb}.{n}.weight"], p[f"{tb}.{n}.bias"], 1e-5)
+
+    def attention(an, z, ctx):
+        q = F.linear(z, p[f"{tb}.{an}.to_q.weight"])
+        k = F.linear(ctx, p[f"{tb}.{an}.to_k.weight"])
+        v = F.linear(ctx, p[f"{tb}.{an}.to_v.weight"])
+        q, k, v = (u.reshape(b, -1, nh, d).permute(0, 2, 1, 3) for u in (q, k, v))     # [B, H, N, d]
+        w = torch.softmax(torch.einsum("bhid,bhjd->bhij", q, k) * (d ** -0.5), dim=-1)
+        o = torch.einsum("bhij,bhjd->bhid", w, v).permute(0, 2, 1, 3).reshape(b, -1, c)
+        return F.linear(o, p[f"{tb}.{an}.to_out.0.weight"], p[f"{tb}.{an}.to_out.0.bias"])
+
+    z = ln("norm1", h)
+    h = h + attention("attn1", z, z)
+    h = h + attention("attn2", ln("norm2", h), context)
+    f = F.linear(ln("norm3", h), p[f"{tb}.ff.net.0.proj.weight"], p[f"{tb}.ff.net.0.proj.bias"])
+    val, gate = f.chunk(2, dim=-1)
+    h = h + F.linear(val * F.gelu(gate), p[f"{tb}.ff.net.2.weight"], p[f"{tb}.ff.net.2.bias"])
+    h = h.transpose(1, 2).reshape(b, c, hh, ww)
+    return x + F.conv2d(h, p[name + ".proj_out.weight"], p[name + ".proj_out.bias"])
 
 
 def _adm_xattn(p, name, x, context, cfg):
@@ -250,6 +290,9 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Option
         return v
 
     def attn(name, h):     # self-attention [+ the text cross-attention stage of the stand-in denoisers]
+        if getattr(cfg, "transformer_depth", 0) > 0:
+            ctx = context if context.dim() == 3 else context[None]
+            return _ldm_spatial_transformer(p, name, h, ctx.expand(h.shape[0], -1, -1), cfg)
         h = _adm_attn(p, name, h, cfg)
         if getattr(cfg, "context_dim", 0) > 0:
             ctx = context if context.dim() == 3 else context[None]
@@ -274,7 +317,11 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Option
                 h = rec(f"input_blocks.{ib}.1", attn(f"input_blocks.{ib}.1", h))
             hs.append(h); ib += 1
         if lvl != nlev - 1:
-            h = rec(f"input_blocks.{ib}.0", _adm_resblock(p, f"input_blocks.{ib}.0", h, emb, cfg, down=True))
+            if getattr(cfg, "resblock_updown", True):
+                h = rec(f"input_blocks.{ib}.0", _adm_resblock(p, f"input_blocks.{ib}.0", h, emb, cfg, down=True))
+            else:           # Downsample(use_conv=True): conv3 stride 2 padding 1 -- unet.py:113-142
+                h = rec(f"input_blocks.{ib}.0", F.conv2d(h, p[f"input_blocks.{ib}.0.op.weight"], p[f"input_blocks.{ib}.0.op.bias"],
+                                                         stride=2, padding=1))
             hs.append(h); ib += 1
             res_px //= 2
     h = rec("middle_block.0", _adm_resblock(p, "middle_block.0", h, emb, cfg))
@@ -289,7 +336,12 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Option
             if res_px in cfg.attn_resolutions:
                 h = rec(f"output_blocks.{ob}.{j}", attn(f"output_blocks.{ob}.{j}", h)); j += 1
             if lvl and i == cfg.num_res_blocks:
-                h = rec(f"output_blocks.{ob}.{j}", _adm_resblock(p, f"output_blocks.{ob}.{j}", h, emb, cfg, up=True))
+                if getattr(cfg, "resblock_updown", True):
+                    h = rec(f"output_blocks.{ob}.{j}", _adm_resblock(p, f"output_blocks.{ob}.{j}", h, emb, cfg, up=True))
+                else:       # Upsample(use_conv=True): nearest x2, conv3 -- unet.py:83-110
+                    h = F.interpolate(h, scale_factor=2, mode="nearest")
+                    h = rec(f"output_blocks.{ob}.{j}", F.conv2d(h, p[f"output_blocks.{ob}.{j}.conv.weight"],
+                                                                p[f"output_blocks.{ob}.{j}.conv.bias"], padding=1))
                 res_px *= 2
             ob += 1
     h = F.silu(_adm_gn(p, "out.0", h, cfg))
