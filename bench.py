@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64", "tloco_sd"], default="celeba_top5")
+    ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64", "tloco_sd", "tloco_sd15"], default="celeba_top5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end phase timing (inversion ... decode)")
@@ -366,16 +366,17 @@ def main():
             return u, s, vT, ed.last_n_iter
         return dict(cfg=cfg, k=k, keep=k, eng=ed.engine, params=None, step=step, x=x, mask=~mask, v0=v0, branches=2)
 
-    def make_tloco_sd(prec):
+    def make_tloco_sd(prec, real=False):
         """config 4: CFG-combined subspace solve of the DECODED image's Jacobian w.r.t. the latent (denoiser engines per
-        prompt + decoder engine)."""
+        prompt + decoder engine).  `real`: the Stable Diffusion v1.x denoiser architecture itself (config.SD15_UNET: latent-
+        diffusion UNetModel with SpatialTransformer blocks, 859.5 M parameters, synthetic weights) instead of the stand-in."""
         from argparse import Namespace
-        from loco_edit_amd.config import SD64_XATTN_STANDIN, SD_VAE_DECODER
+        from loco_edit_amd.config import SD15_UNET, SD64_XATTN_STANDIN, SD_VAE_DECODER
         from loco_edit_amd.tloco_sd import EditStableDiffusion
-        cfg, vcfg = SD64_XATTN_STANDIN, SD_VAE_DECODER
+        cfg, vcfg = (SD15_UNET if real else SD64_XATTN_STANDIN), SD_VAE_DECODER
         k = K_PER_GPU * world
         args = Namespace(device=device, dtype=torch.float32, seed=1, unet_config=cfg, vae_config=vcfg, synthetic_weights=0,
-                         ckpt_path="", vae_ckpt_path="", max_batch=8, precision=prec, dataset_name="Random", for_steps=100,
+                         ckpt_path="", vae_ckpt_path="", max_batch=(5 if real else 8), precision=prec, dataset_name="Random", for_steps=100,
                          use_yh_custom_scheduler=True, guidance_scale=7.5, guidance_scale_edit=4.0, prompt_emb=None,
                          prompt_emb_seed=31, cond_dim=64, for_prompt="standin", edit_prompt="standin-edit", edit_t=0.7,
                          sampling_mode=False, tilda_v_score_type="null+(for-null)+(edit-null)", ablation_method="null-space-proj",
@@ -405,6 +406,8 @@ def main():
             return make_tloco(prec)
         if name == "tloco_sd":
             return make_tloco_sd(prec)
+        if name == "tloco_sd15":
+            return make_tloco_sd(prec, real=True)
         if name == "celeba_top5":
             cfg, k, keep = CELEBA_DDPM, K_PER_GPU * world, K_PER_GPU * world
         else:
@@ -589,7 +592,15 @@ def main():
         cpu = cpu_baseline(cfg, w["params"], t)
 
     if rank == 0:
-        if a.workload == "tloco_sd":
+        if a.workload == "tloco_sd15":
+            metric = "edit-directions/sec (top-5 CFG-combined PMP-Jacobian basis of the decoded 512^2 image w.r.t. the 4x64^2 latent, T-LOCO, Stable Diffusion v1.x architecture)"
+            wl = ("T-LOCO latent space on the Stable Diffusion v1.x denoiser ARCHITECTURE (latent-diffusion UNetModel 320x(1,2,4,4), "
+                  "SpatialTransformer blocks with 8 heads at 64/32/16 and in the middle block, 77x768 prompt states, 859.5 M "
+                  "parameters, synthetic weights), mode null+(for-null) guidance 7.5 = 2 branches, + the SD autoencoder's decoder "
+                  "geometry (64 -> 512), l_eye-sized mask on the decoded image, t=0.7T, 12 power iterations, probes sharded 5 per "
+                  f"GPU; per probe-pass {2 * eng.unet_flops() / 1e12:.2f} TFLOP of denoiser + {w['dec'].unet_flops() / 1e12:.2f} TFLOP of decoder")
+            scaling = "weak"
+        elif a.workload == "tloco_sd":
             metric = "edit-directions/sec (top-5 CFG-combined PMP-Jacobian basis of the decoded 512^2 image w.r.t. the 4x64^2 latent, T-LOCO)"
             wl = ("T-LOCO latent space: SD-shaped stand-in denoiser (4x64x64, 320x(1,2,4,4), text cross-attention over 77x768 prompt states behind every attention block, mode null+(for-null) "
                   "guidance 7.5 = 2 branches) + the SD autoencoder's decoder geometry (49.5 M parameters, 64 -> 512), l_eye-sized "

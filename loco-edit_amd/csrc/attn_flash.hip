@@ -18,8 +18,8 @@
 // j = (t&3) + 8(t>>2) + 4*khalf -- a permutation of the contraction index, which the A operand of the second GEMM
 // (records written by THIS kernel's staging) simply adopts.  No LDS round trip for the score tile.
 //
-// Heads of 64 channels (the ADM / IF / SD-shaped denoisers); token counts that are multiples of 128.  Other shapes stay
-// on the generic path.
+// Heads of up to 64 channels (the ADM / IF-shaped denoisers' 64, Stable Diffusion's 40 at its 4096-token level: narrower
+// heads run zero-padded to 64); token counts that are multiples of 128.  Other shapes stay on the generic path.
 #include "kernels.h"
 
 namespace loco {
@@ -54,13 +54,14 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
 // Load and store halves are separate so the streamed block t+1 is in flight (registers) while block t multiplies.
 template <int NTOK> struct TokRegs { float v[(NTOK * 8) / 256][8]; };
 template <int NTOK>
-__device__ __forceinline__ void load_tokens(TokRegs<NTOK>& R, const float* X, int T, int t0, int tid) {
+__device__ __forceinline__ void load_tokens(TokRegs<NTOK>& R, const float* X, int T, int t0, int tid, int nch) {
 #pragma unroll
     for (int it = 0; it < (NTOK * 8) / 256; ++it) {
         const int e = tid + it * 256;
         const int tok = e % NTOK, oct = e / NTOK;              // lanes run over tokens: coalesced 4-byte loads
 #pragma unroll
-        for (int k = 0; k < 8; ++k) R.v[it][k] = X[(long)(oct * 8 + k) * T + t0 + tok];
+        for (int k = 0; k < 8; ++k)                            // heads narrower than 64 channels: the rest of the K dimension is zero
+            R.v[it][k] = (oct * 8 + k < nch) ? X[(long)(oct * 8 + k) * T + t0 + tok] : 0.f;
     }
 }
 template <int NTOK>
@@ -77,18 +78,22 @@ __device__ __forceinline__ void store_tokens(const TokRegs<NTOK>& R, unsigned ch
     }
 }
 template <int NTOK>
-__device__ __forceinline__ void stage_tokens(const float* X, int T, int t0, unsigned char* dst, int tid) {
+__device__ __forceinline__ void stage_tokens(const float* X, int T, int t0, unsigned char* dst, int tid, int nch) {
     TokRegs<NTOK> R;
-    load_tokens<NTOK>(R, X, T, t0, tid);
+    load_tokens<NTOK>(R, X, T, t0, tid, nch);
     store_tokens<NTOK>(R, dst, tid);
 }
 // channel-major records of X[c][t]: 64 channels x tokens t0 .. t0+63 in 4 blocks of 16, the 16 tokens of a record in the
 // D-fragment order j = (t&3) + 8(t>>2) + 4*khalf (slot = khalf*8 + t) -> dst[(jb * 64 + c) * RP]
 struct ChRegs { f32x4a a[4]; };
-__device__ __forceinline__ void load_channels(ChRegs& R, const float* X, int T, int t0, int tid) {
+__device__ __forceinline__ void load_channels(ChRegs& R, const float* X, int T, int t0, int tid, int nch) {
     const int c = tid >> 2, jb = tid & 3;                      // 4 lanes cover 64 consecutive floats of one row
-    const f32x4a* p = reinterpret_cast<const f32x4a*>(X + (long)c * T + t0 + jb * 16);
-    R.a[0] = p[0]; R.a[1] = p[1]; R.a[2] = p[2]; R.a[3] = p[3];   // tokens 0-3, 4-7, 8-11, 12-15
+    if (c < nch) {
+        const f32x4a* p = reinterpret_cast<const f32x4a*>(X + (long)c * T + t0 + jb * 16);
+        R.a[0] = p[0]; R.a[1] = p[1]; R.a[2] = p[2]; R.a[3] = p[3];   // tokens 0-3, 4-7, 8-11, 12-15
+    } else {
+        R.a[0] = R.a[1] = R.a[2] = R.a[3] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    }
 }
 __device__ __forceinline__ void store_channels(const ChRegs& R, unsigned char* dst, int tid) {
     const int c = tid >> 2, jb = tid & 3;
@@ -143,7 +148,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     const int T = a.T, h = blockIdx.y, b = blockIdx.z;
     const int own0 = blockIdx.x * NOWN;            // first own token of the workgroup
     const int mytok = own0 + wave * 32 + l31;      // the lane's own token (column of every D fragment)
-    const long HS = a.hs, HO = (long)CHD * T;
+    const int nch = a.CH;                          // head width (<= 64; narrower heads run zero-padded)
+    const long HS = a.hs, HO = (long)nch * T;
     const float* q = a.q + h * HS;  const float* k = a.k + h * HS;  const float* v = a.v + h * HS;
     const float* P = a.P + (long)h * T * T;
     const float* o = a.o + h * HO;
@@ -156,8 +162,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     Frag y1[4], y2[MODE == M_TAN ? 4 : 1];
     {
         const float* Y1 = MODE == M_TAN ? dq : (MODE == M_COTQ ? go : v);
-        stage_tokens<NOWN>(Y1, T, own0, lds, tid);
-        if (MODE == M_TAN) stage_tokens<NOWN>(q, T, own0, lds + 4 * NOWN * RP, tid);
+        stage_tokens<NOWN>(Y1, T, own0, lds, tid, nch);
+        if (MODE == M_TAN) stage_tokens<NOWN>(q, T, own0, lds + 4 * NOWN * RP, tid, nch);
         __syncthreads();
 #pragma unroll
         for (int ck = 0; ck < 4; ++ck) {
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     float delta_own = 0.f;                          // COTQ: delta_i = <g_o_i, o_i> of the lane's own query
     if (MODE == M_COTQ) {
         float s = 0.f;
-        for (int c = khalf * 32; c < khalf * 32 + 32; ++c) s += go[(long)c * T + mytok] * o[(long)c * T + mytok];
+        for (int c = khalf * 32; c < khalf * 32 + 32 && c < nch; ++c) s += go[(long)c * T + mytok] * o[(long)c * T + mytok];
         s += __shfl_xor(s, 32, 64);
         delta_own = s;
         if (khalf == 0) a.delta[((long)b * a.NH + h) * T + mytok] = s;
@@ -187,14 +193,14 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     float dreg = 0.f;
     auto fetch = [&](int t0) {
         if (MODE == M_TAN) {
-            load_tokens<NBLK>(ta, k, T, t0, tid); load_tokens<NBLK>(tb, dk, T, t0, tid);
-            load_channels(ca, v, T, t0, tid); load_channels(cb, dv, T, t0, tid);
+            load_tokens<NBLK>(ta, k, T, t0, tid, nch); load_tokens<NBLK>(tb, dk, T, t0, tid, nch);
+            load_channels(ca, v, T, t0, tid, nch); load_channels(cb, dv, T, t0, tid, nch);
         } else if (MODE == M_COTQ) {
-            load_tokens<NBLK>(ta, v, T, t0, tid);
-            load_channels(ca, k, T, t0, tid);
+            load_tokens<NBLK>(ta, v, T, t0, tid, nch);
+            load_channels(ca, k, T, t0, tid, nch);
         } else {
-            load_tokens<NBLK>(ta, go, T, t0, tid);
-            load_channels(ca, go, T, t0, tid); load_channels(cb, q, T, t0, tid);
+            load_tokens<NBLK>(ta, go, T, t0, tid, nch);
+            load_channels(ca, go, T, t0, tid, nch); load_channels(cb, q, T, t0, tid, nch);
             if (tid < NBLK) dreg = a.delta[((long)b * a.NH + h) * T + t0 + tid];
         }
     };
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (c >= nch) continue;
             const long off = (long)c * T + mytok;
             if (MODE == M_TAN) {
                 a.out[(long)b * a.bs_out + h * HO + off] = acc[ct][r] - rsum * o[off];
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
 
 }  // namespace
 
-bool attn_flash_supported(int T, int CH) { return CH == CHD && T >= NOWN && (T % NOWN) == 0; }
+bool attn_flash_supported(int T, int CH) { return CH >= 8 && CH <= CHD && T >= NOWN && (T % NOWN) == 0; }
 
 static void attn_flash_launch(int mode, const AttnFlashArgs& a, hipStream_t st) {
     dim3 grid(a.T / NOWN, a.NH, a.B);

@@ -1326,7 +1326,7 @@ void sa_tangent(const SA& s) {       // dq, dk, dv in arenaT(qkv) -> do in arena
     const float scale = 1.0f / std::sqrt((float)CH);
     if (c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH)) {
         AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
-        fa.T = T; fa.NH = NH; fa.B = B; fa.scale = scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = SP; fa.o = oP;
+        fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = SP; fa.o = oP;
         fa.dq = dq; fa.dk = dk; fa.dv = dv; fa.bs_d = PS; fa.out = oT; fa.bs_out = PS;
         launch_attn_flash_tangent(fa, s.st);
         return;
@@ -1360,7 +1360,7 @@ void sa_cotangent(const SA& s) {     // g_o in arenaT(o) -> g_q, g_k, g_v in are
     const float scale = 1.0f / std::sqrt((float)CH);
     if (c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH)) {
         AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
-        fa.T = T; fa.NH = NH; fa.B = B; fa.scale = scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = SP; fa.o = oP;
+        fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = SP; fa.o = oP;
         fa.go = oG; fa.bs_go = PS; fa.gq = gq; fa.gk = gk; fa.gv = gv; fa.bs_g = PS; fa.delta = c->attn_delta;
         launch_attn_flash_cotangent(fa, s.st);
         return;
@@ -1735,7 +1735,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 const bool flash = c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH);
                 if (flash) {        // do from dq, dk, dv and the primal P / o in one kernel, no [T x T] tangent (attn_flash.hip)
                     AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
-                    fa.T = T; fa.NH = NH; fa.B = B; fa.scale = 1.0f / std::sqrt((float)CH);
+                    fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = 1.0f / std::sqrt((float)CH);
                     fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = TP(op.S); fa.o = TP(op.o);
                     fa.dq = dq; fa.dk = dk; fa.dv = dv; fa.bs_d = PS; fa.out = TT(op.o); fa.bs_out = PS;
                     launch_attn_flash_tangent(fa, st);
@@ -1999,7 +1999,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 const bool flash = c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH);
                 if (flash) {        // g_q, g_k, g_v from g_o and the primal q / k / v / P / o, no [T x T] cotangent (attn_flash.hip)
                     AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
-                    fa.T = T; fa.NH = NH; fa.B = B; fa.scale = 1.0f / std::sqrt((float)CH);
+                    fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = 1.0f / std::sqrt((float)CH);
                     fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = TP(op.S); fa.o = TP(op.o);
                     fa.go = TG(op.o); fa.bs_go = PS; fa.gq = gq; fa.gk = gk; fa.gv = gv; fa.bs_g = PS; fa.delta = c->attn_delta;
                     launch_attn_flash_cotangent(fa, st);
@@ -2211,7 +2211,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         c->flash_attn = !(fa && atoi(fa) == 0);
         long dmax = 1;
         for (const Op& op : c->ops)
-            if (op.kind == OP_ATTN) dmax = std::max(dmax, (long)op.heads * c->tens[op.in].H * c->tens[op.in].W);
+            if (op.kind == OP_ATTN || op.kind == OP_XFMR) dmax = std::max(dmax, (long)op.heads * c->tens[op.in].H * c->tens[op.in].W);
         if (dalloc(c, &c->attn_delta, MB * (size_t)dmax)) return -1;
     }
     c->partial_floats = (size_t)64 << 20;   // 256 MB split-K workspace

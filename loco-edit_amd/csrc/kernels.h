@@ -110,7 +110,7 @@ bool gemm_prefers_bf16x3(const GemmArgs& g);                      // long contra
 // All tensors [channel][token] with the engine's strides; q / k / v (and their tangents / cotangents) of head h start
 // hs floats apart, o (and do / g_o) CH * T floats apart.  Primal q, k, v, P = softmax(scale q^T k) [NH][T][T], o = v P^T: B = 1.
 struct AttnFlashArgs {
-    int T, NH, B; float scale;
+    int T, NH, B, CH; float scale;             // CH: channels per head (<= 64)
     const float *q, *k, *v; long hs;
     const float* P;
     const float* o;
@@ -120,7 +120,7 @@ struct AttnFlashArgs {
     float *gq, *gk, *gv; long bs_g;           // cotangent results per probe
     float* delta;                             // scratch [B][NH][T]: delta_i = <g_o_i, o_i>
 };
-bool attn_flash_supported(int T, int CH);     // heads of 64 channels, token counts that are multiples of 128
+bool attn_flash_supported(int T, int CH);     // heads of <= 64 channels, token counts that are multiples of 128
 void launch_attn_flash_tangent(const AttnFlashArgs& a, hipStream_t st);
 void launch_attn_flash_cotangent(const AttnFlashArgs& a, hipStream_t st);
 

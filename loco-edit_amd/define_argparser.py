@@ -77,7 +77,8 @@ _FLAGS = [
 _UNET_PRESETS = {'celeba_ddpm': 'CELEBA_DDPM', 'ffhq_p2': 'FFHQ_P2', 'tiny_ddpm': 'TINY_DDPM', 'mid_ddpm': 'MID_DDPM',
                  'tiny_adm': 'TINY_ADM', 'if64_standin': 'IF64_STANDIN', 'sd64_standin': 'SD64_STANDIN',
                  'sd64_xattn_standin': 'SD64_XATTN_STANDIN', 'tiny_latent': 'TINY_LATENT', 'tiny_latent_xattn': 'TINY_LATENT_XATTN',
-                 'if64_xattn_standin': 'IF64_XATTN_STANDIN', 'tiny_adm_xattn': 'TINY_ADM_XATTN'}
+                 'if64_xattn_standin': 'IF64_XATTN_STANDIN', 'tiny_adm_xattn': 'TINY_ADM_XATTN', 'sd15_unet': 'SD15_UNET',
+                 'tiny_ldm': 'TINY_LDM'}
 _VAE_PRESETS = {'sd_vae_decoder': 'SD_VAE_DECODER', 'tiny_decoder': 'TINY_DECODER'}
 _TILDA_V = ["proj_null[for-null](edit-null)-direct", "(for-edit)-direct", "(edit-null)-direct",
             "null+(for-null)+(edit-null)", "null+(for-null)", "null+(edit-null)", "(for-edit)",
@@ -208,7 +209,9 @@ def _preset_t2i(args, family):
     from . import config
     if args.is_stable_diffusion:
         if getattr(args, 'unet_config', None) is None:
-            args.unet_config = config.SD64_XATTN_STANDIN      # latent U-Net with text cross-attention (BASELINE config 4)
+            # the Stable Diffusion v1.x denoiser (latent-diffusion UNetModel with SpatialTransformer blocks, 859.5 M
+            # parameters; BASELINE config 4).  `--unet_preset sd64_xattn_standin` selects the round-2 stand-in
+            args.unet_config = config.SD15_UNET
         if getattr(args, 'vae_config', None) is None:
             args.vae_config = config.SD_VAE_DECODER
         args.c_in = args.unet_config.in_channels           # 4

@@ -843,22 +843,27 @@ def test_statistics_fused_into_epilogues_equal_the_standalone_kernels(cfg, monke
     assert max(errs[:6]) < 3e-5 and max(errs[6:]) < 3e-3, errs
 
 
+@pytest.mark.parametrize("which", ["adm64", "ldm40"])
 @pytest.mark.parametrize("prec", ["bf16x3", "f16"])
-def test_flash_attention_tangent_and_cotangent(prec, monkeypatch):
+def test_flash_attention_tangent_and_cotangent(prec, which, monkeypatch):
     """The tangent and cotangent of the multi-head attention blocks without per-probe [T x T] matrices (attn_flash.hip:
     64-channel heads, 1024 and 256 tokens here) against (1) autodiff of the CPU restatement of the reference network
     (guided_diffusion/unet.py:330-356 under jvp / grad) and (2) the generic GEMM + softmax-Jacobian path of the same engine
     (LOCO_FLASH_ATTN=0); adjointness of the pair."""
-    from loco_edit_amd.config import FLASH_ADM as cfg
+    from loco_edit_amd.config import FLASH_ADM, FLASH_LDM
     from loco_edit_amd.hip import LocoEngine
+    # adm64: AttentionBlock, 64-channel heads, 1024 and 256 tokens; ldm40: SpatialTransformer, 40-channel heads (zero-padded
+    # to the kernel's 64), 256 tokens
+    cfg = FLASH_ADM if which == "adm64" else FLASH_LDM
     params = synth_params(cfg, 0)
     p = orc.to_torch(params)
     gen = torch.Generator().manual_seed(17)
-    x = torch.randn(1, 3, 32, 32, generator=gen)
+    x = torch.randn(1, cfg.in_channels, cfg.resolution, cfg.resolution, generator=gen)
     t = torch.tensor(603.0)
     V = torch.randn(3, cfg.n, generator=gen)
     Uc = torch.randn(3, cfg.n, generator=gen)
-    f = lambda x_: orc.unet_forward_adm(p, cfg, x_, t)
+    ctx = torch.randn(cfg.context_len, cfg.context_dim, generator=gen) if cfg.context_dim else None
+    f = lambda x_: orc.unet_forward_adm(p, cfg, x_, t, context=ctx)
     JV = torch.stack([torch.func.jvp(f, (x,), (v.view_as(x),))[1].reshape(-1) for v in V])
     xx = x.clone().requires_grad_(True)
     out = f(xx).reshape(-1)
@@ -869,6 +874,8 @@ def test_flash_attention_tangent_and_cotangent(prec, monkeypatch):
         eng = LocoEngine(cfg, max_batch=4, device=torch.device(DEV))
         eng.load_state_dict(params)
         eng.set_precision(prec)
+        if ctx is not None:
+            eng.set_context(ctx.to(DEV).contiguous())
         eng.pmp_primal(x.to(DEV), float(t), 0.5, None, use_et=True)
         U = eng.pmp_jvp(V.to(DEV))
         A = eng.pmp_vjp(Uc.to(DEV))
