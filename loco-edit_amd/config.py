@@ -112,6 +112,11 @@ TINY_ADM_XATTN = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blo
                             gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True, context_dim=16, context_len=7)
 TINY_ADM = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,),
                       gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True)
+# the same guided-diffusion UNetModel with `use_scale_shift_norm=False, resblock_updown=False` (additive embedding, conv
+# down / up-sampling): the skeleton of the latent-diffusion denoiser, pinned against the reference's own class
+TINY_ADM_PLAIN = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,),
+                            gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=True, scale_shift_norm=False,
+                            resblock_updown=False)
 # 64-channel heads over 1024 and 256 tokens on a network the CPU oracle differentiates in seconds (flash attention tests)
 FLASH_ADM = UNetConfig(resolution=32, ch=64, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(32, 16), gn_eps=1e-5,
                        arch="adm", num_head_channels=64, learn_sigma=True)

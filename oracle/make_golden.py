@@ -79,7 +79,8 @@ def ref_model_adm(cfg, params):
     m = UNetModel(image_size=cfg.resolution, in_channels=3, model_channels=cfg.ch,
                   out_channels=6 if cfg.learn_sigma else 3, num_res_blocks=cfg.num_res_blocks,
                   attention_resolutions=ds, dropout=0, channel_mult=tuple(cfg.ch_mult),
-                  num_head_channels=cfg.num_head_channels, use_scale_shift_norm=True, resblock_updown=True)
+                  num_head_channels=cfg.num_head_channels, use_scale_shift_norm=bool(getattr(cfg, "scale_shift_norm", True)),
+                  resblock_updown=bool(getattr(cfg, "resblock_updown", True)))
     m.device = torch.device("cpu")
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
     m.eval()
@@ -144,7 +145,8 @@ def gen_for_config(tag, cfg, redit, YHS, PullBackDDPM, k, k_null, n_iter, mrect,
     out = {"cfg": dict(resolution=cfg.resolution, ch=cfg.ch, ch_mult=tuple(cfg.ch_mult),
                        num_res_blocks=cfg.num_res_blocks, attn_resolutions=tuple(cfg.attn_resolutions),
                        arch=cfg.arch, num_head_channels=cfg.num_head_channels, learn_sigma=cfg.learn_sigma,
-                       gn_eps=cfg.gn_eps),
+                       gn_eps=cfg.gn_eps, scale_shift_norm=getattr(cfg, "scale_shift_norm", True),
+                       resblock_updown=getattr(cfg, "resblock_updown", True)),
            "weights_seed": 0}
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, cfg.in_channels, cfg.resolution, cfg.resolution, generator=g)
@@ -429,6 +431,12 @@ def main():
         o = gen_for_config("tiny_adm", TINY_ADM, redit, YHS, PullBackDDPM, k=4, k_null=0, n_iter=12,
                            mrect=(12, 20, 8, 18), tmpdir=tmpdir, pipeline=False)
         torch.save(o, os.path.join(GOLD, "tiny_adm.pt"))
+    if not a.only or a.only == "tiny_adm_plain":
+        print("tiny guided-diffusion config without scale-shift norm, conv down / up-sampling (the latent-diffusion skeleton)")
+        from loco_edit_amd.config import TINY_ADM_PLAIN
+        o = gen_for_config("tiny_adm_plain", TINY_ADM_PLAIN, redit, YHS, PullBackDDPM, k=4, k_null=0, n_iter=3,
+                           mrect=(12, 20, 8, 18), tmpdir=tmpdir, pipeline=False)
+        torch.save(o, os.path.join(GOLD, "tiny_adm_plain.pt"))
     if a.only == "p2_256":
         print("full FFHQ-P2 config (256x256)")
         o = gen_for_config("p2_256", FFHQ_P2, redit, YHS, PullBackDDPM, k=4, k_null=0, n_iter=0,

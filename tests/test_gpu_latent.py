@@ -225,10 +225,12 @@ def test_latent_drivers_end_to_end(golden, tmp_path):
     assert tuple(xs.shape) == (1, 64, 64, 3)
 
 
-def test_cli_shipped_sd_script_on_the_standins(tmp_path, monkeypatch):
+@pytest.mark.parametrize("unet", ["tiny_latent", "tiny_ldm"])
+def test_cli_shipped_sd_script_on_the_standins(unet, tmp_path, monkeypatch):
     """`python -m loco_edit_amd.main` with the argument list of scripts/main_T2I_StableDiffusion_null_space_projection.sh
     (tests/golden/script_args.json) plus the deployment flags that replace what is out of scope (architecture presets,
-    synthetic weights; SAM masks come from mask.pt)."""
+    synthetic weights; SAM masks come from mask.pt).  `tiny_ldm` = the Stable Diffusion v1 denoiser layout (SpatialTransformer
+    blocks, prompt states through cross-attention) at test size; without --unet_preset the CLI builds config.SD15_UNET."""
     import json
     from loco_edit_amd.main import main
     argv = json.load(open(os.path.join(ROOT, "tests", "golden", "script_args.json")))["main_T2I_StableDiffusion_null_space_projection.sh"]
@@ -240,7 +242,7 @@ def test_cli_shipped_sd_script_on_the_standins(tmp_path, monkeypatch):
     masks = torch.zeros(3, 1, 64, 64, dtype=torch.bool)
     masks[1, 0, 20:40, 12:44] = True
     torch.save(masks, str(rdir / "mask" / "mask.pt"))
-    lat, x0 = main(argv + ["--device", DEV, "--unet_preset", "tiny_latent", "--vae_preset", "tiny_decoder", "--synthetic_weights", "0"])
+    lat, x0 = main(argv + ["--device", DEV, "--unet_preset", unet, "--vae_preset", "tiny_decoder", "--synthetic_weights", "0"])
     assert x0.dtype == torch.uint8 and tuple(x0.shape) == (3, 64, 64, 3)      # vis_num 1: frames -S, 0, +S
     sdir = rdir / "basis" / 'local_basis-0.7T-"a photo of a man wearing glasses"-pca-rank-1-select-mask1'
     v = torch.load(str(sdir / "vT-modify.pt"))

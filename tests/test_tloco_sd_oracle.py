@@ -70,8 +70,13 @@ def test_preset_routes_stable_diffusion_to_the_latent_path(tmp_path, monkeypatch
     a = define_argparser.preset(a)
     assert a.is_stable_diffusion and not a.is_DeepFloyd_IF_diffusion and not a.is_LCM
     assert a.exp == "Stable_Diffusion-Random-n" and (a.c_in, a.image_size, a.memory_bound) == (4, 64, 5)
-    assert a.unet_config is SD64_XATTN_STANDIN and a.vae_config is SD_VAE_DECODER
+    from loco_edit_amd.config import SD15_UNET
+    assert a.unet_config is SD15_UNET and a.vae_config is SD_VAE_DECODER      # the Stable Diffusion v1 denoiser architecture
     assert (a.unet_config.context_len, a.unet_config.context_dim) == (77, 768)
+    assert (a.unet_config.transformer_depth, a.unet_config.num_heads, a.unet_config.scale_shift_norm) == (1, 8, False)
+    c = define_argparser.parse_args(["--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Random", "--note", "n",
+                                     "--seed", "3", "--device", "cpu", "--unet_preset", "sd64_xattn_standin"])
+    assert define_argparser.preset(c).unet_config is SD64_XATTN_STANDIN            # the round-2 stand-in stays selectable
     b = define_argparser.parse_args(["--model_name", "SimianLuo/LCM_Dreamshaper_v7", "--seed", "3", "--device", "cpu"])
     with pytest.raises(NotImplementedError):
         define_argparser.preset(b)
