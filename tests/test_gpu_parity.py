@@ -58,12 +58,12 @@ def _sched():
     return s
 
 
-@pytest.mark.parametrize("prec", PRECS)
 def _fwd_cfgs():
     from loco_edit_amd.config import TINY_ADM_PLAIN
     return [("tiny", TINY_DDPM), ("mid", MID_DDPM), ("tiny_adm", TINY_ADM), ("tiny_adm_plain", TINY_ADM_PLAIN)]
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("tag,cfg", _fwd_cfgs())
 def test_forward_jvp_vjp_vs_golden(tag, cfg, prec, engines, golden):
     g = golden(tag)
