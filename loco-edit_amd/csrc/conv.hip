@@ -383,9 +383,48 @@ void launch_conv(const ConvArgs& a, int taps, hipStream_t st) {
     }
 }
 
+// the same with 16 bytes per thread and four slab loads in flight (planes are multiples of 4 floats from 8x8 on)
+typedef float f32x4_r __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void conv_splitk_reduce4(ConvArgs a, long total) {
+    const long out_plane = (long)a.Hout * a.Wout;
+    const long per_b = (long)a.Cout * out_plane;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (long)gridDim.x * blockDim.x * 4) {
+        const int b = (int)(i / per_b);
+        const long rem = i - (long)b * per_b;
+        const int co = (int)(rem / out_plane);
+        f32x4_r v = {0.f, 0.f, 0.f, 0.f};
+        const float* pp = a.partial + i;
+        int s = 0;
+        for (; s + 4 <= a.nsplit; s += 4) {
+            const f32x4_r p0 = *reinterpret_cast<const f32x4_r*>(pp + (long)s * total);
+            const f32x4_r p1 = *reinterpret_cast<const f32x4_r*>(pp + (long)(s + 1) * total);
+            const f32x4_r p2 = *reinterpret_cast<const f32x4_r*>(pp + (long)(s + 2) * total);
+            const f32x4_r p3 = *reinterpret_cast<const f32x4_r*>(pp + (long)(s + 3) * total);
+            v += (p0 + p1) + (p2 + p3);
+        }
+        for (; s < a.nsplit; ++s) v += *reinterpret_cast<const f32x4_r*>(pp + (long)s * total);
+        float add = 0.f;
+        if (a.bias) add += a.bias[co];
+        if (a.bias2) add += a.bias2[(long)b * a.bias2_bs + co];
+        v += add;
+        if (a.res) v += *reinterpret_cast<const f32x4_r*>(a.res + (long)b * a.res_bs + rem);
+        float* o = a.out + (long)b * a.out_bs + rem;
+        if (a.accumulate) v += *reinterpret_cast<const f32x4_r*>(o);
+        *reinterpret_cast<f32x4_r*>(o) = v;
+    }
+}
+
 void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st) {
     if (a.nsplit > 1) {
         long total = (long)a.B * a.Cout * a.Hout * a.Wout;
+        const bool vec = ((a.Hout * a.Wout) % 4) == 0 && (a.out_bs % 4) == 0 && (a.res_bs % 4) == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.out) % 16) == 0 && (reinterpret_cast<uintptr_t>(a.res) % 16) == 0;
+        if (vec) {
+            int blocks = (int)((total / 4 + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(conv_splitk_reduce4, dim3(blocks), dim3(256), 0, st, a, total);
+            return;
+        }
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(conv_splitk_reduce, dim3(blocks), dim3(256), 0, st, a, total);

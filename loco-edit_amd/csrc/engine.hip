@@ -1197,6 +1197,10 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     };
     if (rq && rq->kind != ST_NONE) rq->n->ready = true;
     if (!tail_probes) { one(a, 0); return; }
+    // tail-probe split: two launches finish the tensor; their statistics are taken once over the whole batch behind them
+    // (separate statistics for the few tail probes would add a reduce-with-statistics and a finalize launch per conv)
+    const StatReq* rq_all = (rq && rq->kind != ST_NONE) ? rq : nullptr;
+    rq = nullptr;
     ConvArgs m = a, t = a;
     const int nb = a.B - tail_probes;
     m.B = nb;
@@ -1211,6 +1215,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     if (t.tc) t.tc += (long)nb * a.tc_bs;
     one(m, 0);
     one(t, nb);
+    if (rq_all) stats_standalone(c, *rq_all, a.out, a.out_bs, a.B, HWo, 0, st);
 }
 
 inline void setw(ConvArgs& a, const ConvP& p, bool dgrad) {
