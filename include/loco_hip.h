@@ -50,7 +50,11 @@ typedef struct loco_unet_cfg {
      * up levels of num_res_blocks+1 ResnetBlocks + nearest-x2 conv, norm_out/SiLU/conv_out; no skips, no time
      * embedding.  `resolution` is the latent resolution, the output is [out_ch, resolution << (num_levels-1), same];
      * loco_unet_forward ignores t; loco_pmp_primal needs use_et = 1 (raw network Jacobian, mask on the OUTPUT) and
-     * loco_pmp_jvp / _vjp then map [k, in] -> [k, out] / [k, out] -> [k, in]; loco_ddim_step is refused */
+     * loco_pmp_jvp / _vjp then map [k, in] -> [k, out] / [k, out] -> [k, in]; loco_ddim_step is refused;
+     * 3: latent encoder -- the network behind `self.vae.encode(x0).latent_dist` of the latent inversion
+     * (src/modules/edit.py:594-597): conv_in, down levels of num_res_blocks ResnetBlocks + pad (0,1,0,1) conv stride 2,
+     * mid block/attn/block, norm_out/SiLU/conv_out, 1x1 quant_conv.  `resolution` is the IMAGE resolution, the output is
+     * the posterior's moments [out_ch = 2 z, resolution >> (num_levels-1), same]; used through loco_unet_forward (t ignored) */
     int32_t arch;
     int32_t num_head_channels; /* arch 1: channels per attention head (P2: 64) */
     int32_t learn_sigma;       /* arch 1: the head emits 2*out_ch channels, eps = first out_ch (unet.py:680-684) */
@@ -202,6 +206,11 @@ int  loco_set_cond(loco_ctx* ctx, const float* emb_add, void* stream);
  * CFG combination assembled by the caller.  V, E: [k, n]; out may alias either. */
 int  loco_masked_axpby(loco_ctx* ctx, const float* V, const float* E, float cv, float ce, int32_t k, float* out,
                        void* stream);
+/* Latent encoder contexts (arch 3): z[B, Z, h, w] = scale * (mean + exp(0.5 clamp(logvar, -30, 20)) * noise) from the
+ * moments [B, 2 Z, h, w] loco_unet_forward returned (mean | logvar) -- `self.vae.encode(x0).latent_dist.sample() * 0.18215`
+ * of the latent inversion (src/modules/edit.py:594-597; DiagonalGaussianDistribution of diffusers, un-vendored).
+ * noise: [B, Z, h, w] standard normal, or NULL for the posterior mean (`.mode()`). */
+int  loco_latent_sample(loco_ctx* ctx, const float* moments, const float* noise, float scale, int32_t B, float* z, void* stream);
 /* out = sum_{i<n} coef[i] * src[i], n <= 4: the classifier-free-guidance combination of eps / J V / J^T U terms of
  * several conditions (edit.py:1324-1372).  src: host array of device pointers, coef: host array; out may alias a src. */
 /* Encoder states of the prompt for the cross-attention stages (context_dim > 0): tokens = device pointer to

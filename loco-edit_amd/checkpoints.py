@@ -207,3 +207,79 @@ def decoder_to_hf_autoencoder_kl(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -
                     v = v.reshape(v.shape[0], v.shape[1])
                 out[f"decoder.mid_block.attentions.0.{inv_attn[p[2]]}.{suffix}"] = v
     return out
+
+
+def hf_autoencoder_kl_to_encoder(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """diffusers AutoencoderKL state_dict -> the encoder engine's naming (arch "enc": `quant_conv` + `encoder.*`, the half
+    behind `vae.encode` of the latent inversion, reference edit.py:594-597).  Key map written from the published layout
+    (`encoder.down_blocks.L.resnets.B`, `.downsamplers.0.conv`, `mid_block`, `conv_norm_out`), unpinned like the decoder's."""
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        p = k.split(".")
+        suffix = p[-1]
+        if p[0] == "quant_conv":
+            out[k] = v
+            continue
+        if p[0] != "encoder":
+            continue                                    # decoder.*, post_quant_conv.*: the other half
+        p = p[1:]
+        if p[0] in ("conv_in", "conv_out"):
+            out[".".join(p)] = v
+        elif p[0] == "conv_norm_out":
+            out[f"norm_out.{suffix}"] = v
+        elif p[0] == "down_blocks":
+            if p[2] == "resnets":
+                out[f"down.{p[1]}.block.{p[3]}.{_RES[p[4]]}.{suffix}"] = v
+            elif p[2] == "downsamplers":
+                out[f"down.{p[1]}.downsample.conv.{suffix}"] = v
+            else:
+                raise KeyError(k)
+        elif p[0] == "mid_block":
+            if p[1] == "resnets":
+                out[f"mid.block_{int(p[2]) + 1}.{_RES[p[3]]}.{suffix}"] = v
+            elif p[1] == "attentions":
+                name = _ATTN[".".join(p[3:-1])]
+                if name != "norm" and suffix == "weight" and v.dim() == 2:
+                    v = v[:, :, None, None]             # nn.Linear [C,C] -> 1x1 conv
+                out[f"mid.attn_1.{name}.{suffix}"] = v
+            else:
+                raise KeyError(k)
+        else:
+            raise KeyError(f"unexpected key {k}")
+    want = param_shapes(cfg)
+    missing = [n for n in want if n not in out]
+    if missing:
+        raise KeyError(f"{len(missing)} encoder parameters missing after conversion, first: {missing[0]}")
+    for n, shp in want.items():
+        if tuple(out[n].shape) != tuple(shp):
+            raise ValueError(f"shape mismatch for {n}: {tuple(out[n].shape)} vs {tuple(shp)}")
+    return {n: out[n] for n in want}
+
+
+def encoder_to_hf_autoencoder_kl(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """Inverse of ``hf_autoencoder_kl_to_encoder`` (round-trip test; export), attention projections as nn.Linear."""
+    inv_res = {v: k for k, v in _RES.items()}
+    inv_attn = {"norm": "group_norm", "q": "to_q", "k": "to_k", "v": "to_v", "proj_out": "to_out.0"}
+    out = {}
+    for k, v in sd.items():
+        p = k.split(".")
+        suffix = p[-1]
+        if p[0] == "quant_conv":
+            out[k] = v
+        elif p[0] in ("conv_in", "conv_out"):
+            out["encoder." + k] = v
+        elif p[0] == "norm_out":
+            out[f"encoder.conv_norm_out.{suffix}"] = v
+        elif p[0] == "down":
+            if p[2] == "block":
+                out[f"encoder.down_blocks.{p[1]}.resnets.{p[3]}.{inv_res[p[4]]}.{suffix}"] = v
+            elif p[2] == "downsample":
+                out[f"encoder.down_blocks.{p[1]}.downsamplers.0.conv.{suffix}"] = v
+        elif p[0] == "mid":
+            if p[1].startswith("block_"):
+                out[f"encoder.mid_block.resnets.{int(p[1][-1]) - 1}.{inv_res[p[2]]}.{suffix}"] = v
+            else:
+                if p[2] != "norm" and suffix == "weight":
+                    v = v.reshape(v.shape[0], v.shape[1])
+                out[f"encoder.mid_block.attentions.0.{inv_attn[p[2]]}.{suffix}"] = v
+    return out

@@ -62,7 +62,11 @@ class UNetConfig:
 
     @property
     def out_resolution(self) -> int:
-        return self.resolution << (len(self.ch_mult) - 1) if self.arch == "dec" else self.resolution
+        if self.arch == "dec":
+            return self.resolution << (len(self.ch_mult) - 1)
+        if self.arch == "enc":          # image -> moments of the latent posterior, `resolution` = the IMAGE resolution
+            return self.resolution >> (len(self.ch_mult) - 1)
+        return self.resolution
 
     @property
     def n_out(self) -> int:
@@ -93,6 +97,11 @@ SD64_STANDIN = UNetConfig(resolution=64, in_channels=4, out_ch=4, ch=320, ch_mul
                           attn_resolutions=(32, 16, 8), gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=False)
 SD_VAE_DECODER = UNetConfig(resolution=64, in_channels=4, out_ch=3, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
                             attn_resolutions=(), gn_eps=1e-6, arch="dec")
+# the encoder half of the same autoencoder (`vae.encode`, edit.py:594-597): 3 x 512 x 512 image -> 8 x 64 x 64 moments
+SD_VAE_ENCODER = UNetConfig(resolution=512, in_channels=3, out_ch=8, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
+                            attn_resolutions=(), gn_eps=1e-6, arch="enc")
+TINY_ENCODER = UNetConfig(resolution=64, in_channels=3, out_ch=8, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1,
+                          attn_resolutions=(), gn_eps=1e-6, arch="enc")
 TINY_LATENT = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=32, ch_mult=(1, 2), num_res_blocks=1,
                          attn_resolutions=(8,), gn_eps=1e-5, arch="adm", num_head_channels=16, learn_sigma=False)
 TINY_DECODER = UNetConfig(resolution=16, in_channels=4, out_ch=3, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1,
@@ -233,6 +242,47 @@ def adm_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     return shapes
 
 
+def enc_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict layout of the latent-diffusion ``Encoder`` (the network behind ``vae.encode`` of the reference's Stable
+    Diffusion inversion, edit.py:594-597): ``conv_in``, ``down.L.block.B.{norm1,conv1,norm2,conv2,nin_shortcut}``,
+    ``down.L.downsample.conv`` (stride 2 behind a (0,1,0,1) pad), ``mid.{block_1,attn_1,block_2}``, ``norm_out``, ``conv_out``
+    (2 * z channels: mean and log-variance), followed by the autoencoder's 1x1 ``quant_conv``.  ``out_ch`` = 2 * z channels."""
+    shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def conv(name, cin, cout, k):
+        shapes[name + ".weight"] = (cout, cin, k, k); shapes[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        shapes[name + ".weight"] = (c,); shapes[name + ".bias"] = (c,)
+
+    def resblock(name, cin, cout):
+        norm(name + ".norm1", cin); conv(name + ".conv1", cin, cout, 3)
+        norm(name + ".norm2", cout); conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".nin_shortcut", cin, cout, 1)
+
+    ch, mult = cfg.ch, tuple(cfg.ch_mult)
+    in_mult = (1,) + mult
+    conv("conv_in", cfg.in_channels, ch, 3)
+    block_in = ch
+    for lvl in range(len(mult)):
+        block_in, block_out = ch * in_mult[lvl], ch * mult[lvl]
+        for b in range(cfg.num_res_blocks):
+            resblock(f"down.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+        if lvl != len(mult) - 1:
+            conv(f"down.{lvl}.downsample.conv", block_in, block_in, 3)
+    resblock("mid.block_1", block_in, block_in)
+    norm("mid.attn_1.norm", block_in)
+    for q in ("q", "k", "v", "proj_out"):
+        conv("mid.attn_1." + q, block_in, block_in, 1)
+    resblock("mid.block_2", block_in, block_in)
+    norm("norm_out", block_in)
+    conv("conv_out", block_in, cfg.out_ch, 3)
+    conv("quant_conv", cfg.out_ch, cfg.out_ch, 1)
+    return shapes
+
+
 def param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     """Ordered name -> shape map following the constructor order of the
     reference module tree (``diffusion.py:41-126``)."""
@@ -240,6 +290,8 @@ def param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
         return adm_param_shapes(cfg)
     if cfg.arch == "dec":
         return dec_param_shapes(cfg)
+    if cfg.arch == "enc":
+        return enc_param_shapes(cfg)
     shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
 
     def lin(name, cin, cout):

@@ -246,11 +246,13 @@ bool attn_at(const loco_unet_cfg& cfg, int res) {
 
 int build_program_adm(loco_ctx* c);
 int build_program_dec(loco_ctx* c);
+int build_program_enc(loco_ctx* c);
 
 // Build the op list + memory plan (mirrors DDPM.__init__/forward, reference diffusion.py:22-200)
 int build_program(loco_ctx* c) {
     if (c->cfg.arch == 1) return build_program_adm(c);
     if (c->cfg.arch == 2) return build_program_dec(c);
+    if (c->cfg.arch == 3) return build_program_enc(c);
     const loco_unet_cfg& cfg = c->cfg;
     const int ch = cfg.ch, nres = cfg.num_levels, R = cfg.resolution;
     c->n_in = cfg.in_channels * R * R;
@@ -704,6 +706,90 @@ int build_program_dec(loco_ctx* c) {
     return 0;
 }
 
+// Latent encoder (arch 3): `vae.encode` of the reference's latent inversion (edit.py:594-597; diffusers AutoencoderKL =
+// the latent-diffusion `Encoder` + `quant_conv`, un-vendored): conv_in at the image resolution R; per level num_res_blocks
+// embedding-free ResnetBlocks and, except on the last level, pad (0,1,0,1) + conv3 stride 2; mid block / attention / block;
+// norm_out, SiLU, conv_out (2 z channels: mean | log-variance), 1x1 quant_conv.  Output [out_ch, R >> (levels-1), same].
+int build_program_enc(loco_ctx* c) {
+    const loco_unet_cfg& cfg = c->cfg;
+    const int ch = cfg.ch, nlev = cfg.num_levels, R = cfg.resolution;
+    const int Rout = R >> (nlev - 1);
+    c->n_in = cfg.in_channels * R * R;
+    c->n_out = cfg.out_ch * Rout * Rout;
+    auto add_res = [&](const std::string& name, int in_t, int cout) {
+        Op r; r.kind = OP_RES; r.name = name; r.in = in_t; r.has_temb = false;
+        const Tens ti = c->tens[in_t];
+        r.has_nin = (ti.C != cout);
+        r.out = new_tensor(c, cout, ti.H, ti.W);
+        r.h1 = new_tensor(c, cout, ti.H, ti.W);
+        r.a1 = new_tensor(c, ti.C, ti.H, ti.W);
+        r.n1 = new_norm(c, ti.C); r.n2 = new_norm(c, cout);
+        c->ops.push_back(r);
+        return r.out;
+    };
+    int res = R, cur;
+    {
+        Op o; o.kind = OP_CONV_IN; o.name = "conv_in"; o.in = -1; o.out = new_tensor(c, ch, res, res);
+        c->ops.push_back(o);
+        cur = o.out;
+    }
+    for (int l = 0; l < nlev; ++l) {
+        const int block_out = ch * cfg.ch_mult[l];
+        for (int b = 0; b < cfg.num_res_blocks; ++b)
+            cur = add_res("down." + std::to_string(l) + ".block." + std::to_string(b), cur, block_out);
+        if (l != nlev - 1) {
+            Op d; d.kind = OP_DOWN; d.name = "down." + std::to_string(l) + ".downsample.conv"; d.in = cur;
+            d.out = new_tensor(c, block_out, res / 2, res / 2);
+            c->ops.push_back(d);
+            cur = d.out; res /= 2;
+        }
+    }
+    const int block_in = c->tens[cur].C;
+    cur = add_res("mid.block_1", cur, block_in);
+    {
+        Op a; a.kind = OP_ATTN; a.name = "mid.attn_1"; a.in = cur;
+        const Tens t = c->tens[cur];
+        const int T = t.H * t.W;
+        a.out = new_tensor(c, t.C, t.H, t.W);
+        a.hn = new_tensor(c, t.C, t.H, t.W);
+        a.qkv = new_tensor(c, 3 * t.C, t.H, t.W);
+        a.S = new_tensor(c, 1, T, T);
+        a.o = new_tensor(c, t.C, t.H, t.W);
+        a.n1 = new_norm(c, t.C);
+        c->ops.push_back(a);
+        cur = a.out;
+    }
+    cur = add_res("mid.block_2", cur, block_in);
+    {
+        Op o; o.kind = OP_OUT; o.name = "conv_out"; o.in = cur;
+        o.out = new_tensor(c, cfg.out_ch, Rout, Rout);
+        o.a1 = new_tensor(c, c->tens[cur].C, Rout, Rout);
+        o.n1 = new_norm(c, c->tens[cur].C);
+        c->ops.push_back(o);
+        Op q; q.kind = OP_CONV; q.name = "quant_conv"; q.ksize = 1; q.in = o.out; q.out = new_tensor(c, cfg.out_ch, Rout, Rout);
+        c->ops.push_back(q);
+        c->eps_t = q.out;
+    }
+    for (auto& op : c->ops) {
+        if (op.kind == OP_RES) {
+            const Tens& ti = c->tens[op.in];
+            norm_cache(c, op.n1, ti.H * ti.W);
+            norm_cache(c, op.n2, ti.H * ti.W);
+            op.pn_n1 = op.name + ".norm1"; op.pn_c1 = op.name + ".conv1";
+            op.pn_n2 = op.name + ".norm2"; op.pn_c2 = op.name + ".conv2"; op.pn_skip = op.name + ".nin_shortcut";
+        } else if (op.kind == OP_ATTN) {
+            op.pn_n1 = op.name + ".norm"; op.pn_proj = op.name + ".proj_out";
+        } else if (op.kind == OP_OUT) {
+            const Tens& ti = c->tens[op.in];
+            norm_cache(c, op.n1, ti.H * ti.W);
+            op.pn_n1 = "norm_out"; op.pn_conv = "conv_out";
+        } else {
+            op.pn_conv = op.name;
+        }
+    }
+    return 0;
+}
+
 void declare_param(loco_ctx* c, const std::string& name, std::vector<int64_t> shape) {
     HostParam hp; hp.shape = shape;
     c->params[name] = hp;
@@ -726,14 +812,14 @@ void declare_all(loco_ctx* c) {
     const loco_unet_cfg& cfg = c->cfg;
     const bool adm = cfg.arch == 1;
     int temb_ch = cfg.ch * 4;
-    if (cfg.arch != 2) {
+    if (cfg.arch < 2) {
         declare_lin(c, adm ? "time_embed.0" : "temb.dense.0", cfg.ch, temb_ch);
         declare_lin(c, adm ? "time_embed.2" : "temb.dense.1", temb_ch, temb_ch);
     }
     for (auto& op : c->ops) {
         switch (op.kind) {
             case OP_CONV_IN: declare_conv(c, op.pn_conv, cfg.in_channels, c->tens[op.out].C, op.ksize); break;
-            case OP_CONV: declare_conv(c, op.pn_conv, c->tens[op.in].C, c->tens[op.out].C, 3); break;
+            case OP_CONV: declare_conv(c, op.pn_conv, c->tens[op.in].C, c->tens[op.out].C, op.ksize); break;
             case OP_RES: {
                 int cin = c->tens[op.in].C, cout = c->tens[op.out].C;
                 declare_norm(c, op.pn_n1, cin);
@@ -913,7 +999,7 @@ int finalize_params(loco_ctx* c) {
     int temb_ch = cfg.ch * 4;
     const bool adm = cfg.arch == 1;
     const std::string te0 = adm ? "time_embed.0" : "temb.dense.0", te1 = adm ? "time_embed.2" : "temb.dense.1";
-    if (cfg.arch != 2) {
+    if (cfg.arch < 2) {
         if (upload(c, &c->td0w, c->params[te0 + ".weight"].data)) return -1;
         if (upload(c, &c->td0b, c->params[te0 + ".bias"].data)) return -1;
         if (upload(c, &c->td1w, c->params[te1 + ".weight"].data)) return -1;
@@ -1413,7 +1499,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
     const long SB = c->stats_per_sample;
     clear_ready(c);
     auto next_fwd = [&](int tid) { return req_fwd(consumer_norm(c, tid), stats); };   // forward statistics for the consumer of `tid`
-    if (cfg.arch != 2) {
+    if (cfg.arch < 2) {
         launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st, cfg.arch == 1,
                     c->has_cond ? c->cond_add : nullptr, t_ptr);
         launch_temb_proj(c->tact, cfg.ch * 4, c->tp_w, c->tp_b, (int)c->tproj_total, c->tproj, st);
@@ -1438,8 +1524,9 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 a.in = p.T(op.in); a.in_bs = p.bs(); a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false); a.bias = op.conv.bias;
                 a.out = p.T(op.out); a.out_bs = p.bs(); a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                if (op.ksize == 1) a.pad = 0;
                 const StatReq rq = next_fwd(op.out);
-                run_conv(c, a, 9, st, &rq);
+                run_conv(c, a, op.ksize == 1 ? 1 : 9, st, &rq);
                 break;
             }
             case OP_RES: {
@@ -1668,8 +1755,9 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 a.in = TT(op.in); a.in_bs = PS; a.Cin = ti.C; a.Hin = ti.H; a.Win = ti.W;
                 setw(a, op.conv, false);
                 a.out = TT(op.out); a.out_bs = PS; a.Cout = to.C; a.Hout = to.H; a.Wout = to.W; a.B = B;
+                if (op.ksize == 1) a.pad = 0;
                 const StatReq rq = next_tan(op.out);
-                run_conv(c, a, 9, st, &rq);
+                run_conv(c, a, op.ksize == 1 ? 1 : 9, st, &rq);
                 break;
             }
             case OP_RES: {
@@ -1869,6 +1957,9 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
     const int G = cfg.gn_groups;
     auto TP = [&](int id) { return c->arenaP + c->tens[id].off; };
     auto TG = [&](int id) { return c->arenaT + c->tens[id].off; };   // cotangent of tensor id
+    // the op that produces the network output takes the caller's cotangent (conv_out; the encoder's quant_conv)
+    auto GO = [&](const Op& o) -> const float* { return o.out == c->eps_t ? ge : TG(o.out); };
+    auto GOS = [&](const Op& o) -> long { return o.out == c->eps_t ? (long)c->n_out : PS; };
     clear_ready(c);
     for (int oi = (int)c->ops.size() - 1; oi >= 0; --oi) {
         Op& op = c->ops[oi];
@@ -1878,7 +1969,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
             case OP_OUT: {
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
-                a.in = ge; a.in_bs = c->n_out; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
+                a.in = GO(op); a.in_bs = GOS(op); a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
                 setw(a, op.conv, true);
                 a.out = TG(op.a1); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
                 {
@@ -2096,10 +2187,11 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
             case OP_CONV: {
                 const Tens& ti = c->tens[op.in];
                 ConvArgs a; conv_defaults(a);
-                a.in = TG(op.out); a.in_bs = PS; a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
+                a.in = GO(op); a.in_bs = GOS(op); a.Cin = to.C; a.Hin = to.H; a.Win = to.W;
                 setw(a, op.conv, true);
                 a.out = TG(op.in); a.out_bs = PS; a.Cout = ti.C; a.Hout = ti.H; a.Wout = ti.W; a.B = B;
-                run_conv(c, a, 9, st);
+                if (op.ksize == 1) a.pad = 0;
+                run_conv(c, a, op.ksize == 1 ? 1 : 9, st);
                 break;
             }
         }
@@ -2179,6 +2271,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         int r = cfg->resolution;
         for (int l = 0; l < cfg->num_levels - 1; ++l) r /= 2;
         if (cfg->arch == 2) r = cfg->resolution;      // decoder: `resolution` is the coarsest (latent) level
+        if (cfg->arch > 3 || cfg->arch < 0) { c->err = "arch must be 0 (Ho-DDPM), 1 (guided-diffusion family), 2 (latent decoder) or 3 (latent encoder)"; return -2; }
         if (r < 8 || (cfg->resolution & (cfg->resolution - 1))) {
             c->err = "resolution must be a power of two with >= 8x8 at the coarsest level";
             return -2;
@@ -2659,6 +2752,15 @@ int loco_masked_axpby(loco_ctx* c, const float* V, const float* E, float cv, flo
     if (!c) return -2;
     if (!c->primal_ok) { c->err = "loco_pmp_primal has not been called"; return -2; }
     launch_masked_axpby(V, E, c->has_mask ? c->mask : nullptr, cv, ce, out, k, c->n_out, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_latent_sample(loco_ctx* c, const float* moments, const float* noise, float scale, int32_t B, float* z, void* stream) {
+    if (!c) return -2;
+    if (c->cfg.arch != 3 || (c->cfg.out_ch & 1)) { c->err = "latent_sample: the context must be a latent encoder (arch 3) with out_ch = 2 z"; return -2; }
+    if (B < 1 || !moments || !z) { c->err = "latent_sample: bad arguments"; return -2; }
+    launch_latent_sample(moments, noise, scale, z, B, c->n_out / 2, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

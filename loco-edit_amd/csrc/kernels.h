@@ -205,6 +205,7 @@ void launch_ddim_step(const float* x, const float* eps, const float* noise, floa
                       float c_x0_x, float c_x0_e, float c_next_x0, float c_next_e, float c_noise,
                       hipStream_t st);
 // U = mask * (cv*V + ce*dEps); rows >= split use mask2 when it is given (two solves sharing a probe batch)
+void launch_latent_sample(const float* mom, const float* noise, float scale, float* z, int B, long zhw, hipStream_t st);
 void launch_masked_axpby(const float* V, const float* dE, const uint8_t* mask, float cv, float ce,
                          float* U, int k, long n, hipStream_t st, const uint8_t* mask2 = nullptr, long split = 0);
 // G = mask*U (cotangent seed); outputs gE = ce*G  and keeps cv*G in gX0

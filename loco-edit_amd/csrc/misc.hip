@@ -817,6 +817,23 @@ void launch_masked_axpby(const float* V, const float* dE, const uint8_t* mask, f
     hipLaunchKernelGGL(masked_axpby_kernel, dim3(blocks), dim3(256), 0, st, V, dE, mask, cv, ce, U, n, total, mask2, split);
 }
 
+// z = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) over moments [B][2 Z][HW] (mean | logvar), noise / z [B][Z][HW]:
+// DiagonalGaussianDistribution.sample() behind `vae.encode(x0).latent_dist.sample() * 0.18215` (reference edit.py:594-597)
+__global__ void latent_sample_kernel(const float* mom, const float* noise, float scale, float* z, long zhw, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / zhw, j = i - b * zhw;
+        const float mean = mom[b * 2 * zhw + j];
+        const float lv = fminf(fmaxf(mom[b * 2 * zhw + zhw + j], -30.f), 20.f);
+        z[i] = scale * (mean + expf(0.5f * lv) * (noise ? noise[i] : 0.f));
+    }
+}
+void launch_latent_sample(const float* mom, const float* noise, float scale, float* z, int B, long zhw, hipStream_t st) {
+    const long total = (long)B * zhw;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(latent_sample_kernel, dim3(blocks), dim3(256), 0, st, mom, noise, scale, z, zhw, total);
+}
+
 __global__ void cot_seed_kernel(const float* U, const uint8_t* mask, float cv, float ce, float* gE, float* gX0,
                                 long n, long total, const uint8_t* mask2, long split) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {

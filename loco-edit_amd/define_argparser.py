@@ -214,6 +214,14 @@ def _preset_t2i(args, family):
             args.unet_config = config.SD15_UNET
         if getattr(args, 'vae_config', None) is None:
             args.vae_config = config.SD_VAE_DECODER
+        if getattr(args, 'vae_encoder_config', None) is None:      # vae.encode of run_DDIMinversion (engine created on use)
+            args.vae_encoder_config = config.SD_VAE_ENCODER
+        if getattr(args, 'dataset', None) is None and args.dataset_name != 'Random':
+            # the image datasets of the latent path are read at the autoencoder's resolution (utils.py:479-486: 512)
+            from .utils import FolderDataset, SyntheticDataset
+            r = args.vae_encoder_config.resolution
+            args.dataset = (SyntheticDataset(r, 3) if args.dataset_name == 'Synthetic'
+                            else FolderDataset(args.dataset_root, res=r, numeric=args.dataset_name != 'AFHQ'))
         args.c_in = args.unet_config.in_channels           # 4
     else:
         if getattr(args, 'unet_config', None) is None:

@@ -30,7 +30,7 @@ SYMBOLS = [
     "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision", "loco_set_streams",
-    "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby",
+    "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby", "loco_latent_sample",
 ]
 
 
@@ -98,6 +98,7 @@ def load_library():
     lib.loco_set_cond.argtypes = [vp, vp, vp]
     lib.loco_set_context.argtypes = [vp, vp, vp]
     lib.loco_masked_axpby.argtypes = [vp, vp, vp, f32, f32, i32, vp, vp]
+    lib.loco_latent_sample.argtypes = [vp, vp, vp, f32, i32, vp, vp]
     lib.loco_lincomb.argtypes = [vp, C.POINTER(vp), C.POINTER(f32), i32, vp, i64, vp]
     lib.loco_profile_enable.argtypes = [vp, i32]
     lib.loco_profile_report.argtypes = [vp, C.c_char_p, i64]
@@ -148,7 +149,7 @@ class LocoEngine:
         for i, r in enumerate(cfg.attn_resolutions):
             c.attn_resolutions[i] = r
         c.gn_groups, c.gn_eps, c.max_batch = cfg.gn_groups, cfg.gn_eps, self.max_batch
-        c.arch = {"ddpm": 0, "adm": 1, "dec": 2}[cfg.arch]
+        c.arch = {"ddpm": 0, "adm": 1, "dec": 2, "enc": 3}[cfg.arch]
         c.num_head_channels, c.learn_sigma = cfg.num_head_channels, int(cfg.learn_sigma)
         c.context_dim, c.context_len = cfg.context_dim, cfg.context_len
         c.scale_shift_norm, c.resblock_updown = int(cfg.scale_shift_norm), int(cfg.resblock_updown)
@@ -188,7 +189,7 @@ class LocoEngine:
     # ---- denoiser
     def unet_forward(self, x: torch.Tensor, t: float) -> torch.Tensor:
         _chk_dev(x)
-        if self.cfg.arch == "dec":      # decoder: [B, z, R, R] -> [B, out_ch, R_out, R_out]
+        if self.cfg.arch in ("dec", "enc"):      # decoder / encoder: [B, C_in, R, R] -> [B, out_ch, R_out, R_out]
             eps = torch.empty(x.shape[0], self.cfg.out_ch, self.cfg.out_resolution, self.cfg.out_resolution,
                               device=x.device, dtype=torch.float32)
         else:
@@ -336,6 +337,21 @@ class LocoEngine:
         self._check(self.lib.loco_masked_axpby(self._ctx, _ptr(V), _ptr(E), float(cv), float(ce), V.shape[0], _ptr(out),
                                                _stream()), "loco_masked_axpby")
         return out
+
+    def latent_sample(self, moments: torch.Tensor, noise: Optional[torch.Tensor], scale: float) -> torch.Tensor:
+        """Encoder contexts: scale * (mean + std * noise) from the moments [B, 2Z, h, w] (noise None: the mean)."""
+        _chk_dev(moments)
+        B, C2, h, w = moments.shape
+        if C2 * h * w != self.n_out:
+            raise ValueError(f"moments must be [B, {self.cfg.out_ch}, ...] of this encoder, got {tuple(moments.shape)}")
+        if noise is not None:
+            _chk_dev(noise)
+            if tuple(noise.shape) != (B, C2 // 2, h, w):
+                raise ValueError(f"noise must be {(B, C2 // 2, h, w)}, got {tuple(noise.shape)}")
+        z = torch.empty(B, C2 // 2, h, w, device=moments.device, dtype=torch.float32)
+        self._check(self.lib.loco_latent_sample(self._ctx, _ptr(moments), _ptr(noise) if noise is not None else None,
+                                                float(scale), B, _ptr(z), _stream()), "loco_latent_sample")
+        return z
 
     def lincomb(self, terms, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """sum_i coef_i * tensor_i for [(coef, tensor), ...] (<= 4 terms, same shape, fp32, contiguous)."""

@@ -16,8 +16,10 @@ evaluated once per solve at z0_hat.
 Built: ``_classifer_free_guidance`` (:636-674), ``DDIMforwardsteps`` (:677-754, decode + PNG at the end), ``get_x0``
 (:757-781), ``get_delta_zt_via_grad`` (:784-828), ``local_encoder_decoder_pullback_zt`` (:830-915),
 ``run_edit_null_space_projection_zt`` (:918-1041), ``run_edit_null_space_projection_zt_semantic`` (:1045-1174, also
-``use_sega``), ``x_space_guidance_direct`` (:1177-1184).  The runs start from z_T ~ N(0, I) (``dataset_name 'Random'``, as
-all shipped Stable Diffusion scripts do), so ``vae.encode`` / ``run_DDIMinversion`` (:568-633) are not on this path.
+``use_sega``), ``x_space_guidance_direct`` (:1177-1184), and ``run_DDIMinversion`` (:568-633): ``vae.encode`` on an ENCODER
+engine (arch "enc", its own ``loco_ctx``, created on first use), the posterior sample (``loco_latent_sample``) and the
+ascending DDIM loop on the inversion prompt.  The edit runs themselves start from z_T ~ N(0, I) (``dataset_name 'Random'``,
+edit.py:937-938, as all shipped Stable Diffusion scripts do).
 
 NOT built (stated, not hidden): the networks themselves are diffusers' ``UNet2DConditionModel`` (CLIP cross-attention)
 and ``AutoencoderKL`` (un-vendored, hub weights).  The denoiser here is the guided-diffusion U-Net of the engine on 4
@@ -127,6 +129,89 @@ class EditStableDiffusion(EditDeepFloydIF):
         self.edit_t_idx = int((self.scheduler.timesteps - self.edit_t * 1000).abs().argmin())
         self.use_sega = getattr(args, "use_sega", False)
         print(f'decoder : {vcfg.in_channels}x{vcfg.resolution}^2 -> {vcfg.out_ch}x{vcfg.out_resolution}^2')
+        # ---- the inversion's inputs (edit.py:509, 524-529): steps, prompt embedding, image dataset; the encoder engine is
+        # created on first use (run_DDIMinversion is the only caller)
+        self.inv_steps = getattr(args, "inv_steps", 100)
+        self.inv_prompt = getattr(args, "inv_prompt", "")
+        pe = getattr(args, "prompt_emb", None)
+        self.inv_prompt_emb = pe["inv"] if (pe is not None and "inv" in pe) else self.for_prompt_emb
+        self.enc_engine: Optional[LocoEngine] = None
+        self.dataset = getattr(args, "dataset", None)
+
+    # ------------------------------------------------------------------ encode (edit.py:594-597)
+    def _encoder(self) -> LocoEngine:
+        if self.enc_engine is not None:
+            return self.enc_engine
+        args = self.args
+        ecfg: UNetConfig = getattr(args, "vae_encoder_config", None)
+        if ecfg is None:
+            raise ValueError("run_DDIMinversion needs the autoencoder's encoder: set vae_encoder_config (config.SD_VAE_ENCODER)")
+        if ecfg.arch != "enc" or ecfg.out_ch != 2 * self.cfg.in_channels or ecfg.out_resolution != self.cfg.resolution:
+            raise ValueError("vae_encoder_config must be an encoder (arch 'enc') onto the denoiser's latent (2 z moment channels)")
+        eparams = getattr(args, "vae_encoder_params", None)
+        if eparams is None:
+            if getattr(args, "vae_ckpt_path", ""):
+                eparams = torch.load(args.vae_ckpt_path, map_location="cpu")
+                eparams = eparams.get("state_dict", eparams)
+                from .checkpoints import hf_autoencoder_kl_to_encoder, is_hf_autoencoder_kl
+                if is_hf_autoencoder_kl(eparams):          # diffusers AutoencoderKL file: keep quant_conv + encoder.*
+                    eparams = hf_autoencoder_kl_to_encoder(eparams, ecfg)
+            else:
+                seed = getattr(args, "synthetic_weights", None)
+                if seed is None:
+                    raise ValueError("no encoder checkpoint: pass --vae_ckpt_path or --synthetic_weights SEED")
+                eparams = synth_params(ecfg, seed=int(seed))
+        self.enc_cfg = ecfg
+        self.enc_engine = LocoEngine(ecfg, max_batch=1, device=self.device)
+        self.enc_engine.load_state_dict(eparams)
+        prec = getattr(args, "precision", None) or os.environ.get("LOCO_PRECISION")
+        if prec:
+            self.enc_engine.set_precision(prec)
+        print(f'encoder : {ecfg.in_channels}x{ecfg.resolution}^2 -> 2x{ecfg.out_ch // 2}x{ecfg.out_resolution}^2 moments')
+        return self.enc_engine
+
+    def encode(self, x0: torch.Tensor, noise: Optional[torch.Tensor] = None, sample: bool = True) -> torch.Tensor:
+        """``self.vae.encode(x0).latent_dist.sample() * 0.18215`` (edit.py:594-597) for images [B, 3, R, R] in [-1, 1].
+        ``noise``: the posterior's normal draw (default: torch.randn on the device, as diffusers draws it);
+        ``sample=False``: the posterior mean."""
+        enc = self._encoder()
+        x = x0.to(self.device, torch.float32).contiguous()
+        out = []
+        for b in range(x.shape[0]):
+            mom = enc.unet_forward(x[b:b + 1].contiguous(), 0.0)
+            nz = None
+            if sample:
+                shape = (1, mom.shape[1] // 2) + tuple(mom.shape[2:])
+                nz = (torch.randn(shape, device=self.device, dtype=torch.float32) if noise is None
+                      else noise[b:b + 1].to(self.device, torch.float32).contiguous())
+            out.append(enc.latent_sample(mom, nz, float(np.float32(LATENT_SCALE))))
+        return torch.cat(out)
+
+    @torch.no_grad()
+    def run_DDIMinversion(self, idx, guidance=None, vis_traj=False, noise=None):
+        """edit.py:568-633.  Prompt: (CFG) pos inv_prompt / neg null_prompt, (no CFG) inv_prompt alone; CFG only when
+        ``guidance`` is given and guidance_scale > 1.  Ascending custom-scheduler timesteps, the last one is not stepped."""
+        print('start DDIMinversion')
+        self.EXP_NAME = f'DDIMinversion-{self.dataset_name}-{idx}-for_{self.for_prompt}-inv_{self.inv_prompt}'
+        do_cfg = (self.guidance_scale > 1.0) and (guidance is not None)
+        if not self.use_yh_custom_scheduler:
+            raise ValueError('recommend to use yh custom scheduler')
+        self.scheduler.set_timesteps(self.inv_steps, device=self.device, is_inversion=True)
+        timesteps = self.scheduler.timesteps
+        if self.dataset is None:
+            raise ValueError("run_DDIMinversion needs an image dataset (dataset_name 'Random' has none)")
+        x0 = self.dataset[idx]
+        if self.sharder.is_main:
+            _save_image((x0 / 2 + 0.5).clamp(0, 1), os.path.join(self.result_folder, 'original_x0.png'))
+        latents = self.encode(x0, noise=noise)
+        F, E, N = self.inv_prompt_emb, self.edit_prompt_emb, self.null_prompt_emb      # the "for" branch carries inv_prompt
+        for i, t in enumerate(timesteps):
+            if i == len(timesteps) - 1:
+                break
+            noise_pred = self._classifer_free_guidance(latents, t, F, E, N, mode="null+(for-null)",
+                                                       do_classifier_free_guidance=do_cfg)
+            latents = self.scheduler.step(noise_pred, t, latents, eta=0).prev_sample
+        return latents
 
     # ------------------------------------------------------------------ decode (edit.py:748-750, 769-771)
     def decode(self, z_scaled: torch.Tensor) -> torch.Tensor:
@@ -241,8 +326,8 @@ class EditStableDiffusion(EditDeepFloydIF):
     # ------------------------------------------------------------------ drivers
     def _zT(self):
         if self.dataset_name != 'Random':
-            raise ValueError("this path runs from z_T ~ N(0, I) (dataset_name 'Random', edit.py:937-938); vae.encode / "
-                             "DDIM inversion of an image are not built")
+            raise ValueError("the edit runs start from z_T ~ N(0, I) (dataset_name 'Random', edit.py:937-938); "
+                             "run_DDIMinversion is the image entry point")
         return torch.randn(1, self.c_in, self.image_size, self.image_size, dtype=self.dtype, device=self.device)
 
     def _solve_or_load(self, save_dir, zt, t, t_idx, mask, op, block_idx, pca_rank, pca_rank_null, null_space_projection,

@@ -167,6 +167,27 @@ def decoder_forward(p: Dict[str, torch.Tensor], cfg, z: torch.Tensor, trace: Opt
     return F.conv2d(h, p["conv_out.weight"], p["conv_out.bias"], padding=1)
 
 
+def encoder_forward(p: Dict[str, torch.Tensor], cfg, x: torch.Tensor) -> torch.Tensor:
+    """image [B, 3, R, R] -> moments [B, 2 z_ch, R / 2^(levels-1), same] = quant_conv(Encoder(x)): the latent-diffusion
+    `Encoder` + `quant_conv` behind `vae.encode(x0).latent_dist` of the reference's latent inversion (edit.py:594-597;
+    un-vendored diffusers AutoencoderKL, restated from the published latent-diffusion module): conv_in; per level
+    num_res_blocks ResnetBlocks and, except on the last, Downsample = pad (0,1,0,1) + conv3 stride 2; mid block / attention /
+    block; GroupNorm, swish, conv_out."""
+    nlev = len(cfg.ch_mult)
+    h = F.conv2d(x, p["conv_in.weight"], p["conv_in.bias"], padding=1)
+    for lvl in range(nlev):
+        for b in range(cfg.num_res_blocks):
+            h = _resblock_noemb(p, f"down.{lvl}.block.{b}", h, cfg)
+        if lvl != nlev - 1:
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), p[f"down.{lvl}.downsample.conv.weight"], p[f"down.{lvl}.downsample.conv.bias"],
+                         stride=2)
+    h = _resblock_noemb(p, "mid.block_1", h, cfg)
+    h = _attn(p, "mid.attn_1", h, cfg)
+    h = _resblock_noemb(p, "mid.block_2", h, cfg)
+    h = F.conv2d(_swish(_gn(p, "norm_out", h, cfg)), p["conv_out.weight"], p["conv_out.bias"], padding=1)
+    return F.conv2d(h, p["quant_conv.weight"], p["quant_conv.bias"])
+
+
 # --------------------------------------------------------------------------
 # Denoiser B: guided-diffusion / P2 U-Net (reference src/models/guided_diffusion/unet.py, P2_DICT)
 # --------------------------------------------------------------------------

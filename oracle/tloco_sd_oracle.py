@@ -2,7 +2,8 @@
 (Stable Diffusion path, reference ``src/modules/edit.py`` class ``EditStableDiffusion`` :483-1196), used only by tests/
 and the golden generator.  The product path never imports it.
 
-Restated (each function cites the lines it follows): ``get_x0`` with the decode (:757-781), the subspace iteration on
+Restated (each function cites the lines it follows): the latent DDIM inversion with its ``vae.encode`` (:568-633),
+``get_x0`` with the decode (:757-781), the subspace iteration on
 the decoded image's Jacobian (``local_encoder_decoder_pullback_zt`` :830-915), the direction through the Jacobian
 (``get_delta_zt_via_grad`` :784-828), the sampler with the final decode (``DDIMforwardsteps`` :677-754) and the
 ``scaled_linear`` alpha-bar table of the pipeline scheduler the reference patches (utils.py:147-157).  The CFG
@@ -35,6 +36,19 @@ class SDScheduler(tl.IFScheduler):
         self.alphas_cumprod = scaled_linear_alphas_cumprod()
         self.timesteps = self.timesteps_next = None
 
+    def set_inversion_timesteps(self, n: int):
+        """utils.py:172-179 (`is_inversion=True`): ascending float timesteps shifted by 1e-6, the next one as target."""
+        seq = torch.linspace(0, 1, n) * self.t_max + 1e-6
+        self.timesteps, self.timesteps_next = seq[:-1].clone(), seq[1:].clone()
+
+
+def posterior_sample(moments: torch.Tensor, noise) -> torch.Tensor:
+    """diffusers DiagonalGaussianDistribution.sample() (un-vendored; vae.py of the pinned diffusers): mean | logvar
+    chunks, logvar clamped to [-30, 20], mean + exp(0.5 logvar) * noise.  noise None: the mean."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    return mean if noise is None else mean + std * noise
+
 
 class OracleTLocoSD(tl.OracleTLoco):
     def __init__(self, params, cfg, dec_params, dec_cfg, guidance_scale=7.5, guidance_scale_edit=4.0, for_steps=100, edit_t=0.7):
@@ -46,6 +60,26 @@ class OracleTLocoSD(tl.OracleTLoco):
 
     def decode(self, z_scaled):
         return orc.decoder_forward(self.dp, self.dcfg, z_scaled)
+
+    # -- edit.py:568-633 (run_DDIMinversion): z0 = vae.encode(x0).latent_dist.sample() * 0.18215, then the ascending DDIM
+    #    loop on the inversion prompt (classifier-free guidance against the null prompt only when `guidance` is given)
+    def inversion(self, x0, noise, enc_params, enc_cfg, inv_e, null_e, inv_steps, guidance=None, return_z0=False):
+        z0 = posterior_sample(orc.encoder_forward(enc_params, enc_cfg, x0), noise) * LATENT_SCALE
+        do_cfg = (self.guidance_scale > 1.0) and (guidance is not None)
+        sched = SDScheduler()
+        sched.set_inversion_timesteps(inv_steps)
+        z = z0
+        B = z.shape[0]
+        for i, t in enumerate(sched.timesteps):
+            if i == len(sched.timesteps) - 1:
+                break
+            if do_cfg:
+                n = self.unet_full(z, t, null_e.repeat(B, 1, 1))
+                eps = n + self.guidance_scale * (self.unet_full(z, t, inv_e.repeat(B, 1, 1)) - n)
+            else:
+                eps = self.unet_full(z, t, inv_e.repeat(B, 1, 1))
+            z = sched.step(eps, t, z)
+        return (z, z0) if return_z0 else z
 
     # -- edit.py:757-781
     def get_x0(self, zt, t, for_e, edit_e, null_e, mask=None, mode="null+(for-null)+(edit-null)", flatten=False):

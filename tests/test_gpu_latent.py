@@ -443,3 +443,90 @@ def test_ldm_unet_with_spatial_transformer_vs_restatement(prec):
     assert rel(U, JV) < 5 * tol and rel(A, Aref) < 5 * tol
     lhs, rhs = (U.double().cpu() * Uc.double()).sum(), (V.double() * A.double().cpu()).sum()
     assert abs(lhs - rhs) / abs(lhs) < (1e-4 if prec == "f32" else 5e-4)
+
+
+# ------------------------------------------------------------------ vae.encode + latent DDIM inversion (edit.py:568-633)
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_encoder_engine_and_posterior_sample_vs_restatement(prec, golden):
+    """arch "enc": image -> posterior moments against oracle/loco_oracle.encoder_forward (pinned on the reference's own
+    blocks by oracle/make_golden_tloco_sd_inv.py: the fixture's `moments` come from those blocks), J V / U^T J of the
+    encoder against autodiff, and loco_latent_sample against diffusers' DiagonalGaussianDistribution formula."""
+    import tloco_sd_oracle as tsd
+    from loco_edit_amd.config import TINY_ENCODER as cfg
+    from loco_edit_amd.hip import LocoEngine
+    g = golden("tloco_sd_inv")
+    params = synth_params(cfg, 0)
+    eng = LocoEngine(cfg, max_batch=2, device=torch.device(DEV))
+    eng.load_state_dict(params)
+    eng.set_precision(prec)
+    p = orc.to_torch(params)
+    assert (eng.n, eng.n_out) == (3 * 64 * 64, 8 * 16 * 16)
+    mom = eng.unet_forward(g["x0"].to(DEV), 0.0)
+    assert tuple(mom.shape) == (1, 8, 16, 16) and rel(mom, g["moments"]) < TOL[prec]
+    xb = torch.cat([g["x0"], 0.5 * g["x0"].flip(-1)])
+    assert rel(eng.unet_forward(xb.to(DEV), 0.0), orc.encoder_forward(p, cfg, xb)) < TOL[prec]
+    with pytest.raises(RuntimeError):
+        eng.ddim_step(g["x0"].to(DEV), 10.0, 0.5, 0.6)
+    # posterior sample, with log-variances outside the clamp
+    m2 = mom.clone(); m2[0, 4, 0, :4] = torch.tensor([-50.0, 40.0, -30.0, 20.0], device=DEV)
+    nz = g["plain"]["noise"].to(DEV)
+    z = eng.latent_sample(m2, nz, 0.18215)
+    assert torch.allclose(z.cpu(), tsd.posterior_sample(m2.cpu(), nz.cpu()) * 0.18215, rtol=1e-5, atol=1e-6)
+    assert torch.equal(eng.latent_sample(m2, None, 1.0), m2[:, :4])
+    with pytest.raises(ValueError):
+        eng.latent_sample(m2, nz[:, :2].contiguous(), 1.0)
+    # the encoder's Jacobian products (not on the reference's path, but every arch supports them)
+    gg = torch.Generator().manual_seed(3)
+    x = g["x0"]
+    V, U = torch.randn(2, eng.n, generator=gg), torch.randn(2, eng.n_out, generator=gg)
+    f = lambda x_: orc.encoder_forward(p, cfg, x_)
+    JV = torch.stack([torch.func.jvp(f, (x,), (v.view_as(x),))[1].reshape(-1) for v in V])
+    eng.pmp_primal(x.to(DEV), 0.0, 1.0, None, use_et=True)
+    assert rel(eng.pmp_jvp(V.to(DEV)), JV) < TOL[prec] * 5
+    xx = x.clone().requires_grad_(True)
+    y = f(xx).reshape(-1)
+    JtU = torch.stack([torch.autograd.grad(y, xx, u, retain_graph=True)[0].reshape(-1) for u in U])
+    assert rel(eng.pmp_vjp(U.to(DEV)), JtU) < TOL[prec] * 5
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_latent_ddim_inversion_vs_reference_golden(prec, golden, tmp_path):
+    """run_DDIMinversion against the reference's own method run on the stand-ins (tests/golden/tloco_sd_inv.pt): the
+    posterior draw is injected (the reference's came from the seeded global generator), without and with CFG."""
+    from loco_edit_amd.config import TINY_ENCODER
+    gi, gt = golden("tloco_sd_inv"), golden("tloco_sd_tiny")
+    g = dict(gt); g["guidance_scale"] = gi["guidance_scale"]
+    ed = _edit_sd(g, tmp_path, prec)
+    ed.args.vae_encoder_config = TINY_ENCODER
+    ed.inv_steps, ed.inv_prompt_emb, ed.null_prompt_emb = gi["inv_steps"], gi["inv_e"], gi["null_e"]
+    ed.dataset, ed.dataset_name = [gi["x0"]], "Synthetic"
+    tol = TOL[prec]
+    z0 = ed.encode(gi["x0"], noise=gi["plain"]["noise"])
+    assert tuple(z0.shape) == (1, 4, 16, 16) and rel(z0, gi["plain"]["z0"]) < tol
+    assert rel(ed.encode(gi["x0"], sample=False), gi["moments"][:, :4] * 0.18215) < tol
+    for key, guidance in (("plain", None), ("cfg", True)):
+        zT = ed.run_DDIMinversion(idx=0, guidance=guidance, noise=gi[key]["noise"])
+        assert torch.equal(ed.scheduler.timesteps, gi["timesteps"]) and torch.equal(ed.scheduler.timesteps_next, gi["timesteps_next"])
+        assert rel(zT, gi[key]["zT"]) < 20 * tol, key          # 11 guided steps compound the per-evaluation error
+    assert os.path.exists(os.path.join(ed.result_folder, "original_x0.png"))
+    # without an injected draw the posterior is sampled on the device: same mean, unit-variance spread
+    za, zb = ed.encode(gi["x0"]), ed.encode(gi["x0"])
+    assert not torch.equal(za, zb)
+
+
+def test_sd_autoencoder_encoder_at_size():
+    """The Stable Diffusion autoencoder's encoder at its published geometry (34.2 M parameters, 3x512x512 -> 8x64x64
+    moments, 4096-token mid attention) against the restatement on the host."""
+    from loco_edit_amd.config import SD_VAE_ENCODER as cfg
+    from loco_edit_amd.hip import LocoEngine
+    params = synth_params(cfg, 0)
+    eng = LocoEngine(cfg, max_batch=1, device=torch.device(DEV))
+    eng.load_state_dict(params)
+    eng.set_precision("bf16x3")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 3, 512, 512, generator=g).clamp(-1, 1)
+    mom = eng.unet_forward(x.to(DEV), 0.0)
+    assert tuple(mom.shape) == (1, 8, 64, 64) and torch.isfinite(mom).all()
+    with torch.no_grad():
+        ref = orc.encoder_forward(orc.to_torch(params), cfg, x)
+    assert rel(mom, ref) < TOL["bf16x3"]

@@ -99,3 +99,46 @@ def test_autoencoder_kl_key_map_round_trip():
     del hf["decoder.conv_out.bias"]
     with pytest.raises(KeyError):
         hf_autoencoder_kl_to_decoder(hf, TINY_DECODER)
+
+
+def test_oracle_latent_inversion_vs_reference_fixture(golden):
+    """tests/golden/tloco_sd_inv.pt = the reference's own run_DDIMinversion (edit.py:568-633) on the stand-ins."""
+    from loco_edit_amd.config import TINY_ENCODER, SD_VAE_ENCODER
+    gi, gt = golden("tloco_sd_inv"), golden("tloco_sd_tiny")
+    p = orc.to_torch(synth_params(TINY_LATENT, 0))
+    p.update({k: torch.from_numpy(v) for k, v in cond_params(TINY_LATENT, gi["cond_dim"], 0).items()})
+    ot = tsd.OracleTLocoSD(p, TINY_LATENT, orc.to_torch(synth_params(TINY_DECODER, 0)), TINY_DECODER,
+                           guidance_scale=gi["guidance_scale"], guidance_scale_edit=gt["guidance_scale_edit"])
+    ep = orc.to_torch(synth_params(TINY_ENCODER, 0))
+    with torch.no_grad():
+        assert torch.allclose(orc.encoder_forward(ep, TINY_ENCODER, gi["x0"]), gi["moments"], rtol=1e-4, atol=1e-5)
+        for key, guidance in (("plain", None), ("cfg", True)):
+            zT, z0 = ot.inversion(gi["x0"], gi[key]["noise"], ep, TINY_ENCODER, gi["inv_e"], gi["null_e"], gi["inv_steps"],
+                                  guidance=guidance, return_z0=True)
+            assert torch.allclose(z0, gi[key]["z0"], rtol=1e-4, atol=1e-5)
+            assert torch.allclose(zT, gi[key]["zT"], rtol=1e-3, atol=1e-3), key
+    # product scheduler: the inversion timesteps of utils.py:172-179
+    s = SDScheduler()
+    s.set_timesteps(gi["inv_steps"], is_inversion=True)
+    assert torch.equal(s.timesteps, gi["timesteps"]) and torch.equal(s.timesteps_next, gi["timesteps_next"])
+    assert float(s.timesteps[0]) == pytest.approx(1e-6) and s.alpha_at(s.timesteps[0]) == float(s.alphas_cumprod[0])
+    # the encoder preset has the published size of the Stable Diffusion autoencoder's encoder (+ quant_conv)
+    n_enc = sum(int(torch.tensor(sh).prod()) for sh in param_shapes(SD_VAE_ENCODER).values())
+    assert n_enc == 34_163_592 + 72 and SD_VAE_ENCODER.n == 3 * 512 * 512 and SD_VAE_ENCODER.n_out == 8 * 64 * 64
+    assert TINY_ENCODER.out_resolution == TINY_LATENT.resolution and TINY_ENCODER.out_ch == 2 * TINY_LATENT.in_channels
+
+
+def test_autoencoder_kl_encoder_key_map_round_trip():
+    from loco_edit_amd.checkpoints import encoder_to_hf_autoencoder_kl, hf_autoencoder_kl_to_encoder
+    from loco_edit_amd.config import TINY_ENCODER
+    sd = {k: torch.from_numpy(v) for k, v in synth_params(TINY_ENCODER, 3).items()}
+    hf = encoder_to_hf_autoencoder_kl(sd, TINY_ENCODER)
+    assert "encoder.down_blocks.0.resnets.0.conv1.weight" in hf and "encoder.down_blocks.0.downsamplers.0.conv.weight" in hf
+    assert hf["encoder.mid_block.attentions.0.to_q.weight"].dim() == 2 and "quant_conv.weight" in hf
+    assert len(hf) == len(sd)
+    hf["decoder.conv_in.weight"] = torch.zeros(1); hf["post_quant_conv.weight"] = torch.zeros(1)
+    back = hf_autoencoder_kl_to_encoder(hf, TINY_ENCODER)
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    del hf["encoder.conv_out.bias"]
+    with pytest.raises(KeyError):
+        hf_autoencoder_kl_to_encoder(hf, TINY_ENCODER)
