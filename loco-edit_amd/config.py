@@ -141,6 +141,11 @@ TINY_LDM = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=32, ch_mult=(1,
 FLASH_LDM = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=160, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(16,),
                        gn_eps=1e-5, arch="adm", learn_sigma=False, context_dim=16, context_len=7, scale_shift_norm=False,
                        resblock_updown=False, num_heads=4, transformer_depth=1)
+# one level of Stable Diffusion's own width (320 channels, 8 heads of 40) over 64 tokens: the register-resident LayerNorm
+# kernels (C = 64 * 5) and the 1-tap tile choice of the transformer's linear layers, at a size autodiff finishes in seconds
+WIDE_LDM = UNetConfig(resolution=8, in_channels=4, out_ch=4, ch=320, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(8,),
+                      gn_eps=1e-5, arch="adm", learn_sigma=False, context_dim=16, context_len=7, scale_shift_norm=False,
+                      resblock_updown=False, num_heads=8, transformer_depth=1)
 # config 5's geometry (64x64, four levels, attention at 32 / 16 / 8 incl. the 1024-token level, 64-channel heads, learned
 # variance) at a third of IF64_STANDIN's width: the size the CPU reference solves in minutes (tests/golden/tloco_mid.pt)
 MID_IF64 = UNetConfig(resolution=64, ch=64, ch_mult=(1, 2, 3, 4), num_res_blocks=2, attn_resolutions=(32, 16, 8),

@@ -124,6 +124,11 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
     // third weight buffer, and the 1x1 convs are HBM-bound
     constexpr bool XPF = (TAPS == 9 && STG != 2);
     constexpr int NWB = XPF ? 3 : 2;                 // weight stage buffers
+    // 1x1 operators on the per-pixel path: a stage is only TM*TN MFMA groups long, far shorter than a memory latency, so
+    // the operands of DEEP_D chunks are kept in flight in a register ring (pixels AND weights by plain loads: the
+    // compiler then counts vmcnt per ring slot by itself, which it cannot do past an LDS-DMA) -- see the stage loop
+    constexpr bool DEEP1 = (TAPS == 1 && STG == 1 && !NEEDP);
+    constexpr int DEEP_D = 4;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     // double-buffered: weight stage s lives in W buffer s&1, the halo of chunk c in H buffer c&1
@@ -400,8 +405,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
             }
         }
     };
-    auto prefetch_h = [&](int chunk, int part) {
-        if constexpr (!GEN) { prefetch_hv(hr, chunk, part); return; }
+    auto load_consts = [&](int chunk) {
         const int c0 = chunk * BKC;
         if constexpr (MODE != CM_NONE) {
 #pragma unroll
@@ -411,6 +415,9 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 else { cA[kk] = scb[c]; cB[kk] = shb[c]; }
             }
         }
+    };
+    auto load_regs = [&](float (&hvd)[NITEM][8], int chunk) {
+        const int c0 = chunk * BKC;
         if (c0 + BKC <= a.Cin) {
             // fast path: all 16 channels exist -> wave-uniform plane base + per-lane 32-bit offset
 #pragma unroll
@@ -419,7 +426,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 const float2* sk = NEEDP ? sxb + (long)(c0 + k) * in_plane : nullptr;
 #pragma unroll
                 for (int i = 0; i < NITEM; ++i) {
-                    hv[i][k] = pk[ivoff[i]];
+                    hvd[i][k] = pk[ivoff[i]];
                     if constexpr (NEEDP) pv[i][k] = sk[ivoff[i]];
                 }
             }
@@ -432,7 +439,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                     int cc = c < a.Cin ? c : a.Cin - 1;
                     unsigned vo = ivoff[i] - (unsigned)(ioct[i] * 8 * (int)in_plane);
                     float v = inb[(long)cc * in_plane + vo];
-                    hv[i][k] = c < a.Cin ? v : 0.0f;
+                    hvd[i][k] = c < a.Cin ? v : 0.0f;
                     if constexpr (NEEDP) {
                         float2 pp = sxb[(long)cc * in_plane + vo];
                         pv[i][k] = c < a.Cin ? pp : make_float2(0.f, 0.f);
@@ -440,6 +447,11 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 }
             }
         }
+    };
+    auto prefetch_h = [&](int chunk, int part) {
+        if constexpr (!GEN) { prefetch_hv(hr, chunk, part); return; }
+        load_consts(chunk);
+        load_regs(hv, chunk);
     };
     // Weight pieces of this thread: byte offset from the (chunk, row) base.  Records past the padded cout range
     // are CLAMPED to the last one instead of zeroed: a D row only depends on its own A row, and rows >= Cout are
@@ -468,8 +480,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 __builtin_amdgcn_global_load_lds((glb_u8*)(wbase + wrel[i]), (lds_u8*)(Wdst + e0 * 16), 16, 0, 0);
         }
     };
-    auto stage_h = [&](int chunk, int part) {
-        if constexpr (!GEN) { stage_hv(hr, part); return; }
+    auto stage_regs = [&](const float (&hvs)[NITEM][8], int chunk, unsigned char* Hd) {
         const int c0 = chunk * BKC;
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
@@ -480,7 +491,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
                 int c = c0 + ioct[i] * 8 + k;
                 float r = 0.0f;
                 if (ival[i] && c < a.Cin) {
-                    float d = hv[i][k];
+                    float d = hvs[i][k];
                     if constexpr (MODE == CM_NONE) {
                         r = d;
                     } else {
@@ -502,9 +513,13 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
             }
             uint4 hi, lo;
             split8<PR>(v, hi, lo);
-            *reinterpret_cast<uint4*>(Hs + hrec_off<PR>(ipos[i], ioct[i])) = hi;
-            if constexpr (PR == PR_BF16X3) *reinterpret_cast<uint4*>(Hs + hrec_off<PR>(ipos[i], 2 + ioct[i])) = lo;
+            *reinterpret_cast<uint4*>(Hd + hrec_off<PR>(ipos[i], ioct[i])) = hi;
+            if constexpr (PR == PR_BF16X3) *reinterpret_cast<uint4*>(Hd + hrec_off<PR>(ipos[i], 2 + ioct[i])) = lo;
         }
+    };
+    auto stage_h = [&](int chunk, int part) {
+        if constexpr (!GEN) { stage_hv(hr, part); return; }
+        stage_regs(hv, chunk, Hs);
     };
 
     // MFMA operand fragments of one tap; two sets alternate so the ds_reads of tap t+1 are in flight under the
@@ -698,6 +713,80 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
             if (ci + 1 < nch) chunk_body(std::integral_constant<int, 1>{}, ci + 1);
         }
     } else {
+    bool deep_done = false;
+    if constexpr (DEEP1) {
+      if ((a.Cin % BKC) == 0 && !a.no_deep) {     // whole chunks only (uniform); partial last chunks take the two-buffer loop below
+        deep_done = true;
+        // ---- 1x1, per-pixel path: register ring, DEEP_D chunks in flight -----------------------------------------------
+        // Stage ci multiplies chunk ci out of W / H buffer ci & 1; meanwhile it commits chunk ci + 1 (converted pixels and
+        // weight pieces, loaded DEEP_D - 1 stages ago into ring slot (ci + 1) % D) to the other buffer and re-issues that
+        // slot's loads for chunk ci + 1 + D.  No LDS-DMA and no hand-written vmcnt here: every wait is the compiler's own
+        // count for the slot it is about to read (vmcnt(27) = three chunks of 8 + 1 loads), so D - 1 chunks stay in flight
+        // across the stage barrier.  (A third W / H buffer with the operand fragments read one stage ahead, as in the 3x3
+        // loop, measured no better: profiles/r03_experiments.md #10.)
+        constexpr int D = DEEP_D;
+        float hvr[D][NITEM][8];
+        f32x4 wr[D][NWV];
+        const unsigned char* const wgb = reinterpret_cast<const unsigned char*>(wg);
+        auto issue = [&](auto stag, int chunk) {
+            constexpr int sl = decltype(stag)::value;
+            const int c0 = chunk * BKC;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {       // wave-uniform plane base + per-lane 32-bit offset (ivoff holds the octet)
+                const float* pk = inb + (long)(c0 + k) * in_plane;
+#pragma unroll
+                for (int i = 0; i < NITEM; ++i) hvr[sl][i][k] = pk[ivoff[i]];
+            }
+            const unsigned char* wbase = wgb + (unsigned)(chunk * TAPS) * ((unsigned)wpitch * (unsigned)RB);
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) wr[sl][i] = *reinterpret_cast<const f32x4*>(wbase + wrel[i]);
+        };
+        auto commit = [&](auto stag, int chunk, unsigned char* Hd, unsigned char* Wd) {
+            constexpr int sl = decltype(stag)::value;
+            if constexpr (MODE != CM_NONE) load_consts(chunk);
+            stage_regs(hvr[sl], chunk, Hd);
+#pragma unroll
+            for (int i = 0; i < NWV; ++i)
+                if ((WTOT % NTHR) == 0 || tid + i * NTHR < WTOT)
+                    *reinterpret_cast<f32x4*>(Wd + (tid + i * NTHR) * 16) = wr[sl][i];
+        };
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+        static_assert(D == 4, "ring slots are spelled out below");
+        if (nch > 0) {
+            issue(S0{}, cbeg);
+            issue(S1{}, cclamp(cbeg + 1));
+            issue(S2{}, cclamp(cbeg + 2));
+            issue(S3{}, cclamp(cbeg + 3));
+            commit(S0{}, cbeg, Hsb, Wsb);
+            issue(S0{}, cclamp(cbeg + 4));
+            stage_end();
+        }
+        auto body = [&](auto stag, const int ci) {        // stag = ring slot of chunk ci + 1
+            const int chunk = cbeg + ci;
+            unsigned char* const Wcur = Wsb + (ci & 1) * WBYTES;
+            unsigned char* const Wnxt = Wsb + ((ci + 1) & 1) * WBYTES;
+            unsigned char* const Hcur = Hsb + (ci & 1) * HBYTES;
+            unsigned char* const Hnxt = Hsb + ((ci + 1) & 1) * HBYTES;
+            Ws = Wcur; Hs = Hcur;
+            Frag f0;
+            load_frag(f0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frag(f0);
+            commit(stag, cclamp(chunk + 1), Hnxt, Wnxt);
+            issue(stag, cclamp(chunk + 1 + D));
+            stage_end();
+        };
+        int ci = 0;
+        for (; ci + D <= nch; ci += D) {                  // whole ring turns: one basic block, exact waits
+            body(S1{}, ci); body(S2{}, ci + 1); body(S3{}, ci + 2); body(S0{}, ci + 3);
+        }
+        if (ci < nch) body(S1{}, ci);
+        if (ci + 1 < nch) body(S2{}, ci + 1);
+        if (ci + 2 < nch) body(S3{}, ci + 2);
+      }
+    }
+    if (!deep_done) {
     if (nch > 0) {
         dma_w(cbeg, 0, Wsb);
         Hs = Hsb;
@@ -770,6 +859,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
             }
             stage_end();
         }
+    }
     }
 
     }

@@ -129,6 +129,7 @@ struct loco_ctx {
     float *stpart = nullptr, *stpart2 = nullptr;   // row partials of the statistics taken in conv epilogues (lane 0 / lane 1)
     size_t stpart_floats = 0;
     bool fuse_stats = true;        // LOCO_FUSE_STATS=0: every statistics pass as its own kernels (A/B timing)
+    bool deep1 = true;             // LOCO_DEEP1=0: 1x1 operators on the two-buffer stage loop instead of the register ring (A/B)
     bool flash_attn = true;        // LOCO_FLASH_ATTN=0: tangent / cotangent attention on the generic GEMM + softmax-Jacobian path
     float* attn_delta = nullptr;   // [max_batch][heads][tokens] scratch of the flash cotangent
     float* partial = nullptr;      // split-K workspace
@@ -1196,6 +1197,8 @@ void stats_standalone(loco_ctx* c, const StatReq& rq, const float* x, long xbs, 
 // run a conv with automatic split-K selection
 void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq* rq = nullptr) {
     if (c->prec == 2) a.wb = a.wh;
+    a.taps = taps;
+    a.no_deep = c->deep1 ? 0 : 1;
     a.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B)
                             : conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
@@ -2305,6 +2308,8 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         if (dalloc(c, &c->stpart, c->stpart_floats) || dalloc(c, &c->stpart2, c->stpart_floats)) return -1;
         const char* e = getenv("LOCO_FUSE_STATS");
         c->fuse_stats = !(e && atoi(e) == 0);
+        e = getenv("LOCO_DEEP1");
+        c->deep1 = !(e && atoi(e) == 0);
         const char* fa = getenv("LOCO_FLASH_ATTN");
         c->flash_attn = !(fa && atoi(fa) == 0);
         long dmax = 1;

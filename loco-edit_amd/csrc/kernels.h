@@ -56,6 +56,8 @@ struct ConvArgs {
     int in_padded;   // `in` (and `sx`) live in a padded engine arena: 16-byte loads may start 1 float before / end 3 after a plane
     int accumulate;  // out += result
     int nsplit;      // split-K factor (>1: raw partials go to `partial`, epilogue by conv_splitk_reduce)
+    int taps;        // 9 or 1 (0 = not stated)
+    int no_deep;     // 1: the 1x1 per-pixel variants keep the two-buffer stage loop (A/B switch of the register ring)
     float* partial;
     int B;
     // forward-statistics sink (st_kind == ST_FWD): {mean, M2} per (cout row, pixel tile), [B][Cout][pixel tiles][2]

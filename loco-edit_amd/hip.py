@@ -187,8 +187,16 @@ class LocoEngine:
             raise RuntimeError(f"{miss} parameters missing: {self.lib.loco_last_error(self._ctx).decode()}")
 
     # ---- denoiser
+    def _chk_input(self, x: torch.Tensor):
+        """[B, in_channels, R, R] of this network (the C ABI takes a pointer and a count: a wrong shape would be read
+        as garbage, not refused; the batch bound is checked there)."""
+        want = (self.cfg.in_channels, self.cfg.resolution, self.cfg.resolution)
+        if x.dim() != 4 or tuple(x.shape[1:]) != want:
+            raise ValueError(f"input must be [B, {want[0]}, {want[1]}, {want[2]}], got {tuple(x.shape)}")
+
     def unet_forward(self, x: torch.Tensor, t: float) -> torch.Tensor:
         _chk_dev(x)
+        self._chk_input(x)
         if self.cfg.arch in ("dec", "enc"):      # decoder / encoder: [B, C_in, R, R] -> [B, out_ch, R_out, R_out]
             eps = torch.empty(x.shape[0], self.cfg.out_ch, self.cfg.out_resolution, self.cfg.out_resolution,
                               device=x.device, dtype=torch.float32)
@@ -200,6 +208,7 @@ class LocoEngine:
 
     def ddim_step(self, x, t, at, at_next, eta=0.0, noise=None, out=None):
         _chk_dev(x)
+        self._chk_input(x)
         if noise is not None:
             _chk_dev(noise)
         out = torch.empty_like(x) if out is None else out
@@ -220,6 +229,8 @@ class LocoEngine:
     # ---- PMP-Jacobian operator
     def pmp_primal(self, x, t, at, mask: Optional[torch.Tensor] = None, use_et: bool = False):
         _chk_dev(x)
+        if x.numel() != self.n:
+            raise ValueError(f"the linearisation point is one sample of {self.n} elements, got {tuple(x.shape)}")
         m8 = None
         if mask is not None:
             m8 = mask.to(device=x.device, dtype=torch.uint8).contiguous().view(-1)

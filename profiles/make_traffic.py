@@ -1,11 +1,11 @@
 """Aggregate two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as the MI355X guide
 prescribes) into profiles/traffic.json: HBM-side bytes per launch for each conv kernel variant.
-Units: FETCH_SIZE / WRITE_SIZE are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports
-exactly half of the bytes of 16-B-per-lane streaming reads.  The vector-staged conv variants (7th template
-parameter 0) read activations, the primal {S, xhat} cache and the weight records with 16-B-per-lane loads /
-LDS-DMA, so their FETCH bytes are DOUBLED; the per-pixel variants (7th parameter 1, 2) read activations with
-dword loads, for which the raw counter matched the analytical byte count within 3 % in round 1 (DESIGN.md
-section 4) and is left as is.  WRITE_SIZE is exact for these stores.
+Units: FETCH_SIZE / WRITE_SIZE are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of the bytes of
+a WIDE COALESCED streaming read (16 B per lane, 1 KiB per wave); other patterns are to be calibrated on a known byte count.
+The conv kernels read 64-byte runs of halo rows (four lanes x 16 B), and the calibration on their own pattern
+(profiles/r03_fetch_size_calibration.md: the tangent form's extra fetch at one probe is 69.0 MB raw against 67.1 MB of unique /
+89.5 MB of requested primal-cache bytes) shows the raw counter is exact for them: NO doubling (rounds 1-2 doubled the
+vector-staged variants and over-stated their traffic).  WRITE_SIZE is exact for these stores.
 
 The result carries the sha256 of the libloco_hip.so it was measured on (`_lib_sha256`): bench.py only reports
 `roofline.traffic` from a traffic.json whose hash matches the library it is running (a stale file yields null).
@@ -34,8 +34,7 @@ outdir = sys.argv[4] if len(sys.argv) > 4 else os.path.dirname(os.path.abspath(_
 F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 out, rows = {}, []
 def fetch_corr(name):
-    m = re.match(r"void loco::conv_mfma_bf16x3<([\d, ]+)>", name)
-    return 2.0 if m and m.group(1).replace(" ", "").split(",")[-1] == "0" else 1.0
+    return 1.0      # calibrated on the kernel's own access pattern, see the header
 
 for k in F:
     n = norm(k)
@@ -55,8 +54,8 @@ lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 res = {k: round(v["bytes"]) for k, v in out.items()}
 res["_lib_sha256"] = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
 res["_source"] = (f"profiles/{tag}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of `bench.py --steps 1 "
-                  "--warmup 0`, mean bytes per launch of each conv variant; FETCH doubled for the variants that stream with "
-                  "16-byte loads / LDS-DMA (gfx950 counts those at half), WRITE exact for 16-byte streaming stores")
+                  "--warmup 0`, mean bytes per launch of each conv variant; raw counters x 1024 (calibrated on the kernel's own "
+                  "64-byte-run access pattern: profiles/r03_fetch_size_calibration.md), WRITE exact for 16-byte streaming stores")
 json.dump(res, open(os.path.join(here, "traffic.json"), "w"), indent=1)
 with open(os.path.join(here, f"{tag}_pmc_traffic_per_kernel.csv"), "w") as fh:
     fh.write("kernel,launches,fetch_bytes_per_launch_corrected,write_bytes_per_launch\n")

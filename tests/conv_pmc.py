@@ -10,5 +10,6 @@ eng.load_state_dict(synth_params(CELEBA_DDPM, 0))
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
 eng.set_precision(prec)
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-ms = eng.bench_conv(128, 128, 256, 256, 5, mode, 9, 5, 3)
-print(f"{prec} mode {mode}: {ms*1e3:.1f} us")
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+ms = eng.bench_conv(128, 128, 256, 256, B, mode, 9, 5, 3)
+print(f"{prec} mode {mode} B {B}: {ms*1e3:.1f} us")

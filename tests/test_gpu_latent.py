@@ -288,6 +288,75 @@ def test_latent_solver_at_stable_diffusion_size(tmp_path):
     assert (vd @ vd.T - torch.eye(3, device=DEV, dtype=torch.float64)).abs().max().item() < 2e-6
 
 
+def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
+    """BASELINE config 4 on `config.SD15_UNET` itself (859.5 M parameters: SpatialTransformer blocks at the 64 / 32 / 16
+    latent levels and in the middle block, 8 heads of 40 / 80 / 160 channels, 77 x 768 prompt states) with the SD
+    autoencoder's decoder, mask on the decoded 3x512x512 image.  Forward of the denoiser against the CPU restatement at
+    full size; the composed CFG operator: adjointness, linearity, a finite difference of the decoded x0_hat (exact-fp32
+    engine), masked rows; a 2-iteration solve: shapes, orthonormal descending basis.  Architecture parity against
+    diffusers' weights stays unpinned (no diffusers, no weights)."""
+    from loco_edit_amd.config import SD15_UNET, SD_VAE_DECODER
+    from loco_edit_amd.tloco_sd import EditStableDiffusion
+    os.environ.pop("WORLD_SIZE", None)
+
+    def build(prec):
+        args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=SD15_UNET, vae_config=SD_VAE_DECODER,
+                         synthetic_weights=0, ckpt_path="", vae_ckpt_path="", max_batch=4, precision=prec, dataset_name="Random",
+                         for_steps=100, use_yh_custom_scheduler=True, guidance_scale=7.5, guidance_scale_edit=4.0, prompt_emb=None,
+                         prompt_emb_seed=31, for_prompt="a", edit_prompt="b", edit_t=0.7, sampling_mode=False,
+                         tilda_v_score_type="null+(for-null)+(edit-null)", ablation_method="null-space-proj", mask_type="SAM",
+                         vT_path="", use_sega=False, x_space_guidance_edit_step=1.0, x_space_guidance_scale=8.0,
+                         x_space_guidance_num_step=1, result_folder=str(tmp_path))
+        return EditStableDiffusion(args)
+    ed = build("bf16x3")
+    assert ed.cfg is SD15_UNET and ed.use_context and tuple(ed.for_prompt_emb.shape) == (1, 77, 768)
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(1, 4, 64, 64, generator=g).to(DEV)
+    mask = torch.zeros(3, 512, 512, dtype=torch.bool); mask[:, 220:260, 140:220] = True
+    t = ed.scheduler.timesteps[ed.edit_t_idx]
+    F, E, N = ed.for_prompt_emb, ed.edit_prompt_emb, ed.null_prompt_emb
+    # ---- the denoiser against the restatement, full width (one evaluation on the host: ~0.8 TFLOP)
+    p = orc.to_torch(synth_params(SD15_UNET, 0))
+    with torch.no_grad():
+        ref = orc.unet_forward_adm(p, SD15_UNET, z.cpu(), torch.tensor(float(t)), context=F[0])
+    del p
+    ed._bind_all(F, E, N)
+    e = rel(ed.branches["for"].unet_forward(z, float(t)), ref)
+    print(f"SD15 U-Net forward at size, bf16x3 vs CPU restatement: rel err {e:.2e}")
+    assert e < TOL["bf16x3"]
+    # ---- the composed operator J = J_dec . s (I - sigma sum_c w_c J_eps,c), mask on the image
+    x0 = ed.get_x0(z, t, ed.edit_t_idx, F, E, N, mask=None, mode="null+(for-null)")
+    assert tuple(x0.shape) == (1, 3, 512, 512) and torch.isfinite(x0).all()
+    op = ed._operator(z, t, mask.to(DEV), "null+(for-null)")
+    V = torch.randn(2, 4 * 64 * 64, generator=g).to(DEV)
+    U = (torch.randn(2, 3 * 512 * 512, generator=g) * mask.reshape(1, -1)).to(DEV)
+    JV, JtU = op.jvp(V), op.vjp(U)
+    lhs, rhs = (JV.double() * U.double()).sum(dim=1), (V.double() * JtU.double()).sum(dim=1)
+    assert ((lhs - rhs).abs() / (JV.norm(dim=1) * U.norm(dim=1)).double()).max().item() < 2e-4      # split-bf16 passes
+    assert float(JV[:, ~mask.reshape(-1).to(DEV)].abs().max()) == 0.0 and op.dec.mask_count() == int(mask.sum())
+    comb = op.jvp((V[0:1] * 0.5 - V[1:2] * 2.0).contiguous())
+    assert rel(comb, JV[0:1] * 0.5 - JV[1:2] * 2.0) < 1e-3
+    u, s, vT = ed.local_encoder_decoder_pullback_zt(z, t, ed.edit_t_idx, F, E, N, pca_rank=3, min_iter=2, max_iter=2,
+                                                    mask=mask.to(DEV), mode="null+(for-null)", verbose=False)
+    assert u.shape == (int(mask.sum()), 3) and vT.shape == (3, 16384) and bool((s[:-1] >= s[1:]).all())
+    vd = vT.double()
+    assert (vd @ vd.T - torch.eye(3, device=DEV, dtype=torch.float64)).abs().max().item() < 2e-6
+    del ed, op
+    torch.cuda.empty_cache()
+    # ---- finite difference of the decoded x0_hat along a probe, exact-fp32 engine
+    ed = build("f32")
+    opf = ed._operator(z, t, None, "null+(for-null)")
+    v = V[0:1] / V[0:1].norm()
+    jv = opf.jvp(v.contiguous())
+    best = 1.0
+    for h in (2e-2, 1e-2):
+        xp = ed.get_x0(z + h * v.view_as(z), t, ed.edit_t_idx, F, E, N, mask=None, mode="null+(for-null)")
+        xm = ed.get_x0(z - h * v.view_as(z), t, ed.edit_t_idx, F, E, N, mask=None, mode="null+(for-null)")
+        best = min(best, rel(((xp - xm) / (2 * h)).reshape(1, -1), jv))
+    print(f"SD15 composed operator, finite difference vs J v (f32 engine): {best:.2e}")
+    assert best < 2.5e-2
+
+
 def test_long_attention_products_on_the_bf16_pipe():
     """A decoder whose mid attention has 4096 tokens x 256 channels: in the split-bf16 mode its score / value products
     (and their tangent / cotangent forms) run on `gemm_bf16x3_kernel` (K >= 256, >= 4e9 MACs per launch).  Forward vs
@@ -328,7 +397,7 @@ def test_text_cross_attention_stages_vs_restatement(prec):
     eng.load_state_dict(params)
     eng.set_precision(prec)
     g = torch.Generator().manual_seed(41)
-    z = torch.randn(1, 4, 16, 16, generator=g)
+    z = torch.randn(1, 4, cfg.resolution, cfg.resolution, generator=g)
     ctx = torch.randn(cfg.context_len, cfg.context_dim, generator=g)
     t = torch.tensor(603.0)
     with pytest.raises(RuntimeError):
@@ -402,16 +471,18 @@ def test_latent_tloco_with_text_cross_attention_vs_restatement(tmp_path):
 # the latent-diffusion (Stable Diffusion v1) denoiser itself: guided-diffusion skeleton without scale-shift norm, conv
 # down / up-sampling, SpatialTransformer blocks (GroupNorm -> proj_in -> LayerNorm / self-attention, LayerNorm /
 # cross-attention, LayerNorm / GEGLU feed-forward -> proj_out)
+@pytest.mark.parametrize("which", ["tiny", "wide320"])
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
-def test_ldm_unet_with_spatial_transformer_vs_restatement(prec):
+def test_ldm_unet_with_spatial_transformer_vs_restatement(prec, which):
     """`TINY_LDM` (config.SD15_UNET's layout at a size the CPU differentiates in seconds): forward on a batch, J V and
     U^T J of eps against autodiff of the CPU restatement (oracle/loco_oracle.py: the skeleton is pinned bit-exactly
     against the reference's own `UNetModel(use_scale_shift_norm=False, resblock_updown=False)`, the SpatialTransformer is
     restated from the published latent-diffusion module), adjointness, and the parameter count of the full-width preset
     (859 520 964 = Stable Diffusion v1.x)."""
     import numpy as np
-    from loco_edit_amd.config import SD15_UNET, TINY_LDM as cfg, param_shapes
+    from loco_edit_amd.config import SD15_UNET, TINY_LDM, WIDE_LDM, param_shapes
     from loco_edit_amd.hip import LocoEngine
+    cfg = TINY_LDM if which == "tiny" else WIDE_LDM      # wide320: Stable Diffusion's first-level width (LayerNorm over 320)
     assert sum(int(np.prod(v)) for v in param_shapes(SD15_UNET).values()) == 859_520_964
     params = synth_params(cfg, 0)
     p = orc.to_torch(params)
@@ -419,7 +490,7 @@ def test_ldm_unet_with_spatial_transformer_vs_restatement(prec):
     eng.load_state_dict(params)
     eng.set_precision(prec)
     g = torch.Generator().manual_seed(43)
-    z = torch.randn(1, 4, 16, 16, generator=g)
+    z = torch.randn(1, 4, cfg.resolution, cfg.resolution, generator=g)
     ctx = torch.randn(cfg.context_len, cfg.context_dim, generator=g)
     t = torch.tensor(603.0)
     eng.set_context(ctx.to(DEV).contiguous())
