@@ -129,6 +129,7 @@ struct loco_ctx {
     float *stpart = nullptr, *stpart2 = nullptr;   // row partials of the statistics taken in conv epilogues (lane 0 / lane 1)
     size_t stpart_floats = 0;
     bool fuse_stats = true;        // LOCO_FUSE_STATS=0: every statistics pass as its own kernels (A/B timing)
+    bool fuse_xattn = true;        // LOCO_FUSE_XATTN=0: cross-attention as strided GEMM + row kernel + strided GEMM (A/B)
     bool deep1 = true;             // LOCO_DEEP1=0: 1x1 operators on the two-buffer stage loop instead of the register ring (A/B)
     bool flash_attn = true;        // LOCO_FLASH_ATTN=0: tangent / cotangent attention on the generic GEMM + softmax-Jacobian path
     float* attn_delta = nullptr;   // [max_batch][heads][tokens] scratch of the flash cotangent
@@ -1375,6 +1376,19 @@ void xa_values(const XA& x, const float* K, const float* S, long s_bs, float* O,
     g.M = x.CH; g.N = x.T; g.K = x.Lp; g.batch = x.B; g.batch2 = x.NH; g.alpha = 1.f; g.beta = 0.f;
     launch_gemm(g, x.st);
 }
+// the three steps of one pass (scores, row operation, values) as one kernel where the shape allows (LOCO_FUSE_XATTN=0: off)
+//   kind 0 forward: P = softmax(scale X^T K1) -> Pout (per sample), O = K2 P^T
+//   kind 1 tangent / cotangent: R = scale P o (X^T K1 - <P, X^T K1>) with the primal P, O = K2 R^T
+bool xa_fused(const XA& x, int kind, const float* X, long x_bs, const float* K1, const float* K2, float* P, long p_bs,
+              float* O, long o_bs) {
+    loco_ctx* c = x.c;
+    if (!c->fuse_xattn || !xattn_fused_supported(x.T, x.CH, c->cfg.context_len, x.Lp)) return false;
+    XAttnArgs a; std::memset(&a, 0, sizeof(a));
+    a.T = x.T; a.NH = x.NH; a.B = x.B; a.CH = x.CH; a.L = c->cfg.context_len; a.Lp = x.Lp; a.fwd = kind == 0;
+    a.alpha = x.scale; a.X = X; a.x_bs = x_bs; a.K1 = K1; a.K2 = K2; a.P = P; a.p_bs = p_bs; a.O = O; a.o_bs = o_bs;
+    launch_xattn_fused(a, x.st);
+    return true;
+}
 void xa_conv1x1(loco_ctx* c, const ConvP& w, bool dgrad, const float* in, long in_bs, float* out, long out_bs, int C, int H,
                 int W, int B, const float* res, long res_bs, bool with_bias, hipStream_t st, const StatReq* rq = nullptr) {
     ConvArgs a; conv_defaults(a);
@@ -1632,9 +1646,11 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                     qa.mode = CM_GN; qa.sc = sx.sc; qa.sh = sx.sh; qa.scsh_bs = SB;
                     qa.out = p.T(op.xq); qa.out_bs = p.bs(); qa.Cout = C; qa.Hout = to.H; qa.Wout = to.W; qa.B = B;
                     run_conv(c, qa, 1, st);
-                    xa_scores(x, p.T(op.xq), p.bs(), op.xK, p.T(op.xS), p.bs(), x.scale, true);
-                    launch_softmax_rows(p.T(op.xS), (long)NH * T, x.Lp, st, B, p.bs());
-                    xa_values(x, op.xV, p.T(op.xS), p.bs(), p.T(op.xo), p.bs());
+                    if (!xa_fused(x, 0, p.T(op.xq), p.bs(), op.xK, op.xV, p.T(op.xS), p.bs(), p.T(op.xo), p.bs())) {
+                        xa_scores(x, p.T(op.xq), p.bs(), op.xK, p.T(op.xS), p.bs(), x.scale, true);
+                        launch_softmax_rows(p.T(op.xS), (long)NH * T, x.Lp, st, B, p.bs());
+                        xa_values(x, op.xV, p.T(op.xS), p.bs(), p.T(op.xo), p.bs());
+                    }
                     const StatReq rqx = next_fwd(op.out);
                     xa_conv1x1(c, op.xproj, false, p.T(op.xo), p.bs(), p.T(op.out), p.bs(), C, to.H, to.W, B,
                                p.T(op.xmid), p.bs(), true, st, &rqx);
@@ -1666,9 +1682,11 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 // x = x + attn2(LN2(x), context)
                 launch_ln_fwd(X(X_H1), PSb, B, C, T, op.lng[1], op.lnb[1], 1e-5f, X(X_A2), PSb, X(X_LN2), PSb, st);
                 lin1x1(c, op.xqc, false, X(X_A2), PSb, C, X(X_XQ), PSb, C, H, W, B, nullptr, 0, false, st);
-                xa_scores(xa, X(X_XQ), PSb, op.xK, X(X_XS), PSb, xa.scale, true);
-                launch_softmax_rows(X(X_XS), (long)NH * T, xa.Lp, st, B, PSb);
-                xa_values(xa, op.xV, X(X_XS), PSb, X(X_XO), PSb);
+                if (!xa_fused(xa, 0, X(X_XQ), PSb, op.xK, op.xV, X(X_XS), PSb, X(X_XO), PSb)) {
+                    xa_scores(xa, X(X_XQ), PSb, op.xK, X(X_XS), PSb, xa.scale, true);
+                    launch_softmax_rows(X(X_XS), (long)NH * T, xa.Lp, st, B, PSb);
+                    xa_values(xa, op.xV, X(X_XS), PSb, X(X_XO), PSb);
+                }
                 lin1x1(c, op.to_out2, false, X(X_XO), PSb, C, X(X_H2), PSb, C, H, W, B, X(X_H1), PSb, true, st);
                 // x = x + Linear(GEGLU(LN3(x)))
                 launch_ln_fwd(X(X_H2), PSb, B, C, T, op.lng[2], op.lnb[2], 1e-5f, X(X_A3), PSb, X(X_LN3), PSb, st);
@@ -1878,9 +1896,11 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                     launch_gn_apply(1, TT(op.xmid), PS, TP(op.xmid), 0, nullptr, 0, TT(op.xhn), PS, 0, B, C, HW,
                                     cfg.gn_groups, spx.sc, spx.sh, spx.mr, 0, 0, stx.tst, c->stats_per_sample, st);
                     xa_conv1x1(c, op.xqc, false, TT(op.xhn), PS, TT(op.xq), PS, C, to.H, to.W, B, nullptr, 0, false, st);
-                    xa_scores(x, TT(op.xq), PS, op.xK, TT(op.xS), PS, 1.f, false);                  // dS = dq^T K
-                    launch_softmax_jac(TT(op.xS), TP(op.xS), (long)NH * T, x.Lp, (long)NH * T, x.scale, st, B, PS);
-                    xa_values(x, op.xV, TT(op.xS), PS, TT(op.xo), PS);                              // do = V dP^T
+                    if (!xa_fused(x, 1, TT(op.xq), PS, op.xK, op.xV, TP(op.xS), 0, TT(op.xo), PS)) {
+                        xa_scores(x, TT(op.xq), PS, op.xK, TT(op.xS), PS, 1.f, false);                  // dS = dq^T K
+                        launch_softmax_jac(TT(op.xS), TP(op.xS), (long)NH * T, x.Lp, (long)NH * T, x.scale, st, B, PS);
+                        xa_values(x, op.xV, TT(op.xS), PS, TT(op.xo), PS);                              // do = V dP^T
+                    }
                     const StatReq rqx = next_tan(op.out);
                     xa_conv1x1(c, op.xproj, false, TT(op.xo), PS, TT(op.out), PS, C, to.H, to.W, B, TT(op.xmid), PS, false, st, &rqx);
                 }
@@ -1904,9 +1924,11 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 lin1x1(c, op.to_out1, false, XT_(X_O), PS, C, XT_(X_H1), PS, C, H, W, B, XT_(X_H0), PS, false, st);
                 launch_ln_tan(XT_(X_H1), PS, XP(X_H1), XP(X_LN2), B, C, T, op.lng[1], XT_(X_A2), PS, st);
                 lin1x1(c, op.xqc, false, XT_(X_A2), PS, C, XT_(X_XQ), PS, C, H, W, B, nullptr, 0, false, st);
-                xa_scores(xa, XT_(X_XQ), PS, op.xK, XT_(X_XS), PS, 1.f, false);                   // dS = dq^T K
-                launch_softmax_jac(XT_(X_XS), XP(X_XS), (long)NH * T, xa.Lp, (long)NH * T, xa.scale, st, B, PS);
-                xa_values(xa, op.xV, XT_(X_XS), PS, XT_(X_XO), PS);                              // do = V dP^T
+                if (!xa_fused(xa, 1, XT_(X_XQ), PS, op.xK, op.xV, XP(X_XS), 0, XT_(X_XO), PS)) {
+                    xa_scores(xa, XT_(X_XQ), PS, op.xK, XT_(X_XS), PS, 1.f, false);                   // dS = dq^T K
+                    launch_softmax_jac(XT_(X_XS), XP(X_XS), (long)NH * T, xa.Lp, (long)NH * T, xa.scale, st, B, PS);
+                    xa_values(xa, op.xV, XT_(X_XS), PS, XT_(X_XO), PS);                              // do = V dP^T
+                }
                 lin1x1(c, op.to_out2, false, XT_(X_XO), PS, C, XT_(X_H2), PS, C, H, W, B, XT_(X_H1), PS, false, st);
                 launch_ln_tan(XT_(X_H2), PS, XP(X_H2), XP(X_LN3), B, C, T, op.lng[2], XT_(X_A3), PS, st);
                 lin1x1(c, op.ff1, false, XT_(X_A3), PS, C, XT_(X_F), PS, 8 * C, H, W, B, nullptr, 0, false, st);
@@ -2079,9 +2101,11 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                     // cotangent of the cross-attention stage: g_out -> g_xmid (residual + the q path through GN)
                     const XA x = xa_of(c, op, B, st);
                     xa_conv1x1(c, op.xproj, true, TG(op.out), PS, TG(op.xo), PS, C, to.H, to.W, B, nullptr, 0, false, st);
-                    xa_scores(x, TG(op.xo), PS, op.xV, TG(op.xS), PS, 1.f, false);                  // g_P = g_o^T V
-                    launch_softmax_jac(TG(op.xS), TP(op.xS), (long)NH * T, x.Lp, (long)NH * T, x.scale, st, B, PS);
-                    xa_values(x, op.xK, TG(op.xS), PS, TG(op.xq), PS);                              // g_q = K g_S^T
+                    if (!xa_fused(x, 1, TG(op.xo), PS, op.xV, op.xK, TP(op.xS), 0, TG(op.xq), PS)) {
+                        xa_scores(x, TG(op.xo), PS, op.xV, TG(op.xS), PS, 1.f, false);                  // g_P = g_o^T V
+                        launch_softmax_jac(TG(op.xS), TP(op.xS), (long)NH * T, x.Lp, (long)NH * T, x.scale, st, B, PS);
+                        xa_values(x, op.xK, TG(op.xS), PS, TG(op.xq), PS);                              // g_q = K g_S^T
+                    }
                     xa_conv1x1(c, op.xqc, true, TG(op.xq), PS, TG(op.xhn), PS, C, to.H, to.W, B, nullptr, 0, false, st);
                     cot_stats(c, op.nx, TG(op.xhn), PS, TP(op.xmid), HW, B, 2, st);
                     NS spx = nstats(c, c->statsP, op.nx);
@@ -2158,9 +2182,11 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 launch_ln_cot(XG(X_A3), PS, XP(X_H2), XP(X_LN3), B, C, T, op.lng[2], XG(X_H3), PS, XG(X_H2), PS, st);  // g_h2
                 // cross-attention: h2 = h1 + to_out2(V P^T), q = to_q(LN2(h1))
                 lin1x1(c, op.to_out2, true, XG(X_H2), PS, C, XG(X_XO), PS, C, H, W, B, nullptr, 0, false, st);
-                xa_scores(xa, XG(X_XO), PS, op.xV, XG(X_XS), PS, 1.f, false);                     // g_P = g_o^T V
-                launch_softmax_jac(XG(X_XS), XP(X_XS), (long)NH * T, xa.Lp, (long)NH * T, xa.scale, st, B, PS);
-                xa_values(xa, op.xK, XG(X_XS), PS, XG(X_XQ), PS);                                // g_q = K g_S^T
+                if (!xa_fused(xa, 1, XG(X_XO), PS, op.xV, op.xK, XP(X_XS), 0, XG(X_XQ), PS)) {
+                    xa_scores(xa, XG(X_XO), PS, op.xV, XG(X_XS), PS, 1.f, false);                     // g_P = g_o^T V
+                    launch_softmax_jac(XG(X_XS), XP(X_XS), (long)NH * T, xa.Lp, (long)NH * T, xa.scale, st, B, PS);
+                    xa_values(xa, op.xK, XG(X_XS), PS, XG(X_XQ), PS);                                // g_q = K g_S^T
+                }
                 lin1x1(c, op.xqc, true, XG(X_XQ), PS, C, XG(X_A2), PS, C, H, W, B, nullptr, 0, false, st);
                 launch_ln_cot(XG(X_A2), PS, XP(X_H1), XP(X_LN2), B, C, T, op.lng[1], XG(X_H2), PS, XG(X_H1), PS, st);  // g_h1
                 // self-attention: h1 = h0 + to_out1(attn(qkv(LN1(h0))))
@@ -2310,6 +2336,8 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         c->fuse_stats = !(e && atoi(e) == 0);
         e = getenv("LOCO_DEEP1");
         c->deep1 = !(e && atoi(e) == 0);
+        e = getenv("LOCO_FUSE_XATTN");
+        c->fuse_xattn = !(e && atoi(e) == 0);
         const char* fa = getenv("LOCO_FLASH_ATTN");
         c->flash_attn = !(fa && atoi(fa) == 0);
         long dmax = 1;

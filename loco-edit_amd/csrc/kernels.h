@@ -136,6 +136,17 @@ void launch_ln_tan(const float* dx, long dbs, const float* xprim, const float* s
 void launch_ln_cot(const float* gy, long gbs, const float* xprim, const float* sprim, int B, int C, int T, const float* gamma,
                    const float* base, long base_bs, float* gx, long xbs, hipStream_t st);
 // GEGLU on f = [value | gate] (2 * n4 floats per sample): kind 0 forward, 1 tangent (in = df), 2 cotangent (in = g of the output)
+// fused text cross-attention of one pass (xattn.hip): scores of X against K1 -> row operation -> values out of K2
+struct XAttnArgs {
+    int T, NH, B, CH, L, Lp, fwd;     // tokens, heads, samples, channels per head, real / padded context length; fwd: softmax (writes P)
+    float alpha;                      // softmax scale
+    const float* X; long x_bs;        // [B][C][T]: q (forward), dq (tangent), g_o (cotangent)
+    const float* K1; const float* K2; // [C][Lp]: forward / tangent K_ctx, V_ctx; cotangent V_ctx, K_ctx
+    float* P; long p_bs;              // [.][NH][T][Lp]: written by the forward (per sample), read by the others (sample 0)
+    float* O; long o_bs;              // [B][C][T]
+};
+bool xattn_fused_supported(int T, int CH, int L, int Lp);
+void launch_xattn_fused(const XAttnArgs& a, hipStream_t st);
 void launch_geglu(int kind, const float* in, long in_bs, const float* fprim, int B, long n4, float* out, long out_bs,
                   hipStream_t st);
 

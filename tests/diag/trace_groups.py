@@ -3,7 +3,7 @@ import csv, sys
 from collections import defaultdict
 d = defaultdict(lambda: [0, 0])
 for r in csv.DictReader(open(sys.argv[1])):
-    n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("loco::", "").replace("(anonymous namespace)::", "")[:60]
+    n = r["Kernel_Name"].replace("void ", "").replace("loco::", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
     key = (n, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")), r.get("LDS_Block_Size", ""))
     d[key][0] += 1; d[key][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 tot = sum(v[1] for v in d.values())
