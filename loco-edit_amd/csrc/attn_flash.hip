@@ -149,7 +149,6 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     const int own0 = blockIdx.x * NOWN;            // first own token of the workgroup
     const int mytok = own0 + wave * 32 + l31;      // the lane's own token (column of every D fragment)
     const int nch = a.CH;                          // head width (<= 64; narrower heads run zero-padded)
-    const int nck = (nch + 15) >> 4;               // 16-channel k-steps of the score products that hold channels
     const long HS = a.hs, HO = (long)nch * T;
     const float* q = a.q + h * HS;  const float* k = a.k + h * HS;  const float* v = a.v + h * HS;
     const float* P = a.P + (long)h * T * T;
@@ -241,7 +240,6 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
             for (int r = 0; r < 16; ++r) s_[mt][r] = 0.f;
 #pragma unroll
             for (int ck = 0; ck < 4; ++ck) {
-                if (ck >= nck) continue;            // heads narrower than 64 channels: the zero k-steps are skipped (uniform)
                 mma3(s_[mt], ld_frag(RA + (ck * NBLK + 32 * mt + l31) * RP, khalf), y1[ck]);
                 if (MODE == M_TAN) mma3(s_[mt], ld_frag(RA + 4 * NBLK * RP + (ck * NBLK + 32 * mt + l31) * RP, khalf), y2[ck]);
             }
