@@ -364,7 +364,8 @@ def main():
             u, s, vT = ed.local_encoder_decoder_pullback_xt(x, tt, ed.edit_t_idx, F_, E_, N_, pca_rank=k, min_iter=N_ITER,
                                                             max_iter=N_ITER, mask=~mask, mode="null+(for-null)", v0=v0, verbose=False)
             return u, s, vT, ed.last_n_iter
-        return dict(cfg=cfg, k=k, keep=k, eng=ed.engine, params=None, step=step, x=x, mask=~mask, v0=v0, branches=2)
+        return dict(cfg=cfg, k=k, keep=k, eng=ed.engine, params=None, step=step, x=x, mask=~mask, v0=v0, branches=2,
+                    branch_streams=ed.branch_streams.enabled)
 
     def make_tloco_sd(prec, real=False):
         """config 4: CFG-combined subspace solve of the DECODED image's Jacobian w.r.t. the latent (denoiser engines per
@@ -399,7 +400,8 @@ def main():
             u, s, vT = ed.local_encoder_decoder_pullback_zt(z, tt, ed.edit_t_idx, F_, E_, N_, pca_rank=k, min_iter=N_ITER,
                                                             max_iter=N_ITER, mask=mask, mode="null+(for-null)", v0=v0, verbose=False)
             return u, s, vT, ed.last_n_iter
-        return dict(cfg=cfg, k=k, keep=k, eng=ed.engine, params=None, step=step, x=z, mask=mask, v0=v0, branches=2, dec=ed.vae_engine)
+        return dict(cfg=cfg, k=k, keep=k, eng=ed.engine, params=None, step=step, x=z, mask=mask, v0=v0, branches=2, dec=ed.vae_engine,
+                    branch_streams=ed.branch_streams.enabled)
 
     def make_workload(name, prec):
         if name == "tloco_if64":
@@ -633,7 +635,10 @@ def main():
                        "convergence_check": "not executed inside the timed region (min_iter == max_iter == 12; the "
                                             "reference flow with min_iter=10 adds one 2-float readback per iteration after the 11th)"},
             "singular_values": [round(float(v), 4) for v in s.tolist()[:5]],
-            "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "extra_workloads": extra or None,
+            "parity": parity, "roofline": roofline,
+            **({"cfg_branch_streams": "the CFG branches (one engine context per prompt) run side by side on two HIP streams "
+                "(LOCO_CFG_STREAMS=0: one after the other); kernels of the two branches overlap, so this workload's per-kernel "
+                "averages are durations under overlap, not isolated kernel times"} if w.get("branch_streams") else {}), "cpu_baseline": cpu, "e2e": e2e, "extra_workloads": extra or None,
             "distinct_gpus": n_distinct_gpus,
             # the headline scales WEAKLY (5 probes per rank: a wider basis of the same image); the line the north-star
             # ">= 6x at 8 GPUs" is about is the STRONG-scaling 64-probe workload of the same run:

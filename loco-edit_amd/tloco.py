@@ -111,10 +111,38 @@ def cfg_weights(mode: str, g: float, ge: float, do_cfg: bool = True) -> List[Tup
     return table[mode]
 
 
+class BranchStreams:
+    """The CFG branches are independent engine contexts evaluating the same input under different prompts: their passes
+    run side by side on separate HIP streams and join before the combination.  At 64x64 a 5-probe pass leaves most launches
+    below one workgroup per CU, so two or three branches fill the chip where one does not (the reference batches the
+    prompts through one U-Net call, edit.py:1319-1322; here each prompt owns a context with its own cached primal).
+    ``LOCO_CFG_STREAMS=0``: one branch after the other on the current stream."""
+
+    def __init__(self, n: int, device):
+        self.enabled = os.environ.get("LOCO_CFG_STREAMS", "1") != "0" and torch.device(device).type == "cuda" and n > 1
+        self.side = [torch.cuda.Stream(device=device) for _ in range(n - 1)] if self.enabled else []
+
+    def run(self, fns):
+        if not self.enabled or len(fns) < 2:
+            return [f() for f in fns]
+        main = torch.cuda.current_stream()
+        outs = [None] * len(fns)
+        for i, f in enumerate(fns[1:]):
+            self.side[i].wait_stream(main)                 # the inputs were produced on the current stream
+            with torch.cuda.stream(self.side[i]):
+                outs[i + 1] = f()
+        outs[0] = fns[0]()
+        for i in range(len(fns) - 1):
+            main.wait_stream(self.side[i])
+            if isinstance(outs[i + 1], torch.Tensor):
+                outs[i + 1].record_stream(main)            # allocated under the side stream, consumed on this one
+        return outs
+
+
 class CFGJacobianOperator:
     """J and J^T of x0_hat(x_t) under classifier-free guidance, assembled from the per-prompt engines."""
 
-    def __init__(self, branches: Dict[str, LocoEngine], weights, x, t, at, mask):
+    def __init__(self, branches: Dict[str, LocoEngine], weights, x, t, at, mask, streams: Optional[BranchStreams] = None):
         self.w = [(branches[name], w) for name, w in weights if w != 0.0]
         self.lead = self.w[0][0]
         self.n = self.lead.n
@@ -122,20 +150,24 @@ class CFGJacobianOperator:
         self.masked = mask is not None
         self.cv = 1.0 / float(np.sqrt(np.float32(at)))
         self.ce = -float(np.sqrt(np.float32(1.0) - np.float32(at))) / float(np.sqrt(np.float32(at)))
-        for eng, _ in self.w:
-            eng.pmp_primal(x.contiguous(), float(t), at, mask, use_et=True)      # dEps products; x0 algebra applied here
+        self.streams = streams or BranchStreams(1, "cpu")
+        xc = x.contiguous()
+        # dEps products; x0 algebra applied here
+        self.streams.run([(lambda e=eng: e.pmp_primal(xc, float(t), at, mask, use_et=True)) for eng, _ in self.w])
 
     def check_mask(self):
         if self.masked and self.lead.mask_count() == 0:
             raise ValueError("empty mask: J = d x0_hat[mask] / d x_t has no rows")
 
     def jvp(self, V):
-        terms = [(w, eng.pmp_jvp(V)) for eng, w in self.w]
+        outs = self.streams.run([(lambda e=eng: e.pmp_jvp(V)) for eng, _ in self.w])
+        terms = [(w, o) for (_, w), o in zip(self.w, outs)]
         dE = terms[0][1] if (len(terms) == 1 and terms[0][0] == 1.0) else self.lead.lincomb(terms)
         return self.lead.masked_axpby(V, dE, self.cv, self.ce)
 
     def vjp(self, U):
-        terms = [(self.ce * w, eng.pmp_vjp(U)) for eng, w in self.w]
+        outs = self.streams.run([(lambda e=eng: e.pmp_vjp(U)) for eng, _ in self.w])
+        terms = [(self.ce * w, o) for (_, w), o in zip(self.w, outs)]
         terms.append((1.0, self.lead.masked_axpby(U, U, self.cv, 0.0)))
         return self.lead.lincomb(terms)
 
@@ -196,6 +228,7 @@ class EditDeepFloydIF(object):
                 eng.set_precision(prec)
             self.branches[name] = eng
         self.engine = self.branches["for"]
+        self.branch_streams = BranchStreams(len(self.branches), self.device)
         self._cond_of: Dict[str, int] = {}
         for name, e in (("for", self.for_prompt_emb), ("edit", self.edit_prompt_emb), ("null", self.null_prompt_emb)):
             self._bind(name, e)
@@ -250,7 +283,8 @@ class EditDeepFloydIF(object):
         out = torch.empty_like(x)
         for b0 in range(0, x.shape[0], mb):
             xs = x[b0:b0 + mb].contiguous()
-            terms = [(w, self.branches[name].unet_forward(xs, float(t))) for name, w in weights]
+            outs = self.branch_streams.run([(lambda n=name: self.branches[n].unet_forward(xs, float(t))) for name, _ in weights])
+            terms = [(w, o) for (_, w), o in zip(weights, outs)]
             out[b0:b0 + mb] = terms[0][1] if (len(terms) == 1 and terms[0][0] == 1.0) else self.engine.lincomb(terms)
         return out
 
@@ -272,7 +306,7 @@ class EditDeepFloydIF(object):
     def _operator(self, xt, t, mask, mode):
         weights = cfg_weights(mode, self.guidance_scale, self.guidance_scale_edit, self.guidance_scale > 1.0)
         return CFGJacobianOperator(self.branches, weights, xt.to(self.device, torch.float32).contiguous(), t,
-                                   self.scheduler.alpha_at(t), mask)
+                                   self.scheduler.alpha_at(t), mask, streams=self.branch_streams)
 
     # ------------------------------------------------------------------ solver (edit.py:1589-1676)
     def local_encoder_decoder_pullback_xt(self, xt, t, t_idx, for_prompt_emb, edit_prompt_emb, null_prompt_emb, op=None,

@@ -44,7 +44,7 @@ import torch
 from . import solver
 from .config import UNetConfig, synth_params
 from .hip import LocoEngine
-from .tloco import EditDeepFloydIF, IFScheduler, cfg_weights
+from .tloco import BranchStreams, EditDeepFloydIF, IFScheduler, cfg_weights
 from .utils import save_image as _save_image
 
 LATENT_SCALE = 0.18215          # edit.py:605, 748, 769
@@ -67,7 +67,8 @@ class SDScheduler(IFScheduler):
 class LatentCFGJacobianOperator:
     """J and J^T of the decoded x0_hat(z_t) under classifier-free guidance: per-prompt denoiser engines + decoder engine."""
 
-    def __init__(self, branches: Dict[str, LocoEngine], weights, decoder: LocoEngine, z, t, at, z0_scaled, mask):
+    def __init__(self, branches: Dict[str, LocoEngine], weights, decoder: LocoEngine, z, t, at, z0_scaled, mask, streams=None):
+        self.streams = streams or BranchStreams(1, "cpu")
         self.w = [(branches[name], w) for name, w in weights if w != 0.0]
         self.lead = self.w[0][0]
         self.dec = decoder
@@ -77,8 +78,8 @@ class LatentCFGJacobianOperator:
         a32 = np.float32(at)
         self.s = float(np.float32(1.0) / (np.float32(LATENT_SCALE) * np.sqrt(a32)))
         self.sigma = float(np.sqrt(np.float32(1.0) - a32))
-        for eng, _ in self.w:
-            eng.pmp_primal(z.contiguous(), float(t), at, None, use_et=True)       # dEps products in latent space
+        zc = z.contiguous()
+        self.streams.run([(lambda e=eng: e.pmp_primal(zc, float(t), at, None, use_et=True)) for eng, _ in self.w])   # dEps products in latent space
         decoder.pmp_primal(z0_scaled.contiguous(), 0.0, 1.0, mask, use_et=True)   # raw decoder Jacobian, mask on the image
 
     def check_mask(self):
@@ -86,12 +87,14 @@ class LatentCFGJacobianOperator:
             raise ValueError("empty mask: J = d x0_hat[mask] / d z_t has no rows")
 
     def jvp(self, V):              # [k, n_z] -> dense masked [k, n_image]
-        terms = [(self.s, V)] + [(-self.s * self.sigma * w, eng.pmp_jvp(V)) for eng, w in self.w]
+        outs = self.streams.run([(lambda e=eng: e.pmp_jvp(V)) for eng, _ in self.w])
+        terms = [(self.s, V)] + [(-self.s * self.sigma * w, o) for (_, w), o in zip(self.w, outs)]
         return self.dec.pmp_jvp(self.lead.lincomb(terms))
 
     def vjp(self, U):              # dense [k, n_image] -> [k, n_z]
         g = self.dec.pmp_vjp(U)
-        terms = [(self.s, g)] + [(-self.s * self.sigma * w, eng.pmp_vjp(g)) for eng, w in self.w]
+        outs = self.streams.run([(lambda e=eng: e.pmp_vjp(g)) for eng, _ in self.w])
+        terms = [(self.s, g)] + [(-self.s * self.sigma * w, o) for (_, w), o in zip(self.w, outs)]
         return self.lead.lincomb(terms)
 
     def gather(self, U):
@@ -246,7 +249,8 @@ class EditStableDiffusion(EditDeepFloydIF):
         F, E, N = self.for_prompt_emb, self.edit_prompt_emb, self.null_prompt_emb
         noise_pred = self._classifer_free_guidance(zt, t, F, E, N, mode=mode, do_classifier_free_guidance=self.guidance_scale > 1.0)
         z0s = self._z0_scaled(zt, t, noise_pred)
-        return LatentCFGJacobianOperator(self.branches, weights, self.vae_engine, zt, t, self.scheduler.alpha_at(t), z0s, mask)
+        return LatentCFGJacobianOperator(self.branches, weights, self.vae_engine, zt, t, self.scheduler.alpha_at(t), z0s, mask,
+                                         streams=self.branch_streams)
 
     # ------------------------------------------------------------------ solver (edit.py:830-915)
     def local_encoder_decoder_pullback_zt(self, zt, t, t_idx, for_prompt_emb, edit_prompt_emb, null_prompt_emb, op=None,
