@@ -194,10 +194,15 @@ class LocoEngine:
         if x.dim() != 4 or tuple(x.shape[1:]) != want:
             raise ValueError(f"input must be [B, {want[0]}, {want[1]}, {want[2]}], got {tuple(x.shape)}")
 
-    def unet_forward(self, x: torch.Tensor, t: float) -> torch.Tensor:
+    def unet_forward(self, x: torch.Tensor, t: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         _chk_dev(x)
         self._chk_input(x)
-        if self.cfg.arch in ("dec", "enc"):      # decoder / encoder: [B, C_in, R, R] -> [B, out_ch, R_out, R_out]
+        if out is not None:
+            _chk_dev(out)
+            if out.numel() != x.shape[0] * self.n_out:
+                raise ValueError(f"out must hold {x.shape[0]} x {self.n_out} elements, got {tuple(out.shape)}")
+            eps = out
+        elif self.cfg.arch in ("dec", "enc"):      # decoder / encoder: [B, C_in, R, R] -> [B, out_ch, R_out, R_out]
             eps = torch.empty(x.shape[0], self.cfg.out_ch, self.cfg.out_resolution, self.cfg.out_resolution,
                               device=x.device, dtype=torch.float32)
         else:
@@ -250,17 +255,27 @@ class LocoEngine:
         self._mask2_keepalive = m8                   # the copy is enqueued on the stream: keep the source alive, no host sync
         self._check(self.lib.loco_pmp_set_second_mask(self._ctx, _ptr(m8), int(from_row), _stream()), "loco_pmp_set_second_mask")
 
-    def pmp_jvp(self, V: torch.Tensor) -> torch.Tensor:
+    def pmp_jvp(self, V: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``out``: a [k, n_out] tensor to write into (callers that launch on a side stream allocate it on their own
+        stream first, so no allocation happens under the side stream)."""
         _chk_dev(V)
         k = V.shape[0]
-        U = torch.empty(k, self.n_out, device=V.device, dtype=torch.float32)
+        U = torch.empty(k, self.n_out, device=V.device, dtype=torch.float32) if out is None else out
+        if out is not None:
+            _chk_dev(out)
+            if tuple(out.shape) != (k, self.n_out):
+                raise ValueError(f"out must be {(k, self.n_out)}, got {tuple(out.shape)}")
         self._check(self.lib.loco_pmp_jvp(self._ctx, _ptr(V), k, _ptr(U), _stream()), "loco_pmp_jvp")
         return U
 
-    def pmp_vjp(self, U: torch.Tensor) -> torch.Tensor:
+    def pmp_vjp(self, U: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         _chk_dev(U)
         k = U.shape[0]
-        A = torch.empty(k, self.n, device=U.device, dtype=torch.float32)
+        A = torch.empty(k, self.n, device=U.device, dtype=torch.float32) if out is None else out
+        if out is not None:
+            _chk_dev(out)
+            if tuple(out.shape) != (k, self.n):
+                raise ValueError(f"out must be {(k, self.n)}, got {tuple(out.shape)}")
         self._check(self.lib.loco_pmp_vjp(self._ctx, _ptr(U), k, _ptr(A), _stream()), "loco_pmp_vjp")
         return A
 

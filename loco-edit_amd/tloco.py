@@ -116,11 +116,51 @@ class BranchStreams:
     run side by side on separate HIP streams and join before the combination.  At 64x64 a 5-probe pass leaves most launches
     below one workgroup per CU, so two or three branches fill the chip where one does not (the reference batches the
     prompts through one U-Net call, edit.py:1319-1322; here each prompt owns a context with its own cached primal).
-    ``LOCO_CFG_STREAMS=0``: one branch after the other on the current stream."""
+    ``LOCO_CFG_STREAMS=0``: one branch after the other on the current stream.
+    The callables must not allocate device memory: outputs are allocated by the caller on its own stream and passed in
+    (``out=``) -- an allocation under a side stream belongs to that stream's pool, and when the pool has to grow (hipMalloc
+    synchronises the device) the overlap is lost: measured 474 vs 334 ms per config-5 solve inside a process whose memory
+    was mostly taken."""
 
     def __init__(self, n: int, device):
         self.enabled = os.environ.get("LOCO_CFG_STREAMS", "1") != "0" and torch.device(device).type == "cuda" and n > 1
-        self.side = [torch.cuda.Stream(device=device) for _ in range(n - 1)] if self.enabled else []
+        self.side = self._pick(n - 1, device) if self.enabled else []
+        if self.enabled and len(self.side) < n - 1:
+            self.enabled = False          # no stream found that runs beside the current one: stay serial
+
+    @staticmethod
+    def _pick(count: int, device, candidates: int = 12):
+        """HIP streams share a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), handed out round-robin at creation:
+        a side stream that lands on the queue of the current stream (or of another side stream) runs strictly after it
+        and the overlap is lost without a trace -- whether that happens depends on how many streams the process created
+        before (measured: the same config-5 solve 326 ms in a fresh process, 468 ms after an unrelated engine had run).
+        So the streams are chosen by measurement: two spin kernels, one per stream; streams that finish them in the time of
+        one are on different queues."""
+        if not hasattr(torch.cuda, "_sleep"):
+            return [torch.cuda.Stream(device=device) for _ in range(count)]
+        import time
+        main = torch.cuda.current_stream(device)
+        cyc = 1_500_000
+
+        def spin(streams):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for s_ in streams:
+                with torch.cuda.stream(s_):
+                    torch.cuda._sleep(cyc)
+            torch.cuda.synchronize(device)
+            return time.perf_counter() - t0
+        spin([main])
+        one = min(spin([main]) for _ in range(3))
+        chosen = []
+        for _ in range(candidates):
+            if len(chosen) == count:
+                break
+            c = torch.cuda.Stream(device=device)
+            spin([main, c])
+            if all(min(spin([o, c]) for _ in range(2)) < 1.5 * one for o in [main] + chosen):
+                chosen.append(c)
+        return chosen
 
     def run(self, fns):
         if not self.enabled or len(fns) < 2:
@@ -134,8 +174,6 @@ class BranchStreams:
         outs[0] = fns[0]()
         for i in range(len(fns) - 1):
             main.wait_stream(self.side[i])
-            if isinstance(outs[i + 1], torch.Tensor):
-                outs[i + 1].record_stream(main)            # allocated under the side stream, consumed on this one
         return outs
 
 
@@ -152,21 +190,27 @@ class CFGJacobianOperator:
         self.ce = -float(np.sqrt(np.float32(1.0) - np.float32(at))) / float(np.sqrt(np.float32(at)))
         self.streams = streams or BranchStreams(1, "cpu")
         xc = x.contiguous()
+        m8 = None if mask is None else mask.to(device=xc.device, dtype=torch.uint8).contiguous()   # converted on this stream
         # dEps products; x0 algebra applied here
-        self.streams.run([(lambda e=eng: e.pmp_primal(xc, float(t), at, mask, use_et=True)) for eng, _ in self.w])
+        self.streams.run([(lambda e=eng: e.pmp_primal(xc, float(t), at, m8, use_et=True)) for eng, _ in self.w])
 
     def check_mask(self):
         if self.masked and self.lead.mask_count() == 0:
             raise ValueError("empty mask: J = d x0_hat[mask] / d x_t has no rows")
 
+    def _outs(self, rows, width):
+        return [torch.empty(rows, width, device=self.lead.device, dtype=torch.float32) for _ in self.w]
+
     def jvp(self, V):
-        outs = self.streams.run([(lambda e=eng: e.pmp_jvp(V)) for eng, _ in self.w])
+        bufs = self._outs(V.shape[0], self.n_out)
+        outs = self.streams.run([(lambda e=eng, o=o: e.pmp_jvp(V, out=o)) for (eng, _), o in zip(self.w, bufs)])
         terms = [(w, o) for (_, w), o in zip(self.w, outs)]
         dE = terms[0][1] if (len(terms) == 1 and terms[0][0] == 1.0) else self.lead.lincomb(terms)
         return self.lead.masked_axpby(V, dE, self.cv, self.ce)
 
     def vjp(self, U):
-        outs = self.streams.run([(lambda e=eng: e.pmp_vjp(U)) for eng, _ in self.w])
+        bufs = self._outs(U.shape[0], self.n)
+        outs = self.streams.run([(lambda e=eng, o=o: e.pmp_vjp(U, out=o)) for (eng, _), o in zip(self.w, bufs)])
         terms = [(self.ce * w, o) for (_, w), o in zip(self.w, outs)]
         terms.append((1.0, self.lead.masked_axpby(U, U, self.cv, 0.0)))
         return self.lead.lincomb(terms)
@@ -283,7 +327,9 @@ class EditDeepFloydIF(object):
         out = torch.empty_like(x)
         for b0 in range(0, x.shape[0], mb):
             xs = x[b0:b0 + mb].contiguous()
-            outs = self.branch_streams.run([(lambda n=name: self.branches[n].unet_forward(xs, float(t))) for name, _ in weights])
+            bufs = [torch.empty_like(xs) for _ in weights]          # allocated here: nothing is allocated under a side stream
+            outs = self.branch_streams.run([(lambda n=name, o=o: self.branches[n].unet_forward(xs, float(t), out=o))
+                                            for (name, _), o in zip(weights, bufs)])
             terms = [(w, o) for (_, w), o in zip(weights, outs)]
             out[b0:b0 + mb] = terms[0][1] if (len(terms) == 1 and terms[0][0] == 1.0) else self.engine.lincomb(terms)
         return out

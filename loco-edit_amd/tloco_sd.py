@@ -87,13 +87,15 @@ class LatentCFGJacobianOperator:
             raise ValueError("empty mask: J = d x0_hat[mask] / d z_t has no rows")
 
     def jvp(self, V):              # [k, n_z] -> dense masked [k, n_image]
-        outs = self.streams.run([(lambda e=eng: e.pmp_jvp(V)) for eng, _ in self.w])
+        bufs = [torch.empty(V.shape[0], self.lead.n_out, device=V.device, dtype=torch.float32) for _ in self.w]
+        outs = self.streams.run([(lambda e=eng, o=o: e.pmp_jvp(V, out=o)) for (eng, _), o in zip(self.w, bufs)])
         terms = [(self.s, V)] + [(-self.s * self.sigma * w, o) for (_, w), o in zip(self.w, outs)]
         return self.dec.pmp_jvp(self.lead.lincomb(terms))
 
     def vjp(self, U):              # dense [k, n_image] -> [k, n_z]
         g = self.dec.pmp_vjp(U)
-        outs = self.streams.run([(lambda e=eng: e.pmp_vjp(g)) for eng, _ in self.w])
+        bufs = [torch.empty(g.shape[0], self.n, device=g.device, dtype=torch.float32) for _ in self.w]
+        outs = self.streams.run([(lambda e=eng, o=o: e.pmp_vjp(g, out=o)) for (eng, _), o in zip(self.w, bufs)])
         terms = [(self.s, g)] + [(-self.s * self.sigma * w, o) for (_, w), o in zip(self.w, outs)]
         return self.lead.lincomb(terms)
 

@@ -319,3 +319,34 @@ def test_config5_full_width_operator_and_solver_at_size(preset, tmp_path):
     assert bool((s[:-1] >= s[1:] * (1 - 1e-5)).all()) and bool(torch.isfinite(vT).all())
     op = ed._operator(x, t, mask, mode)
     assert torch.allclose(op.jvp(vT.contiguous()).norm(dim=1).cpu(), s.cpu(), rtol=2e-2)
+
+
+def test_cfg_branches_side_by_side_equal_the_serial_order(golden, tmp_path):
+    """The CFG branches on their own HIP streams (tloco.BranchStreams, the default) against one branch after the other:
+    guided noise on a batch, J V and J^T U of the three-branch operator and a 4-iteration solve -- bit-identical (the branches
+    are separate engine contexts; only the order of independent launches changes)."""
+    g = golden("tloco_tiny")
+    ed = _edit(g, tmp_path, "bf16x3")
+    assert ed.branch_streams.enabled and len(ed.branch_streams.side) == 2
+    x, t = g["x"].to(DEV), g["t"]
+    F, E, N = g["for_e"], g["edit_e"], g["null_e"]
+    mode = "null+(for-null)+(edit-null)"
+    gen = torch.Generator().manual_seed(9)
+    mask = g["mask"].to(DEV)
+    V = torch.randn(4, ed.engine.n, generator=gen).to(DEV)
+    U = torch.randn(4, ed.engine.n, generator=gen).to(DEV)
+    xb = torch.cat([x, 0.5 * x.flip(-1), x + 0.1])
+
+    def everything():
+        e = ed._classifer_free_guidance(xb, t, F, E, N, mode, True)
+        op = ed._operator(x, t, mask, mode)
+        jv, jtu = op.jvp(V), op.vjp(U)
+        u, s, vT = ed.local_encoder_decoder_pullback_xt(x, t, ed.edit_t_idx, F, E, N, pca_rank=3, min_iter=4, max_iter=4, mask=mask,
+                                                        mode=mode, v0=g["v0"].to(DEV), verbose=False)
+        torch.cuda.synchronize()
+        return [z.clone() for z in (e, jv, jtu, u, s, vT)]
+    side = everything()
+    ed.branch_streams.enabled = False
+    serial = everything()
+    for a, b in zip(side, serial):
+        assert torch.equal(a, b)

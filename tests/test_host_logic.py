@@ -413,3 +413,13 @@ def test_max_batch_follows_the_probe_counts(monkeypatch):
     monkeypatch.delenv("LOCO_PAIR_SOLVES")
     assert pa(["--model_name", "runwayml/stable-diffusion-v1-5", "--pca_rank", "50"]).max_batch == 8
     assert pa(["--max_batch", "4", "--pca_rank", "50"]).max_batch == 4
+
+
+def test_branch_streams_on_cpu_run_in_order():
+    """Without a GPU the CFG branches run one after the other on the caller's thread, results in branch order."""
+    from loco_edit_amd.tloco import BranchStreams
+    bs = BranchStreams(3, "cpu")
+    assert not bs.enabled and bs.side == []
+    order = []
+    out = bs.run([lambda i=i: (order.append(i), i * i)[1] for i in range(3)])
+    assert out == [0, 1, 4] and order == [0, 1, 2]
