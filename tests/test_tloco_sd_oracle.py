@@ -77,6 +77,13 @@ def test_preset_routes_stable_diffusion_to_the_latent_path(tmp_path, monkeypatch
     c = define_argparser.parse_args(["--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Random", "--note", "n",
                                      "--seed", "3", "--device", "cpu", "--unet_preset", "sd64_xattn_standin"])
     assert define_argparser.preset(c).unet_config is SD64_XATTN_STANDIN            # the round-2 stand-in stays selectable
+    # an image dataset (latent inversion, edit.py:568-633): read at the autoencoder's resolution, encoder preset attached
+    d = define_argparser.parse_args(["--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Synthetic", "--note", "n",
+                                     "--seed", "3", "--device", "cpu", "--run_ddim_inversion", "True"])
+    d = define_argparser.preset(d)
+    from loco_edit_amd.config import SD_VAE_ENCODER
+    assert d.vae_encoder_config is SD_VAE_ENCODER and tuple(d.dataset[0].shape) == (1, 3, 512, 512)
+    assert getattr(a, "dataset", None) is None and a.vae_encoder_config is SD_VAE_ENCODER      # 'Random': no images
     b = define_argparser.parse_args(["--model_name", "SimianLuo/LCM_Dreamshaper_v7", "--seed", "3", "--device", "cpu"])
     with pytest.raises(NotImplementedError):
         define_argparser.preset(b)
