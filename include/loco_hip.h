@@ -154,6 +154,13 @@ int  loco_qr_rows(loco_ctx* ctx, float* A, int32_t k, int64_t n, void* stream);
  * out[1] = 1.0 if allclose(Vp, V, atol, rtol=1e-5) else 0.0 (device floats). */
 int  loco_convergence(loco_ctx* ctx, const float* Vprev, const float* V, int64_t count,
                       float atol, float* out2, void* stream);
+/* The same test row by row and up to each row's sign: the reference compares LAPACK's singular vectors
+ * (edit.py:2482-2492), whose signs are LAPACK's choice and, for k >= 2, change from one iteration to the next
+ * (tests/golden/converge.pt records it); the rows computed here carry no sign of their own.  Vprev, V: [k, n];
+ * out[0] = sqrt(sum_rows min(||vp - v||^2, ||vp + v||^2)), out[1] = 1.0 if every row is allclose(atol, rtol=1e-5)
+ * to +-its predecessor. k <= 64. */
+int  loco_convergence_rows(loco_ctx* ctx, const float* Vprev, const float* V, int32_t k, int64_t n,
+                           float atol, float* out2, void* stream);
 
 /* Null-space projection + row normalisation (edit.py:2317-2323):
  * out = normalize_rows(Vm - (Vn^T (Vn Vm^T))^T); Vn==nullptr: normalise only. */

@@ -283,3 +283,163 @@ def encoder_to_hf_autoencoder_kl(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -
                     v = v.reshape(v.shape[0], v.shape[1])
                 out[f"encoder.mid_block.attentions.0.{inv_attn[p[2]]}.{suffix}"] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stable Diffusion denoiser checkpoints (the reference gets the network from
+# ``StableDiffusionPipeline.from_pretrained(...).unet``, utils.py:140-144 / edit.py:619-623).  The engine keeps the
+# latent-diffusion ``UNetModel`` names (config.adm_param_shapes).  Two on-disk layouts are recognised:
+#   * CompVis / Stability ``*.ckpt``: the whole pipeline in one state_dict -- the denoiser under
+#     ``model.diffusion_model.``, next to ``first_stage_model.*`` (autoencoder), ``cond_stage_model.*`` (text encoder)
+#     and the schedule buffers (``betas``, ``alphas_cumprod`` ...): keep the denoiser keys, strip the prefix;
+#   * diffusers ``UNet2DConditionModel`` (``unet/diffusion_pytorch_model.*``): renamed by the inverse of diffusers'
+#     ``convert_from_ckpt`` block map.  Written from the published naming; **parity unpinned** (no diffusers, no weights):
+#     what is tested is that the map is a bijection onto the engine's parameter list with the right shapes.
+# Stable Diffusion 2.x stores the transformer's proj_in / proj_out as ``nn.Linear`` [C, C] (``use_linear_in_transformer``);
+# on [C][T] activations that is the same operator as v1's 1x1 conv [C, C, 1, 1], so the weights are reshaped.
+_COMPVIS_PREFIX = "model.diffusion_model."
+_LDM_RES = {"norm1": "in_layers.0", "conv1": "in_layers.2", "time_emb_proj": "emb_layers.1", "norm2": "out_layers.0",
+            "conv2": "out_layers.3", "conv_shortcut": "skip_connection"}
+
+
+def is_compvis_sd(sd: Dict[str, torch.Tensor]) -> bool:
+    return any(k.startswith(_COMPVIS_PREFIX) for k in sd)
+
+
+def is_hf_unet2d_condition(sd: Dict[str, torch.Tensor]) -> bool:
+    return "time_embedding.linear_1.weight" in sd and any(".transformer_blocks." in k for k in sd) \
+        and any(k.startswith("down_blocks.") for k in sd)
+
+
+def compvis_sd_to_ldm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """``model.diffusion_model.*`` of an ``sd-v1-x.ckpt`` / ``v2-1_512-ema-pruned.ckpt`` state_dict -> denoiser keys."""
+    return {k[len(_COMPVIS_PREFIX):]: v for k, v in sd.items() if k.startswith(_COMPVIS_PREFIX)}
+
+
+def _ldm_block_index(cfg: UNetConfig):
+    """(level, block) -> input_blocks index / output_blocks index, and whether the level carries transformer blocks."""
+    nrb, nlev = cfg.num_res_blocks, len(cfg.ch_mult)
+    has_attn = [(cfg.resolution >> lvl) in cfg.attn_resolutions for lvl in range(nlev)]
+    return nrb, nlev, has_attn
+
+
+def hf_unet2d_condition_to_ldm(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """diffusers ``UNet2DConditionModel`` keys -> latent-diffusion ``UNetModel`` keys (the layout of
+    ``config.adm_param_shapes`` for the SpatialTransformer presets)."""
+    nrb, nlev, has_attn = _ldm_block_index(cfg)
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        p = k.split(".")
+        if p[0] == "time_embedding":
+            out[f"time_embed.{0 if p[1] == 'linear_1' else 2}.{p[-1]}"] = v
+        elif p[0] == "conv_in":
+            out[f"input_blocks.0.0.{p[-1]}"] = v
+        elif p[0] == "conv_norm_out":
+            out[f"out.0.{p[-1]}"] = v
+        elif p[0] == "conv_out":
+            out[f"out.2.{p[-1]}"] = v
+        elif p[0] == "down_blocks":
+            lvl = int(p[1])
+            if p[2] == "resnets":
+                out[f"input_blocks.{(nrb + 1) * lvl + int(p[3]) + 1}.0.{_LDM_RES[p[4]]}.{p[-1]}"] = v
+            elif p[2] == "attentions":
+                out[f"input_blocks.{(nrb + 1) * lvl + int(p[3]) + 1}.1." + ".".join(p[4:])] = v
+            elif p[2] == "downsamplers":
+                out[f"input_blocks.{(nrb + 1) * (lvl + 1)}.0.op.{p[-1]}"] = v
+            else:
+                raise KeyError(k)
+        elif p[0] == "mid_block":
+            if p[1] == "resnets":
+                out[f"middle_block.{0 if p[2] == '0' else 2}.{_LDM_RES[p[3]]}.{p[-1]}"] = v
+            elif p[1] == "attentions":
+                out["middle_block.1." + ".".join(p[3:])] = v
+            else:
+                raise KeyError(k)
+        elif p[0] == "up_blocks":
+            i = int(p[1])
+            lvl = nlev - 1 - i
+            if p[2] == "resnets":
+                out[f"output_blocks.{(nrb + 1) * i + int(p[3])}.0.{_LDM_RES[p[4]]}.{p[-1]}"] = v
+            elif p[2] == "attentions":
+                out[f"output_blocks.{(nrb + 1) * i + int(p[3])}.1." + ".".join(p[4:])] = v
+            elif p[2] == "upsamplers":
+                out[f"output_blocks.{(nrb + 1) * i + nrb}.{2 if has_attn[lvl] else 1}.conv.{p[-1]}"] = v
+            else:
+                raise KeyError(k)
+        else:
+            raise KeyError(f"not a UNet2DConditionModel key: {k}")
+    return out
+
+
+def ldm_to_hf_unet2d_condition(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """Inverse of ``hf_unet2d_condition_to_ldm`` (round-trip tests; exporting a synthetic checkpoint in diffusers naming)."""
+    nrb, nlev, has_attn = _ldm_block_index(cfg)
+    inv_res = {v: k for k, v in _LDM_RES.items()}
+    out: Dict[str, torch.Tensor] = {}
+
+    def res_name(rest):          # "in_layers.0.weight" -> "norm1.weight"
+        q = rest.split(".")
+        return inv_res[".".join(q[:-1])] + "." + q[-1]
+
+    for k, v in sd.items():
+        p = k.split(".")
+        if p[0] == "time_embed":
+            out[f"time_embedding.linear_{1 if p[1] == '0' else 2}.{p[-1]}"] = v
+        elif p[0] == "out":
+            out[f"{'conv_norm_out' if p[1] == '0' else 'conv_out'}.{p[-1]}"] = v
+        elif p[0] == "input_blocks":
+            ib = int(p[1])
+            if ib == 0:
+                out[f"conv_in.{p[-1]}"] = v
+                continue
+            lvl, j = divmod(ib - 1, nrb + 1)
+            if p[3] == "op":
+                out[f"down_blocks.{lvl}.downsamplers.0.conv.{p[-1]}"] = v
+            elif p[2] == "0":
+                out[f"down_blocks.{lvl}.resnets.{j}." + res_name(".".join(p[3:]))] = v
+            else:
+                out[f"down_blocks.{lvl}.attentions.{j}." + ".".join(p[3:])] = v
+        elif p[0] == "middle_block":
+            if p[1] == "1":
+                out["mid_block.attentions.0." + ".".join(p[2:])] = v
+            else:
+                out[f"mid_block.resnets.{0 if p[1] == '0' else 1}." + res_name(".".join(p[2:]))] = v
+        elif p[0] == "output_blocks":
+            i, j = divmod(int(p[1]), nrb + 1)
+            if p[3] == "conv":
+                out[f"up_blocks.{i}.upsamplers.0.conv.{p[-1]}"] = v
+            elif p[2] == "0":
+                out[f"up_blocks.{i}.resnets.{j}." + res_name(".".join(p[3:]))] = v
+            else:
+                out[f"up_blocks.{i}.attentions.{j}." + ".".join(p[3:])] = v
+        else:
+            raise KeyError(k)
+    return out
+
+
+def normalize_unet_state_dict(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """Whatever ``--ckpt_path`` held -> the engine's parameter names and shapes for ``cfg``.
+
+    Unwraps ``{"state_dict": ...}``, recognises the CompVis pipeline layout and the diffusers ``UNet2DConditionModel``
+    layout (above) and the diffusers ``UNet2DModel`` layout of the unconditional models, reshapes ``nn.Linear``
+    proj_in / proj_out weights of Stable Diffusion 2.x to the 1x1-conv shape, and refuses what is left over with the
+    list of foreign keys instead of failing on the first one inside ``loco_load_param``."""
+    sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+    if is_compvis_sd(sd):
+        sd = compvis_sd_to_ldm(sd)
+    elif is_hf_unet2d_condition(sd):
+        sd = hf_unet2d_condition_to_ldm(sd, cfg)
+    elif is_hf_unet2d(sd) and cfg.arch == "ddpm":
+        sd = hf_unet2d_to_vendored(sd, cfg)
+    want = param_shapes(cfg)
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        if k in want and len(want[k]) == 4 and getattr(v, "ndim", 0) == 2 and tuple(v.shape) == tuple(want[k][:2]) \
+                and tuple(want[k][2:]) == (1, 1):
+            v = v[:, :, None, None]
+        out[k] = v
+    foreign = [k for k in out if k not in want and not k.startswith("cond_proj.")]
+    if foreign:
+        raise ValueError(f"{len(foreign)} checkpoint keys are not parameters of this architecture "
+                         f"(first: {foreign[:3]}); expected e.g. {list(want)[:2]}")
+    return out

@@ -134,6 +134,14 @@ FLASH_ADM = UNetConfig(resolution=32, ch=64, ch_mult=(1, 2), num_res_blocks=1, a
 SD15_UNET = UNetConfig(resolution=64, in_channels=4, out_ch=4, ch=320, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
                        attn_resolutions=(64, 32, 16), gn_eps=1e-5, arch="adm", learn_sigma=False, context_dim=768,
                        context_len=77, scale_shift_norm=False, resblock_updown=False, num_heads=8, transformer_depth=1)
+# Stable Diffusion 2.1-base (the id the shipped T-LOCO scripts name: scripts/main_T2I_StableDiffusion_null_space_projection*.sh:4,
+# "stabilityai/stable-diffusion-2-1-base"): the same skeleton with 1024-wide OpenCLIP states, heads of 64 channels at
+# every level (5 / 10 / 20 / 20 heads) and nn.Linear proj_in / proj_out (the 1x1 operator on [C][T]; checkpoints.py
+# reshapes those weights); 865 910 724 parameters
+SD21_BASE_UNET = UNetConfig(resolution=64, in_channels=4, out_ch=4, ch=320, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
+                            attn_resolutions=(64, 32, 16), gn_eps=1e-5, arch="adm", learn_sigma=False, context_dim=1024,
+                            context_len=77, scale_shift_norm=False, resblock_updown=False, num_head_channels=64,
+                            transformer_depth=1)
 TINY_LDM = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=32, ch_mult=(1, 2), num_res_blocks=1,
                       attn_resolutions=(16, 8), gn_eps=1e-5, arch="adm", learn_sigma=False, context_dim=16, context_len=7,
                       scale_shift_norm=False, resblock_updown=False, num_heads=4, transformer_depth=1)

@@ -312,12 +312,11 @@ static void attn_flash_launch_n(int mode, const AttnFlashArgs& a, hipStream_t st
     auto k0 = &attn_flash_kernel<M_TAN, NCK>;
     auto k1 = &attn_flash_kernel<M_COTQ, NCK>;
     auto k2 = &attn_flash_kernel<M_COTK, NCK>;
-    static bool done = false;
-    if (!done) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        done = true;
     }
     if (mode == M_TAN) hipLaunchKernelGGL(k0, grid, dim3(256), ldsb, st, a);
     else if (mode == M_COTQ) hipLaunchKernelGGL(k1, grid, dim3(256), ldsb, st, a);

@@ -1045,11 +1045,10 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     auto kern = PR == PR_F16 ? &conv_mfma_f16<TAPS, WM, WN, TM, TN, MODE, STG>
                              : &conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;
     if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
+        static DeviceOnce once;
+        if (first_on_device(once)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024);
-            done = true;
         }
     }
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, a);

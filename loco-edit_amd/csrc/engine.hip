@@ -132,7 +132,8 @@ struct loco_ctx {
     bool fuse_xattn = true;        // LOCO_FUSE_XATTN=0: cross-attention as strided GEMM + row kernel + strided GEMM (A/B)
     bool deep1 = true;             // LOCO_DEEP1=0: 1x1 operators on the two-buffer stage loop instead of the register ring (A/B)
     bool flash_attn = true;        // LOCO_FLASH_ATTN=0: tangent / cotangent attention on the generic GEMM + softmax-Jacobian path
-    float* attn_delta = nullptr;   // [max_batch][heads][tokens] scratch of the flash cotangent
+    float* attn_delta = nullptr;   // [max_batch][heads][tokens] scratch of the flash cotangent (a lane's samples start at its first sample: LaneSwap)
+    long attn_dmax = 0;            // heads * tokens of the largest attention = the per-sample pitch of attn_delta
     float* partial = nullptr;      // split-K workspace
     size_t partial_floats = 0;
     float *tact = nullptr, *tproj = nullptr, *freq = nullptr;
@@ -1662,7 +1663,8 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 const int C = to.C, T = HW, NH = op.heads, H = to.H, W = to.W;
                 const long PSb = p.bs();
                 auto X = [&](int i) { return p.T(op.xt[i]); };
-                gn_forward_stats(p, op.n1, p.T(op.in), PSb, HW);
+                if (!op.n1.ready) gn_forward_stats(p, op.n1, p.T(op.in), PSb, HW);
+                op.n1.ready = false;
                 NS s = nstats(c, stats, op.n1);
                 {   // h0 = proj_in(GN(x))
                     ConvArgs a; conv_defaults(a);
@@ -1910,7 +1912,8 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 const int C = to.C, T = HW, NH = op.heads, H = to.H, W = to.W;
                 auto XP = [&](int i) { return TP(op.xt[i]); };
                 auto XT_ = [&](int i) { return TT(op.xt[i]); };
-                tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
+                if (!op.n1.ready) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HW, B, st);
+                op.n1.ready = false;
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 launch_gn_apply(1, TT(op.in), PS, TP(op.in), 0, nullptr, 0, XT_(X_G0), PS, 0, B, C, HW,
@@ -2237,9 +2240,11 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
 // arena and its own reduction / split-K scratch; the host enqueues lane 0 completely, then lane 1.
 namespace {
 struct LaneSwap {
-    loco_ctx* c; float *arenaT, *statsT, *partial, *eps_buf, *ge, *gx0, *stpart; double* red; size_t partial_floats;
+    loco_ctx* c; float *arenaT, *statsT, *partial, *eps_buf, *ge, *gx0, *stpart, *attn_delta; double* red; size_t partial_floats;
     LaneSwap(loco_ctx* c_, int s0) : c(c_) {
         arenaT = c->arenaT; statsT = c->statsT; partial = c->partial; eps_buf = c->eps_buf; ge = c->ge; gx0 = c->gx0;
+        // the flash cotangent indexes its delta scratch by the lane-local sample: lane 1 gets the slots of ITS samples
+        attn_delta = c->attn_delta; c->attn_delta += (long)s0 * c->attn_dmax;
         red = c->red; partial_floats = c->partial_floats; stpart = c->stpart; c->stpart = c->stpart2;
         c->arenaT += (long)s0 * c->per_sample; c->statsT += (long)s0 * c->stats_per_sample;
         c->eps_buf += (long)s0 * c->n_out; c->ge += (long)s0 * c->n_out; c->gx0 += (long)s0 * c->n_in;
@@ -2248,7 +2253,7 @@ struct LaneSwap {
     }
     ~LaneSwap() {
         c->arenaT = arenaT; c->statsT = statsT; c->partial = partial; c->eps_buf = eps_buf; c->ge = ge; c->gx0 = gx0;
-        c->red = red; c->partial_floats = partial_floats; c->stpart = stpart;
+        c->red = red; c->partial_floats = partial_floats; c->stpart = stpart; c->attn_delta = attn_delta;
     }
 };
 template <typename F>
@@ -2313,7 +2318,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
     // which norm takes its statistics over exactly which tensor: the conv that finishes that tensor delivers them
     for (size_t i = 0; i < c->ops.size(); ++i) {
         const Op& op = c->ops[i];
-        if ((op.kind == OP_RES || op.kind == OP_ATTN || op.kind == OP_OUT) && op.in >= 0) {
+        if ((op.kind == OP_RES || op.kind == OP_ATTN || op.kind == OP_OUT || op.kind == OP_XFMR) && op.in >= 0) {
             c->tens[op.in].cons_op = (int)i; c->tens[op.in].cons_norm = 1;
         }
         if (op.kind == OP_ATTN && op.has_x) { c->tens[op.xmid].cons_op = (int)i; c->tens[op.xmid].cons_norm = 2; }
@@ -2343,6 +2348,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         long dmax = 1;
         for (const Op& op : c->ops)
             if (op.kind == OP_ATTN || op.kind == OP_XFMR) dmax = std::max(dmax, (long)op.heads * c->tens[op.in].H * c->tens[op.in].W);
+        c->attn_dmax = dmax;
         if (dalloc(c, &c->attn_delta, MB * (size_t)dmax)) return -1;
     }
     c->partial_floats = (size_t)64 << 20;   // 256 MB split-K workspace
@@ -2650,6 +2656,15 @@ int loco_convergence(loco_ctx* c, const float* Vprev, const float* V, int64_t co
                      void* stream) {
     if (!c) return -2;
     launch_convergence(Vprev, V, count, atol, 1e-5f, out2, c->gscratch, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int loco_convergence_rows(loco_ctx* c, const float* Vprev, const float* V, int32_t k, int64_t n, float atol,
+                          float* out2, void* stream) {
+    if (!c) return -2;
+    if (k < 1 || k > 64 || n < 1) { c->err = "convergence_rows: need 1 <= k <= 64"; return -2; }
+    launch_convergence_rows(Vprev, V, k, n, atol, 1e-5f, out2, c->gscratch, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

@@ -8,6 +8,19 @@
 
 namespace loco {
 
+// One-time per-DEVICE setup guard for launchers (kernel attributes such as the dynamic-LDS limit belong to the device's
+// copy of the code object): true the first time it is called with `flags` on the current device.
+struct DeviceOnce { bool seen[64] = {}; };
+inline bool first_on_device(DeviceOnce& f) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    if (f.seen[d]) return false;
+    f.seen[d] = true;
+    return true;
+}
+
+
 enum ConvMode : int {
     CM_NONE = 0,      // raw input
     CM_GN_SILU = 1,   // a = silu(sc*x + sh)                         (forward, ResnetBlock norm->swish->conv)
@@ -246,6 +259,9 @@ void launch_cholesky(double* G, int k, hipStream_t st);
 void launch_trsm_rows(const float* Ain, float* Aout, int k, long n, const double* L, hipStream_t st);
 void launch_convergence(const float* a, const float* b, long count, float atol, float rtol, float* out2,
                         double* scratch, hipStream_t st);
+// the same per row and up to each row's sign; scratch: k * 64 * 4 doubles
+void launch_convergence_rows(const float* a, const float* b, int k, long n, float atol, float rtol, float* out2,
+                             double* scratch, hipStream_t st);
 // out = Vm - C^T Vn  (C: [k0][k] double = Vn Vm^T), then row-normalise
 void launch_project_rows(const float* Vm, int k, const float* Vn, int k0, long n, const double* C,
                          float* out, hipStream_t st);

@@ -361,6 +361,63 @@ void launch_convergence(const float* a, const float* b, long count, float atol, 
     hipLaunchKernelGGL(conv_final_kernel, dim3(1), dim3(64), 0, st, scratch, blocks, out2);
 }
 
+// The same test per ROW and up to the row's sign (edit.py:2489-2492 compares LAPACK's singular vectors, whose signs are
+// LAPACK's choice; the eigenvectors here carry no sign of their own): for every row both orientations are accumulated
+// in one pass -- ||a - b||^2, ||a + b||^2 and the allclose verdict of each -- and the final kernel keeps, per row, the
+// orientation with the smaller distance.  out2[0] = sqrt(sum_rows min(||a-b||^2, ||a+b||^2)), out2[1] = 1 when every
+// row is allclose in its orientation.  grid (segments, k); part: [k][nseg][4] doubles.
+__global__ __launch_bounds__(256) void conv_rows_partial_kernel(const float* a, const float* b, long n, float atol,
+                                                                float rtol, double* part) {
+    __shared__ double sp[4], sm_[4];
+    __shared__ int bp[4], bm[4];
+    const long r0 = (long)blockIdx.y * n;
+    double ssp = 0.0, ssm = 0.0;
+    int nbp = 0, nbm = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = a[r0 + i], y = b[r0 + i];
+        const float dp = x - y, dm = x + y;
+        ssp += (double)dp * (double)dp;
+        ssm += (double)dm * (double)dm;
+        const float tol = atol + rtol * fabsf(y);
+        if (!(fabsf(dp) <= tol)) nbp = 1;
+        if (!(fabsf(dm) <= tol)) nbm = 1;
+    }
+    ssp = wsum(ssp); ssm = wsum(ssm);
+    nbp = __any(nbp) ? 1 : 0; nbm = __any(nbm) ? 1 : 0;
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sp[w] = ssp; sm_[w] = ssm; bp[w] = nbp; bm[w] = nbm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        o[0] = sp[0] + sp[1] + sp[2] + sp[3];
+        o[1] = sm_[0] + sm_[1] + sm_[2] + sm_[3];
+        o[2] = (double)(bp[0] | bp[1] | bp[2] | bp[3]);
+        o[3] = (double)(bm[0] | bm[1] | bm[2] | bm[3]);
+    }
+}
+__global__ void conv_rows_final_kernel(const double* part, int nseg, int k, float* out2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double ss = 0.0;
+        int bad = 0;
+        for (int r = 0; r < k; ++r) {
+            double p = 0.0, m = 0.0, badp = 0.0, badm = 0.0;
+            for (int i = 0; i < nseg; ++i) {
+                const double* o = part + ((long)r * nseg + i) * 4;
+                p += o[0]; m += o[1]; badp += o[2]; badm += o[3];
+            }
+            if (m < p) { ss += m; bad |= badm > 0; } else { ss += p; bad |= badp > 0; }
+        }
+        out2[0] = (float)sqrt(ss);
+        out2[1] = bad ? 0.f : 1.f;
+    }
+}
+void launch_convergence_rows(const float* a, const float* b, int k, long n, float atol, float rtol, float* out2,
+                             double* scratch, hipStream_t st) {
+    int nseg = (int)((n + 255) / 256);
+    if (nseg > 64) nseg = 64;
+    hipLaunchKernelGGL(conv_rows_partial_kernel, dim3(nseg, k), dim3(256), 0, st, a, b, n, atol, rtol, scratch);
+    hipLaunchKernelGGL(conv_rows_final_kernel, dim3(1), dim3(64), 0, st, scratch, nseg, k, out2);
+}
+
 // out[i][c] = Vm[i][c] - sum_j C[j][i] * Vn[j][c]        (C = Vn Vm^T, [k0][k])
 __global__ __launch_bounds__(256) void project_rows_kernel(const float* Vm, int k, const float* Vn, int k0, long n,
                                                            const double* C, float* out) {

@@ -122,11 +122,10 @@ void xattn_launch(const XAttnArgs& a, hipStream_t st) {
     auto kf = &xattn_fused_kernel<LG, true>;
     auto kl = &xattn_fused_kernel<LG, false>;
     if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
+        static DeviceOnce once;
+        if (first_on_device(once)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
         }
     }
     if (a.fwd) hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, a);

@@ -77,7 +77,7 @@ _FLAGS = [
 _UNET_PRESETS = {'celeba_ddpm': 'CELEBA_DDPM', 'ffhq_p2': 'FFHQ_P2', 'tiny_ddpm': 'TINY_DDPM', 'mid_ddpm': 'MID_DDPM',
                  'tiny_adm': 'TINY_ADM', 'if64_standin': 'IF64_STANDIN', 'sd64_standin': 'SD64_STANDIN',
                  'sd64_xattn_standin': 'SD64_XATTN_STANDIN', 'tiny_latent': 'TINY_LATENT', 'tiny_latent_xattn': 'TINY_LATENT_XATTN',
-                 'if64_xattn_standin': 'IF64_XATTN_STANDIN', 'tiny_adm_xattn': 'TINY_ADM_XATTN', 'sd15_unet': 'SD15_UNET',
+                 'if64_xattn_standin': 'IF64_XATTN_STANDIN', 'tiny_adm_xattn': 'TINY_ADM_XATTN', 'sd15_unet': 'SD15_UNET', 'sd21_base_unet': 'SD21_BASE_UNET',
                  'tiny_ldm': 'TINY_LDM'}
 _VAE_PRESETS = {'sd_vae_decoder': 'SD_VAE_DECODER', 'tiny_decoder': 'TINY_DECODER'}
 _TILDA_V = ["proj_null[for-null](edit-null)-direct", "(for-edit)-direct", "(edit-null)-direct",
@@ -211,7 +211,9 @@ def _preset_t2i(args, family):
         if getattr(args, 'unet_config', None) is None:
             # the Stable Diffusion v1.x denoiser (latent-diffusion UNetModel with SpatialTransformer blocks, 859.5 M
             # parameters; BASELINE config 4).  `--unet_preset sd64_xattn_standin` selects the round-2 stand-in
-            args.unet_config = config.SD15_UNET
+            # model names of the 2.x family (the shipped scripts: stabilityai/stable-diffusion-2-1-base) get that family's
+            # widths: 1024-wide prompt states, 64-channel heads, nn.Linear proj_in / proj_out (config.SD21_BASE_UNET)
+            args.unet_config = config.SD21_BASE_UNET if 'stable-diffusion-2' in args.model_name else config.SD15_UNET
         if getattr(args, 'vae_config', None) is None:
             args.vae_config = config.SD_VAE_DECODER
         if getattr(args, 'vae_encoder_config', None) is None:      # vae.encode of run_DDIMinversion (engine created on use)

@@ -27,7 +27,7 @@ SYMBOLS = [
     "loco_version", "loco_device_count", "loco_create", "loco_destroy", "loco_last_error",
     "loco_load_param", "loco_params_missing", "loco_unet_forward", "loco_ddim_step", "loco_sched_step",
     "loco_pmp_primal", "loco_pmp_set_second_mask", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
-    "loco_convergence", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
+    "loco_convergence", "loco_convergence_rows", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision", "loco_set_streams",
     "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby", "loco_latent_sample",
@@ -81,6 +81,7 @@ def load_library():
     lib.loco_orthonormalize.argtypes = [vp, vp, i32, i64, vp, vp]
     lib.loco_qr_rows.argtypes = [vp, vp, i32, i64, vp]
     lib.loco_convergence.argtypes = [vp, vp, vp, i64, f32, vp, vp]
+    lib.loco_convergence_rows.argtypes = [vp, vp, vp, i32, i64, f32, vp, vp]
     lib.loco_null_project.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp]
     lib.loco_edit_axpy.argtypes = [vp, vp, vp, C.POINTER(f32), i32, i64, vp, vp]
     lib.loco_mask_gather.argtypes = [vp, vp, i32, vp, vp]
@@ -299,6 +300,16 @@ class LocoEngine:
         out = torch.empty(2, device=V.device, dtype=torch.float32)
         self._check(self.lib.loco_convergence(self._ctx, _ptr(Vprev), _ptr(V), V.numel(), float(atol), _ptr(out),
                                               _stream()), "loco_convergence")
+        return out
+
+    def convergence_rows(self, Vprev, V, atol) -> torch.Tensor:
+        """[distance, allclose flag] of the rows of V against +-the rows of Vprev (loco_convergence_rows)."""
+        _chk_dev(Vprev)
+        _chk_dev(V)
+        k, n = V.shape
+        out = torch.empty(2, device=V.device, dtype=torch.float32)
+        self._check(self.lib.loco_convergence_rows(self._ctx, _ptr(Vprev), _ptr(V), k, n, float(atol), _ptr(out),
+                                                   _stream()), "loco_convergence_rows")
         return out
 
     def null_project(self, Vm, Vn=None) -> torch.Tensor:

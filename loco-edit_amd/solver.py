@@ -14,12 +14,42 @@ the k x k algebra is replicated.
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Optional, Tuple
 
 import torch
 
 from .dist import ProbeSharder
+
+
+def default_stop_rule() -> str:
+    """How the stop test of edit.py:2489-2492 is applied (``LOCO_STOP_RULE``, default ``reference``).
+
+    The reference tests ``torch.allclose(v_prev, v, atol)`` on the right singular vectors LAPACK returns.  Measured on
+    the reference itself (``oracle/make_golden.py --only converge`` -> ``tests/golden/converge.pt``): with ONE probe the
+    sign LAPACK picks is stable and the loop stops when the vector has converged; with k >= 2 probes the left factor of
+    the nearly diagonal k x k problem comes back as a reflection (first row ~ -e_0, others vary), so at least one row of
+    ``v`` is the NEGATIVE of its predecessor in every iteration, the test never holds, and the reference runs ``max_iter``
+    iterations (40 of 40 random near-diagonal problems for every k in 2..64).
+
+    ``reference``: what the reference does -- a single probe stops on the test (rows compared up to sign, which for one
+    probe is the reference's own comparison); k >= 2 runs ``max_iter`` iterations, the test is still evaluated where the
+    reference evaluates it (every iteration after ``min_iter``) and reported, but does not end the loop.
+    ``aligned``: the test the reference intends -- every row allclose to +-its predecessor -- ends the loop for any k
+    (fewer iterations than the reference on spectra that converge; same subspace).
+    """
+    rule = os.environ.get("LOCO_STOP_RULE", "reference")
+    if rule not in ("reference", "aligned"):
+        raise ValueError(f"LOCO_STOP_RULE must be 'reference' or 'aligned', got {rule!r}")
+    return rule
+
+
+def _converged(algebra, V_prev, V, thr):
+    """[distance, flag] of the stop test, rows compared up to sign (``loco_convergence_rows``); test doubles that only
+    provide the flat comparison (fixed signs) are used as they are."""
+    fn = getattr(algebra, "convergence_rows", None) or algebra.convergence
+    return fn(V_prev, V, thr).tolist()
 
 
 class JacobianOperator:
@@ -56,7 +86,8 @@ def _n_out(op, V: torch.Tensor) -> int:
 
 def subspace_iteration(op, algebra, V0: torch.Tensor, min_iter: int = 10, max_iter: int = 100,
                        convergence_threshold: float = 1e-3, sharder: Optional[ProbeSharder] = None,
-                       verbose: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
+                       verbose: bool = True, stop_rule: Optional[str] = None
+                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
     """Core loop of edit.py:2443-2494 on orthonormal rows ``V0`` [k, n].
 
     ``op`` provides jvp/vjp/gather, ``algebra`` provides orthonormalize_/convergence
@@ -64,9 +95,11 @@ def subspace_iteration(op, algebra, V0: torch.Tensor, min_iter: int = 10, max_it
     sharding logic under gloo).  Returns (U_dense [k,n], s [k], V [k,n], n_iter)
     where U = J V_prev of the last iteration (edit.py:2457 -- the reference
     returns u one iteration behind vT) and s are the singular values of A.
+    ``stop_rule``: see ``default_stop_rule``.
     """
     sharder = sharder or ProbeSharder(None)
     k = V0.shape[0]
+    may_stop = (stop_rule or default_stop_rule()) == "aligned" or k == 1
     V = V0
     n_done = 0
     U = None
@@ -87,10 +120,10 @@ def subspace_iteration(op, algebra, V0: torch.Tensor, min_iter: int = 10, max_it
         n_done = i + 1
         need_flag = i > min_iter
         if verbose or need_flag:
-            dist_close = algebra.convergence(V_prev, V, convergence_threshold).tolist()   # edit.py:2489-2492
+            dist_close = _converged(algebra, V_prev, V, convergence_threshold)   # edit.py:2489-2492
             if verbose:
                 print(f'power method : {i}-th step convergence : ', dist_close[0])
-            if need_flag and dist_close[1] > 0.5:
+            if need_flag and may_stop and dist_close[1] > 0.5:
                 if verbose:
                     print('reach convergence threshold : ', dist_close[0])
                 break
@@ -100,7 +133,7 @@ def subspace_iteration(op, algebra, V0: torch.Tensor, min_iter: int = 10, max_it
 
 def local_basis(engine, x, t, at, pca_rank: int, mask=None, noise=False, min_iter=10, max_iter=100,
                 convergence_threshold=1e-3, v0: Optional[torch.Tensor] = None,
-                sharder: Optional[ProbeSharder] = None, verbose=True):
+                sharder: Optional[ProbeSharder] = None, verbose=True, stop_rule: Optional[str] = None):
     """Top-``pca_rank`` right singular subspace of J (edit.py:2406-2504).
 
     ``v0``: optional [n, k] Gaussian matrix standing in for the ``torch.randn``
@@ -117,7 +150,7 @@ def local_basis(engine, x, t, at, pca_rank: int, mask=None, noise=False, min_ite
     engine.qr_rows_(V)                                                       # edit.py:2436 (thin QR)
     op = JacobianOperator(engine, x, t, at, mask, noise)
     U, s, V, n_iter = subspace_iteration(op, engine, V, min_iter, max_iter, convergence_threshold,
-                                         sharder=sharder, verbose=verbose)
+                                         sharder=sharder, verbose=verbose, stop_rule=stop_rule)
     op.check_mask()
     u = op.gather(U).T.contiguous()                                          # [L, k]  (edit.py:2500-2502)
     if verbose:
@@ -128,7 +161,7 @@ def local_basis(engine, x, t, at, pca_rank: int, mask=None, noise=False, min_ite
 
 def local_basis_pair(engine, x, t, at, rank_a: int, mask_a, rank_b: int, mask_b, noise=False, min_iter=10, max_iter=100,
                      convergence_threshold=1e-3, v0_a: Optional[torch.Tensor] = None, v0_b: Optional[torch.Tensor] = None,
-                     sharder: Optional[ProbeSharder] = None, verbose=True):
+                     sharder: Optional[ProbeSharder] = None, verbose=True, stop_rule: Optional[str] = None):
     """The two solves of ``run_edit_null_space_projection`` -- modify space on ``mask_a``, null space on ``mask_b`` (its
     complement), same ``x``, ``t`` (edit.py:2290-2310) -- with their probes in ONE batch per pass.
 
@@ -140,6 +173,8 @@ def local_basis_pair(engine, x, t, at, rank_a: int, mask_a, rank_b: int, mask_b,
     ``((u_a, s_a, vT_a, n_iter_a), (u_b, s_b, vT_b, n_iter_b))`` with ``local_basis``'s conventions."""
     sharder = sharder or ProbeSharder(None)
     n, dev = engine.n, x.device
+    rule = stop_rule or default_stop_rule()
+    may_stop = [rule == "aligned" or rank_a == 1, rule == "aligned" or rank_b == 1]
     time_s = time.time()
     if v0_a is None:
         v0_a = torch.randn(n, rank_a, device=dev, dtype=torch.float32)          # edit.py:2435, first solve
@@ -189,10 +224,10 @@ def local_basis_pair(engine, x, t, at, rank_a: int, mask_a, rank_b: int, mask_b,
             need_flag = i > min_iter
             conv = False
             if verbose or need_flag:
-                dist_close = engine.convergence(Vj_prev, Vj, convergence_threshold).tolist()
+                dist_close = _converged(engine, Vj_prev, Vj, convergence_threshold)
                 if verbose:
                     print(f'power method [{"modify" if j == 0 else "null"}] : {i}-th step convergence : ', dist_close[0])
-                conv = need_flag and dist_close[1] > 0.5
+                conv = need_flag and may_stop[j] and dist_close[1] > 0.5
             if conv or i == max_iter - 1:
                 # this solve ends here: keep its U = J V_prev of this iteration (edit.py:2457 convention)
                 U_all = sharder.all_gather_rows(U_loc, k)

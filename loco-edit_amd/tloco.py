@@ -250,8 +250,11 @@ class EditDeepFloydIF(object):
         params = getattr(args, "params", None)
         if params is None:
             if getattr(args, "ckpt_path", ""):
-                params = torch.load(args.ckpt_path, map_location="cpu")
-                params = params.get("state_dict", params)
+                # vendored / latent-diffusion names load as they are; a CompVis pipeline file (`model.diffusion_model.*`
+                # next to the autoencoder and text encoder) and the diffusers UNet2DConditionModel naming are recognised
+                # and renamed, anything else is refused with the list of foreign keys (checkpoints.py)
+                from .checkpoints import normalize_unet_state_dict
+                params = normalize_unet_state_dict(torch.load(args.ckpt_path, map_location="cpu"), cfg)
             else:
                 seed = getattr(args, "synthetic_weights", None)
                 if seed is None:

@@ -398,6 +398,92 @@ def gen_celeba256_null(redit, YHS, PullBackDDPM, tmpdir, n_iter=3, k_null=5):
             "vT_projected_f16": vT.to(torch.float16), "u_null_norms": u_n.norm(dim=0)}
 
 
+def gen_converge(redit, YHS, PullBackDDPM, tmpdir):
+    """The FREE-RUNNING stop rule of edit.py:2489-2492 with the shipped arguments of run_edit_null_space_projection
+    (edit.py:2292-2310: min_iter=10, max_iter=50, convergence_threshold=1e-4; scripts: --pca_rank 1 --pca_rank_null 5).
+
+    torch.linalg.svd is wrapped to record every iterate the reference sees, so the fixture also holds, per iteration,
+    which rows LAPACK returned with the opposite sign of their predecessor (`flips`) and the largest elementwise change
+    up to sign (`max_delta`): with one probe the sign is stable and the loop stops when max_delta < 1e-4 (+ rtol); with
+    five probes some row flips in every iteration and the loop runs all 50.  `lapack_sign_trials`: the same observation
+    on random nearly diagonal k x n problems (k, n, trials, trials with a flipped first row, trials with any flipped row)."""
+    import io
+    import contextlib
+    import loco_oracle as orc
+    from loco_edit_amd.config import TINY_DDPM, MID_DDPM, synth_params
+    out = {"min_iter": 10, "max_iter": 50, "convergence_threshold": 1e-4, "weights_seed": 0, "v0_seed": 7, "x_seed": 1}
+
+    def run(cfg, k, mask, x, t, ed, v0):
+        real_randn, real_svd = torch.randn, torch.linalg.svd
+        vs = []
+
+        def fake_randn(*size, **kw):
+            if len(size) == 2 and size[0] == cfg.n:
+                return v0[:, :size[1]].clone()
+            return real_randn(*size, **kw)
+
+        def rec_svd(A, **kw):
+            r = real_svd(A, **kw)
+            vs.append(r[2].clone())
+            return r
+
+        torch.randn, torch.linalg.svd = fake_randn, rec_svd
+        try:
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                u, s, vT = ed.local_encoder_decoder_pullback_xt(x=x, t=t, pca_rank=k, min_iter=10, max_iter=50,
+                                                                convergence_threshold=1e-4, mask=mask)
+        finally:
+            torch.randn, torch.linalg.svd = real_randn, real_svd
+        flips = torch.stack([((vs[i - 1] * vs[i]).sum(dim=1) < 0) for i in range(1, len(vs))])
+        sg = [(vs[i - 1] * vs[i]).sum(dim=1, keepdim=True).sign() for i in range(1, len(vs))]
+        max_delta = torch.tensor([(vs[i - 1] - vs[i] * sg[i - 1]).abs().max().item() for i in range(1, len(vs))])
+        return u, s, vT, len(vs), flips, max_delta
+
+    for tag, cfg, mrect in (("tiny", TINY_DDPM, (15, 16, 10, 11)), ("mid", MID_DDPM, (40, 42, 12, 14))):
+        params = synth_params(cfg, seed=0)
+        model = ref_model(PullBackDDPM, cfg, params)
+        ed = ref_edit(redit, YHS, model, tmpdir)
+        oed = orc.OracleEdit(orc.to_torch(params), cfg)
+        x = torch.randn(1, cfg.in_channels, cfg.resolution, cfg.resolution, generator=torch.Generator().manual_seed(1))
+        t = ed.scheduler.timesteps[int(ed.edit_t_idx)]
+        mask = rect_mask(cfg, *mrect)
+        v0 = torch.randn(cfg.n, 5, generator=torch.Generator().manual_seed(7))
+        o = {"mask": mask, "x": x, "t": t.clone()}
+        u, s, vT, n_it, flips, md = run(cfg, 1, mask, x, t, ed, v0)
+        print(f"  {tag}: modify space, 1 probe: reference stopped after {n_it} iterations; rows flipped in "
+              f"{int(flips.any(dim=1).sum())} of {n_it - 1} iterations; max_delta around the stop "
+              f"{md[n_it - 3].item():.3e} -> {md[n_it - 2].item():.3e}")
+        assert 13 <= n_it <= 40, "pick a mask whose one-probe solve stops inside the window"
+        o.update(n_iter_modify=n_it, s_modify=s, vT_modify=vT, u_modify=u, flips_modify=flips, max_delta_modify=md)
+        _, os_, ovT, on = oed.pullback(x, t, 1, v0[:, :1], min_iter=10, max_iter=50, convergence_threshold=1e-4, mask=mask)
+        assert on == n_it, (on, n_it)
+        check(f"converge/{tag}/modify s", os_, s, rtol=1e-4)
+        assert abs_cos_rows(ovT, vT).min() > 0.9999
+        if tag == "tiny":           # the five-probe null-space solve on the complement: every iteration has a flipped row
+            u, s, vT, n_it, flips, md = run(cfg, 5, ~mask, x, t, ed, v0)
+            print(f"  {tag}: null space, 5 probes: reference ran {n_it} iterations; rows flipped in "
+                  f"{int(flips.any(dim=1).sum())} of {n_it - 1} iterations")
+            assert n_it == 50 and bool(flips[10:].any(dim=1).all())
+            o.update(n_iter_null=n_it, s_null=s, vT_null=vT, flips_null=flips, max_delta_null=md)
+        out[tag] = o
+    g = torch.Generator().manual_seed(0)
+    trials = []
+    for k in (2, 3, 5, 8, 16, 20, 64):
+        for n in (3072, 12288):
+            neg0 = anyflip = 0
+            for _ in range(40):
+                V = torch.linalg.qr(torch.randn(n, k, generator=g))[0].T
+                sv = torch.sort(torch.rand(k, generator=g) * 3 + 0.5, descending=True)[0]
+                A = ((torch.eye(k) + 0.02 * torch.randn(k, k, generator=g)) * sv[None, :]) @ V
+                d = (torch.linalg.svd(A, full_matrices=False)[2] * V).sum(1)
+                neg0 += int(d[0] < 0)
+                anyflip += int((d < 0).any())
+            trials.append((k, n, 40, neg0, anyflip))
+            print(f"  LAPACK on nearly diagonal {k} x {n}: first row flipped {neg0}/40, any row flipped {anyflip}/40")
+    out["lapack_sign_trials"] = torch.tensor(trials)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the 256x256 CelebA-DDPM summaries (minutes of CPU)")
@@ -455,6 +541,9 @@ def main():
         print(f"config 2 at size: null-space solve on the complement mask, {a.iters} iterations + projection")
         torch.save(gen_celeba256_null(redit, YHS, PullBackDDPM, tmpdir, n_iter=a.iters),
                    os.path.join(GOLD, "celeba256_null.pt"))
+    if a.only == "converge":
+        print("free-running stop rule (shipped arguments) on the tiny and mid configs")
+        torch.save(gen_converge(redit, YHS, PullBackDDPM, tmpdir), os.path.join(GOLD, "converge.pt"))
     if a.only == "eta1":
         print("tiny eta=1 decode with injected noise")
         torch.save(gen_eta1_decode(redit, YHS, PullBackDDPM, tmpdir), os.path.join(GOLD, "tiny_eta1.pt"))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-call A/B of library builds (by hand, through gpurun): bash tests/ab_bench.sh libA.so libB.so ...
+# Same-call A/B of library builds (by hand, through gpurun): bash tests/diag/ab_bench.sh libA.so libB.so ...
 # Every library in loco-edit_amd/ named on the command line runs the default bench twice, interleaved.
 cd ${GRAFT_REPO_ROOT:-.}
 for i in 1 2; do

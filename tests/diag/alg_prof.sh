@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/alg -o a --output-format csv -- python3 $R/tests/algebra_bench.py > $R/gpurun_out/alg.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/alg -o a --output-format csv -- python3 $R/tests/diag/algebra_bench.py > $R/gpurun_out/alg.log 2>&1
 python3 - <<'PY'
 import csv,os
 R=os.environ['GRAFT_REPO_ROOT']

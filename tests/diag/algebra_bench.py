@@ -1,7 +1,7 @@
 """Tuning aid (by hand): time the replicated k x n solver algebra for the multi-GPU probe counts."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import loco_edit_amd  # noqa
 from loco_edit_amd.config import CELEBA_DDPM, synth_params

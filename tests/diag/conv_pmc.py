@@ -1,6 +1,6 @@
 """Diagnostic (by hand, under rocprofv3 --pmc): a few launches of the dominant bf16x3 conv shape."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import loco_edit_amd  # noqa
 import loco_edit_amd.hip as H

@@ -3,7 +3,7 @@
 the complement, projection, edit frames, 59-step decode of the frames), per stage."""
 import os, sys, time, tempfile
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import loco_edit_amd  # noqa
 from loco_edit_amd.define_argparser import parse_args, preset

@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python3 $R/tests/fwd_b1_time.py ${FB:-1} 50 2>&1 | grep -v amdgpu
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/fb1 -o f --output-format csv -- python3 $R/tests/fwd_b1_time.py ${FB:-1} 50 > $R/gpurun_out/fb1.log 2>&1
+python3 $R/tests/diag/fwd_b1_time.py ${FB:-1} 50 2>&1 | grep -v amdgpu
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/fb1 -o f --output-format csv -- python3 $R/tests/diag/fwd_b1_time.py ${FB:-1} 50 > $R/gpurun_out/fb1.log 2>&1
 grep "B=" $R/gpurun_out/fb1.log
 python3 - <<'PY'
 import csv,os

@@ -2,7 +2,7 @@
 the summed kernel time of a rocprofv3 --kernel-trace --stats run of this script."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import loco_edit_amd  # noqa
 from loco_edit_amd.config import CELEBA_DDPM, synth_params

@@ -2,7 +2,7 @@
 layer-by-layer comparison of the HIP engine with the CPU oracle, then the
 tangent / cotangent passes and the solver algebra against the golden vectors.
 
-    python tests/gpu_bringup.py [tiny|mid|full] ...
+    python tests/diag/gpu_bringup.py [tiny|mid|full] ...
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 

@@ -1,7 +1,13 @@
-"""Diagnostic: mean FETCH_SIZE / WRITE_SIZE (KiB -> MB, fetch doubled for the 16-byte-load variants: gfx950 correction)
-of the conv kernel in a rocprofv3 --pmc run of tests/conv_pmc.py.  python tests/diag/pmc_shape.py <dir> <counter>"""
+"""Diagnostic: mean FETCH_SIZE / WRITE_SIZE of the conv kernel in a rocprofv3 --pmc run of tests/diag/conv_pmc.py, as the
+RAW counter (KiB x 1024 -> MB; this is what profiles/r03_fetch_size_calibration.md tabulates: for this kernel's 64-byte
+runs the raw FETCH_SIZE lands inside the hard bounds of the bytes it requests, no doubling) and, for FETCH_SIZE, next to
+it the x2 value the MI355X guide prescribes for wide 16-byte-per-lane streams.
+python tests/diag/pmc_shape.py <dir> <counter>"""
 import csv, glob, os, sys
 f = (glob.glob(os.path.join(sys.argv[1], "*counter_collection.csv")) + glob.glob(os.path.join(sys.argv[1], "*", "*counter_collection.csv")))[0]
 v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == sys.argv[2] and "conv_mfma" in r["Kernel_Name"]]
-corr = 2.0 if sys.argv[2] == "FETCH_SIZE" else 1.0
-print(sys.argv[2], len(v), "launches, mean MB per launch", round(sum(v) / len(v) * 1024 * corr / 1e6, 1), "(min", round(min(v) * 1024 * corr / 1e6, 1), "max", round(max(v) * 1024 * corr / 1e6, 1), ")")
+mb = lambda x: round(x * 1024 / 1e6, 1)
+line = f"{sys.argv[2]} {len(v)} launches, RAW mean MB per launch {mb(sum(v) / len(v))} (min {mb(min(v))} max {mb(max(v))})"
+if sys.argv[2] == "FETCH_SIZE":
+    line += f"; x2 (16-byte streaming correction, not applied in the tables) {mb(2 * sum(v) / len(v))}"
+print(line)

@@ -1,7 +1,7 @@
 """Tuning aid (by hand): per-layer-shape conv timing inside one real solver iteration."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import loco_edit_amd  # noqa
 from loco_edit_amd.config import CELEBA_DDPM, synth_params

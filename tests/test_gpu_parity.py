@@ -192,6 +192,50 @@ def test_headline_config_12_iterations_vs_reference(prec, engines, golden):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+def test_free_running_stop_rule_vs_reference(prec, engines, golden, monkeypatch):
+    """The solver FREE-RUNNING with the shipped arguments of run_edit_null_space_projection (edit.py:2292-2310:
+    min_iter=10, max_iter=50, convergence_threshold=1e-4; scripts: --pca_rank 1 --pca_rank_null 5) against
+    tests/golden/converge.pt, the reference's own free runs: the one-probe modify-space solve stops at the reference's
+    iteration (tiny: 20, mid: 24) with its vector; the five-probe null-space solve runs all 50 iterations like the
+    reference (LAPACK hands back a sign-flipped row in every iteration, its allclose never holds) under the default
+    stop rule, and stops early (same subspace) under LOCO_STOP_RULE=aligned."""
+    from loco_edit_amd import solver
+    g = golden("converge")
+    monkeypatch.delenv("LOCO_STOP_RULE", raising=False)
+    kw = dict(min_iter=g["min_iter"], max_iter=g["max_iter"], convergence_threshold=g["convergence_threshold"], verbose=False)
+    for tag, cfg in (("tiny", TINY_DDPM), ("mid", MID_DDPM)):
+        f = g[tag]
+        eng = engines(cfg, prec)
+        at = float(_sched().alpha_at(f["t"]))
+        v0 = torch.randn(cfg.n, 5, generator=torch.Generator().manual_seed(g["v0_seed"])).to(DEV)
+        x, mask = f["x"].to(DEV), f["mask"].to(DEV)
+        u, s, vT, n_it = solver.local_basis(eng, x, float(f["t"]), at, 1, mask=mask, v0=v0[:, :1].contiguous(), **kw)
+        c = (vT.cpu() * f["vT_modify"]).sum().abs().item()
+        print(f"[{prec}] {tag}: one probe stopped after {n_it} (reference {f['n_iter_modify']}), |cos| {c:.7f}")
+        assert n_it == f["n_iter_modify"]
+        assert c > 0.9999 and torch.allclose(s.cpu(), f["s_modify"], rtol=1e-3)
+        assert torch.nn.functional.cosine_similarity(u.cpu().T, f["u_modify"].T, dim=1).abs().min().item() > 0.999
+        if tag != "tiny":
+            continue
+        u, s, vT, n_it = solver.local_basis(eng, x, float(f["t"]), at, 5, mask=~mask, v0=v0, **kw)
+        cos, span = _row_cos(vT, f["vT_null"])
+        print(f"[{prec}] tiny: five probes ran {n_it} (reference {f['n_iter_null']}), |cos| {cos.tolist()}, span {span.min().item():.6f}")
+        assert n_it == f["n_iter_null"] == 50
+        assert span.min().item() > 0.999 and cos.min().item() > 0.99 and torch.allclose(s.cpu(), f["s_null"], rtol=1e-3)
+        # the intended test (rows up to sign): the count the reference's own iterates give under it, or max_iter
+        md = f["max_delta_null"]
+        hit = [i + 1 for i in range(1, len(md) + 1) if i > 10 and md[i - 1] < 0.97e-4]
+        _, _, vA, n_al = solver.local_basis(eng, x, float(f["t"]), at, 5, mask=~mask, v0=v0, stop_rule="aligned", **kw)
+        assert n_al == (hit[0] if hit else 50)
+        # and on a problem that does converge: 2 probes on the one-pixel mask (3 rows: rank 3) stop early when aligned
+        _, _, v2r, n2r = solver.local_basis(eng, x, float(f["t"]), at, 2, mask=mask, v0=v0[:, :2].contiguous(), **kw)
+        _, _, v2a, n2a = solver.local_basis(eng, x, float(f["t"]), at, 2, mask=mask, v0=v0[:, :2].contiguous(),
+                                            stop_rule="aligned", **kw)
+        print(f"[{prec}] tiny: two probes, reference rule {n2r} iterations, aligned rule {n2a}")
+        assert n2r == 50 and 12 <= n2a <= 50 and _row_cos(v2a, v2r.cpu())[1].min().item() > 0.9999
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_mid_config_solver_vs_reference(prec, engines, golden):
     """64x64 config, 3 probes, 3 iterations (tests/golden/mid.pt, full reference tensors)."""
     from loco_edit_amd import solver

@@ -423,3 +423,57 @@ def test_branch_streams_on_cpu_run_in_order():
     order = []
     out = bs.run([lambda i=i: (order.append(i), i * i)[1] for i in range(3)])
     assert out == [0, 1, 4] and order == [0, 1, 2]
+
+
+def test_stop_rule_reference_and_aligned(monkeypatch):
+    """solver.subspace_iteration's stop rules on a small dense operator with LAPACK-signed rows (as the reference sees
+    them): `reference` stops a single probe on the test and runs k >= 2 probes to max_iter; `aligned` (rows compared up
+    to sign) stops both.  LOCO_STOP_RULE selects the default; a wrong value is refused."""
+    import pytest
+    import torch
+    from loco_edit_amd import solver
+
+    g = torch.Generator().manual_seed(0)
+    Uq = torch.linalg.qr(torch.randn(12, 12, generator=g, dtype=torch.float64))[0]
+    Vq = torch.linalg.qr(torch.randn(60, 12, generator=g, dtype=torch.float64))[0]
+    J = (Uq * torch.tensor([10.0, 5.0, 2.5, 1.2] + [0.5] * 8, dtype=torch.float64)) @ Vq.T     # fast-decaying spectrum
+
+    class Op:
+        n_out = 12
+
+        def jvp(self, V):
+            return V @ J.T
+
+        def vjp(self, U):
+            return U @ J
+
+        def gather(self, U):
+            return U
+
+    class LapackAlgebra:                      # raw LAPACK rows, sign-agnostic row test = what loco_convergence_rows does
+        def orthonormalize_(self, A):
+            _, s, vh = torch.linalg.svd(A, full_matrices=False)
+            A.copy_(vh)
+            return s
+
+        def convergence_rows(self, a, b, atol):
+            sg = (a * b).sum(dim=1, keepdim=True).sign()
+            return torch.tensor([torch.dist(a, b * sg).item(), float(torch.allclose(a, b * sg, atol=atol))])
+
+        convergence = None
+
+    def run(k, rule):
+        V0 = torch.linalg.qr(torch.randn(60, k, generator=torch.Generator().manual_seed(1), dtype=torch.float64))[0].T.contiguous()
+        return solver.subspace_iteration(Op(), LapackAlgebra(), V0, min_iter=3, max_iter=40, convergence_threshold=1e-6,
+                                         verbose=False, stop_rule=rule)
+
+    n1_ref, n1_al = run(1, "reference")[3], run(1, "aligned")[3]
+    assert n1_ref == n1_al and 5 <= n1_ref < 40
+    assert run(3, "reference")[3] == 40
+    n3 = run(3, "aligned")[3]
+    assert 5 <= n3 < 40
+    monkeypatch.setenv("LOCO_STOP_RULE", "aligned")
+    assert run(3, None)[3] == n3
+    monkeypatch.setenv("LOCO_STOP_RULE", "lapack")
+    with pytest.raises(ValueError):
+        run(3, None)

@@ -1,6 +1,8 @@
 """CPU: the latent T-LOCO oracle (oracle/tloco_sd_oracle.py) against the fixture the reference's own EditStableDiffusion
 methods produced on the stand-in networks (tests/golden/tloco_sd_tiny.pt, oracle/make_golden_tloco_sd.py), plus the
 host logic of the product module (scheduler table, preset routing)."""
+import os
+
 import pytest
 import torch
 
@@ -149,3 +151,63 @@ def test_autoencoder_kl_encoder_key_map_round_trip():
     del hf["encoder.conv_out.bias"]
     with pytest.raises(KeyError):
         hf_autoencoder_kl_to_encoder(hf, TINY_ENCODER)
+
+
+def test_shipped_stable_diffusion_model_id_gets_the_2_1_base_architecture(tmp_path, monkeypatch):
+    """scripts/main_T2I_StableDiffusion_null_space_projection*.sh:4 name `stabilityai/stable-diffusion-2-1-base`: names of
+    the 2.x family build config.SD21_BASE_UNET (1024-wide prompt states, 64-channel heads = 5/10/20/20 heads, the published
+    865 910 724 parameters), v1 names keep SD15_UNET."""
+    import json
+    import numpy as np
+    from loco_edit_amd import define_argparser
+    from loco_edit_amd.config import SD15_UNET, SD21_BASE_UNET, param_shapes
+    monkeypatch.chdir(tmp_path)
+    scripts = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "script_args.json")))
+    ids = {a[a.index("--model_name") + 1] for a in scripts.values() if "--model_name" in a and "stable-diffusion" in a[a.index("--model_name") + 1]}
+    assert ids == {"stabilityai/stable-diffusion-2-1-base"}
+    a = define_argparser.preset(define_argparser.parse_args(
+        ["--model_name", "stabilityai/stable-diffusion-2-1-base", "--dataset_name", "Random", "--note", "n", "--seed", "3",
+         "--device", "cpu", "--run_edit_null_space_projection_zt", "True"]))
+    assert a.unet_config is SD21_BASE_UNET and (a.unet_config.context_len, a.unet_config.context_dim) == (77, 1024)
+    assert a.unet_config.num_heads == -1 and a.unet_config.num_head_channels == 64
+    assert sum(int(np.prod(v)) for v in param_shapes(SD21_BASE_UNET).values()) == 865_910_724
+    b = define_argparser.preset(define_argparser.parse_args(
+        ["--model_name", "CompVis/stable-diffusion-v1-4", "--dataset_name", "Random", "--note", "n", "--seed", "3", "--device", "cpu"]))
+    assert b.unet_config is SD15_UNET
+
+
+def test_stable_diffusion_checkpoint_layouts_load_by_name():
+    """checkpoints.normalize_unet_state_dict: (1) a CompVis pipeline file (`model.diffusion_model.*` next to
+    `first_stage_model.*`, `cond_stage_model.*`, schedule buffers, wrapped in {"state_dict": ...}); (2) the diffusers
+    UNet2DConditionModel naming, with nn.Linear proj_in / proj_out as Stable Diffusion 2.x stores them; both come back as
+    exactly the engine's parameter list with its shapes and values.  Foreign keys are refused with their names."""
+    from loco_edit_amd.checkpoints import (hf_unet2d_condition_to_ldm, is_compvis_sd, is_hf_unet2d_condition,
+                                           ldm_to_hf_unet2d_condition, normalize_unet_state_dict)
+    from loco_edit_amd.config import SD21_BASE_UNET, TINY_LDM, param_shapes
+    cfg = TINY_LDM
+    sd = {k: torch.from_numpy(v) for k, v in synth_params(cfg, 5).items()}
+    want = param_shapes(cfg)
+    ck = {"model.diffusion_model." + k: v for k, v in sd.items()}
+    ck.update({"first_stage_model.decoder.conv_in.weight": torch.zeros(2), "cond_stage_model.transformer.x": torch.zeros(1),
+               "betas": torch.zeros(3), "model_ema.decay": torch.zeros(())})
+    assert is_compvis_sd(ck)
+    got = normalize_unet_state_dict({"state_dict": ck}, cfg)
+    assert list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    hf = ldm_to_hf_unet2d_condition(sd, cfg)
+    assert is_hf_unet2d_condition(hf) and not is_hf_unet2d_condition(sd) and len(hf) == len(sd)
+    for k in ("time_embedding.linear_1.weight", "conv_in.weight", "down_blocks.0.resnets.0.time_emb_proj.weight",
+              "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight", "down_blocks.0.downsamplers.0.conv.weight",
+              "mid_block.attentions.0.proj_in.weight", "mid_block.resnets.1.conv2.weight", "up_blocks.0.resnets.1.conv_shortcut.weight",
+              "up_blocks.0.upsamplers.0.conv.weight", "up_blocks.1.attentions.1.transformer_blocks.0.ff.net.0.proj.weight",
+              "conv_norm_out.weight", "conv_out.bias"):
+        assert k in hf, k
+    hf2 = {k: (v[:, :, 0, 0] if k.endswith(("proj_in.weight", "proj_out.weight")) else v) for k, v in hf.items()}   # 2.x: nn.Linear
+    got = normalize_unet_state_dict(hf2, cfg)
+    assert set(got) == set(sd) and all(tuple(got[k].shape) == tuple(want[k]) and torch.equal(got[k], sd[k]) for k in sd)
+    with pytest.raises(ValueError, match="not parameters of this architecture"):
+        normalize_unet_state_dict({**sd, "lora.up.weight": torch.zeros(1)}, cfg)
+    # the full-size layout: the map is a bijection onto the 686 tensors of the 2.1-base architecture (names only)
+    big = param_shapes(SD21_BASE_UNET)
+    names = ldm_to_hf_unet2d_condition({k: None for k in big}, SD21_BASE_UNET)
+    assert len(names) == len(big) and "up_blocks.0.upsamplers.0.conv.weight" in names and "up_blocks.3.attentions.2.proj_out.bias" in names
+    assert set(hf_unet2d_condition_to_ldm(names, SD21_BASE_UNET)) == set(big)
