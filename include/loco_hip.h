@@ -176,6 +176,12 @@ int  loco_mask_gather(loco_ctx* ctx, const float* U, int32_t k, float* out, void
  * on the device; the first call after a primal reads L back (one 4-byte copy + stream sync). */
 int64_t loco_mask_count(loco_ctx* ctx);
 
+/* Measurement helper for bench.py: enqueue a one-lane kernel that writes {shader-clock counter (s_memtime),
+ * 100 MHz counter (s_memrealtime)} to out2 (device, 2 x uint64).  Two stamps around a timed region give the average
+ * shader clock over it: (d s_memtime / d s_memrealtime) x 100 MHz -- MI355X lowers its clock under matrix load and
+ * boxes differ by several percent, which otherwise hides kernel changes in box-to-box comparisons. */
+int  loco_clock_stamp(loco_ctx* ctx, uint64_t* out2, void* stream);
+
 /* Work model helpers for bench.py: 2*MAC of one denoiser evaluation (B=1). */
 double loco_unet_flops(loco_ctx* ctx);
 /* Bytes of device memory the ctx holds. */

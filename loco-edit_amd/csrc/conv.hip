@@ -356,6 +356,12 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
     if (prec && t == 4) t = 5;
     if (prec && a.stride == 2 && t == 5) t = 0;
     if (t < 0 || t > 5) t = 0;
+    if (prec && conv_lowp_uses_spec(a, taps)) {
+        static char sn[3][5][40];
+        const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;
+        if (!sn[prec][mm][0]) snprintf(sn[prec][mm], 40, "%s<%d>", prec == 1 ? "conv_spec_bf16x3" : "conv_spec_f16", mm);
+        return sn[prec][mm];
+    }
     int ti = taps == 9 ? 0 : 1;
     int m = a.mode;
     if (taps != 9 && m != CM_NONE) m = CM_GN;

@@ -53,6 +53,22 @@ int conv_bf16_tile_couts(const ConvArgs& a) {
     static const int MTs[6] = {128, 128, 32, 64, 128, 128};
     return MTs[bf16_tile_of(a)];
 }
+// Role-split 3x3 kernel (conv_spec_kernel.h): 128 x 256 tiles of stride-1 convs whose input lives in a padded engine
+// arena (16-byte halo loads) with whole 16-channel chunks.  LOCO_CONV_SPEC=0 is the A/B switch back to the lock-step kernel.
+static int conv_spec_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LOCO_CONV_SPEC"); v = e ? (atoi(e) != 0) : 0; }
+    return v;
+}
+int conv_spec_dma_by_compute() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LOCO_SPEC_DMA"); v = e ? (atoi(e) != 0) : 1; }
+    return v;
+}
+bool conv_lowp_uses_spec(const ConvArgs& a, int taps) {
+    return conv_spec_enabled() && taps == 9 && bf16_tile_of(a) == 5 && a.stride == 1 && !a.upsample && !a.zins &&
+           (a.Cin % BKC) == 0 && a.in_padded && a.pad == 1;
+}
 // the epilogue statistics exist on the LDS-staged path of whole cout tiles (conv_bf16_kernel.h) and need the finished
 // sums, i.e. no split-K
 bool conv_lowp_can_fuse_stats(const ConvArgs& a) {

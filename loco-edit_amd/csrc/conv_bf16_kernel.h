@@ -75,10 +75,19 @@ __device__ __forceinline__ void cvt2(float a, float b, unsigned& hi, unsigned& l
         hi = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
         lo = 0;
     } else {
-        __bf16 ha = (__bf16)a, hb = (__bf16)b;
-        __bf16 la = (__bf16)(a - (float)ha), lb = (__bf16)(b - (float)hb);
-        hi = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
-        lo = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
+        // both halves of a dword by ONE v_cvt_pk_bf16_f32 each (scalar __bf16 casts compile to one conversion per value
+        // plus shift / or packing: 11 vector instructions per pair instead of 6); the hi values go back to fp32 as the
+        // dword's two 16-bit fields -- same roundings, same bits
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+        const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+        // the residuals as two scalar subtractions: left to itself the compiler packs them into one v_pk_add_f32, which
+        // costs more beside MFMAs than the two v_sub_f32 it replaces (measured: 304.5 vs 302.8 ms per step)
+        float da = a - ha;
+        asm volatile("" : "+v"(da));
+        const float db = b - hb;
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){da, db}, bf16x2_));
     }
 }
 
@@ -98,6 +107,176 @@ constexpr int max_halo(int NT, int taps, bool s2) {
         return s2 ? (2 * th + 1) * 65 : (th + 2) * 34;
     }
     return s2 ? 17 * 17 : 10 * 10;   // NT = 64 : 8x8 output tile
+}
+
+// Epilogue of the low-precision conv kernels (shared by the lock-step kernel below and the role-split kernel of
+// conv_spec_kernel.h): the WM x WN compute waves (threads 0 .. WM*WN*64-1) write their accumulator tiles.
+// D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem_b, const int co0,
+                                                   const int oy0, const int ox0, const int TW, const int tile_id, const int b,
+                                                   const int split) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int MT = WM * TM * 32;
+    constexpr int NT = WN * TN * 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int khalf = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const long out_plane = (long)a.Hout * a.Wout;
+    const bool full_co = (co0 + MT <= a.Cout);
+    if (full_co) {
+        // Whole cout tiles leave through LDS: in the accumulator layout a lane owns ONE pixel of 16 couts, i.e. 64 dword
+        // stores per lane and tile, and the tile's write-out is bound by store ISSUE, not by bandwidth (512 wave-stores of
+        // 256 bytes per workgroup).  Staged through the (now idle) operand buffers as S[cout][pixel], a lane reads back 4
+        // consecutive pixels of one cout and the tile leaves in 16-byte stores: a quarter of the vector-memory
+        // instructions for the same bytes, residual / accumulate reads likewise as 16-byte loads.  One round per
+        // accumulator row block h (WM x 32 couts x NT pixels <= 64 KB).
+        constexpr int SROWS = WM * 32, NQ = NT / 4, NTASK = (SROWS * NQ) / NTHR;
+        static_assert((SROWS * NQ) % NTHR == 0 && (NQ & (NQ - 1)) == 0, "epilogue task split");
+        float* const S = reinterpret_cast<float*>(smem_b);
+        const bool part = a.nsplit > 1;
+        float* const ob = part ? a.partial + (((long)split * a.B + b) * a.Cout) * out_plane : a.out + (long)b * a.out_bs;
+        const float* const rb = (!part && a.res) ? a.res + (long)b * a.res_bs : nullptr;
+        const float* const b2 = (!part && a.bias2) ? a.bias2 + (long)b * a.bias2_bs : nullptr;
+        const float* const b1 = part ? nullptr : a.bias;
+        const bool accu = !part && a.accumulate;
+        const int twsh = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
+#pragma unroll
+        for (int h = 0; h < TM; ++h) {
+            if (h > 0) {                                   // the previous round's read-back is done in every wave
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    S[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * NT + (wn * TN + j) * 32 + l31] = acc[h][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            f32x4 v[NTASK], rv[NTASK];
+            unsigned off[NTASK];                        // element offset inside one sample's tensor (< 2^31)
+            int cos_[NTASK];
+#pragma unroll
+            for (int q = 0; q < NTASK; ++q) {
+                const int t = q * NTHR + tid;
+                const int row = t / NQ, quad = t & (NQ - 1);
+                v[q] = *reinterpret_cast<const f32x4*>(&S[row * NT + quad * 4]);
+                const int co = co0 + ((row >> 5) * TM + h) * 32 + (row & 31);
+                const int p = quad * 4;
+                const int ty = p >> twsh, tx = p & (TW - 1);
+                cos_[q] = co;
+                off[q] = (unsigned)co * (unsigned)out_plane + (unsigned)((oy0 + ty) * a.Wout + ox0 + tx);
+            }
+            if (rb || accu) {
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+                    if (rb) t4 = *reinterpret_cast<const f32x4*>(rb + off[q]);
+                    if (accu) t4 += *reinterpret_cast<const f32x4*>(ob + off[q]);
+                    rv[q] = t4;
+                }
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) v[q] += rv[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NTASK; ++q) {
+                float add = 0.f;
+                if (b1) add += b1[cos_[q]];
+                if (b2) add += b2[cos_[q]];
+                v[q] += add;
+                __builtin_nontemporal_store(v[q], reinterpret_cast<f32x4*>(ob + off[q]));   // streamed once: keep L2 for the shared primal cache / weights
+            }
+            // Forward GroupNorm statistics of the finished tile for the norm that consumes this tensor (kernels.h
+            // ConvArgs::st_part): the NQ lanes of a task row hold one cout over the tile's NT pixels; sums about a pivot
+            // inside the row's data (its first value in this tile: no cancellation of sum x^2 - n mean^2 when |mean| >> std),
+            // butterfly over the row's lanes, one lane writes {mean, M2} of the row tile.  (The tangent / cotangent means
+            // were tried here too: they need the {S, xhat} records of the output tile, 8 more bytes per element read in the
+            // latency-exposed epilogue -- 9-26 us per launch against the 16-21 us of the standalone pass, not adopted.)
+            if (a.st_kind == ST_FWD && !part) {
+                const int ntile = (a.Hout * a.Wout) / NT;
+                float* const sp = a.st_part + (long)b * a.Cout * ntile * 2;
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    const float pivot = __shfl(v[q][0], lane & ~(NQ - 1) & 63, 64);
+                    const float d0 = v[q][0] - pivot, d1 = v[q][1] - pivot, d2 = v[q][2] - pivot, d3 = v[q][3] - pivot;
+                    float s1 = (d0 + d1) + (d2 + d3);
+                    float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+                    for (int m = 1; m < (NQ < 64 ? NQ : 64); m <<= 1) {
+                        s1 += __shfl_xor(s1, m, 64);
+                        s2 += __shfl_xor(s2, m, 64);
+                    }
+                    const float m = s1 * (1.0f / NT);
+                    const int t = q * NTHR + tid;
+                    if ((t & (NQ - 1)) == 0)
+                        *reinterpret_cast<f32x2*>(sp + ((long)cos_[q] * ntile + tile_id) * 2) = f32x2{pivot + m, s2 - s1 * m};
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int p = (wn * TN + j) * 32 + l31;
+        int ty = p / TW, tx = p - ty * TW;
+        int oy = oy0 + ty, ox = ox0 + tx;
+        const unsigned pix = (unsigned)(oy * a.Wout + ox);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int cob = co0 + (wm * TM + i) * 32 + 4 * khalf;
+            if (a.nsplit > 1) {
+                float* pb = a.partial + (((long)split * a.B + b) * a.Cout) * out_plane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co = cob + (r & 3) + 8 * (r >> 2);
+                    if (full_co || co < a.Cout) pb[(long)co * out_plane + pix] = acc[i][j][r];
+                }
+            } else {
+                float* ob = a.out + (long)b * a.out_bs;
+                const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+                const float* b2 = a.bias2 ? a.bias2 + (long)b * a.bias2_bs : nullptr;
+                if (rb || a.accumulate) {
+                    // The residual may alias the output (nin shortcut written in place), so the compiler cannot
+                    // move a residual load above the previous store: gather the 16 residual / accumulate values of
+                    // the tile first (each thread only touches its own elements), then add and store.
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = cob + (r & 3) + 8 * (r >> 2);
+                        const bool ok = full_co || co < a.Cout;
+                        const long off = (long)(ok ? co : a.Cout - 1) * out_plane + pix;
+                        float t = 0.f;
+                        if (rb) t = rb[off];
+                        if (a.accumulate) t += ob[off];
+                        rv[r] = t;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = cob + (r & 3) + 8 * (r >> 2);
+                        if (!(full_co || co < a.Cout)) continue;
+                        float v = acc[i][j][r] + rv[r];
+                        if (a.bias) v += a.bias[co];
+                        if (b2) v += b2[co];
+                        __builtin_nontemporal_store(v, &ob[(long)co * out_plane + pix]);   // streamed once: keep L2 for the shared primal cache / weights (2 ms per step)
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = cob + (r & 3) + 8 * (r >> 2);
+                        if (!(full_co || co < a.Cout)) continue;
+                        float v = acc[i][j][r];
+                        if (a.bias) v += a.bias[co];
+                        if (b2) v += b2[co];
+                        __builtin_nontemporal_store(v, &ob[(long)co * out_plane + pix]);   // streamed once: keep L2 for the shared primal cache / weights (2 ms per step)
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int PR, int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
@@ -864,159 +1043,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
 
     }
 
-    // epilogue.  D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const long out_plane = (long)a.Hout * a.Wout;
-    const bool full_co = (co0 + MT <= a.Cout);
-    if (full_co) {
-        // Whole cout tiles leave through LDS: in the accumulator layout a lane owns ONE pixel of 16 couts, i.e. 64 dword
-        // stores per lane and tile, and the tile's write-out is bound by store ISSUE, not by bandwidth (512 wave-stores of
-        // 256 bytes per workgroup).  Staged through the (now idle) operand buffers as S[cout][pixel], a lane reads back 4
-        // consecutive pixels of one cout and the tile leaves in 16-byte stores: a quarter of the vector-memory
-        // instructions for the same bytes, residual / accumulate reads likewise as 16-byte loads.  One round per
-        // accumulator row block h (WM x 32 couts x NT pixels <= 64 KB).
-        constexpr int SROWS = WM * 32, NQ = NT / 4, NTASK = (SROWS * NQ) / NTHR;
-        static_assert((SROWS * NQ) % NTHR == 0 && (NQ & (NQ - 1)) == 0, "epilogue task split");
-        float* const S = reinterpret_cast<float*>(smem_b);
-        const bool part = a.nsplit > 1;
-        float* const ob = part ? a.partial + (((long)split * a.B + b) * a.Cout) * out_plane : a.out + (long)b * a.out_bs;
-        const float* const rb = (!part && a.res) ? a.res + (long)b * a.res_bs : nullptr;
-        const float* const b2 = (!part && a.bias2) ? a.bias2 + (long)b * a.bias2_bs : nullptr;
-        const float* const b1 = part ? nullptr : a.bias;
-        const bool accu = !part && a.accumulate;
-        const int twsh = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
-#pragma unroll
-        for (int h = 0; h < TM; ++h) {
-            if (h > 0) {                                   // the previous round's read-back is done in every wave
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    S[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * NT + (wn * TN + j) * 32 + l31] = acc[h][j][r];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            f32x4 v[NTASK], rv[NTASK];
-            unsigned off[NTASK];                        // element offset inside one sample's tensor (< 2^31)
-            int cos_[NTASK];
-#pragma unroll
-            for (int q = 0; q < NTASK; ++q) {
-                const int t = q * NTHR + tid;
-                const int row = t / NQ, quad = t & (NQ - 1);
-                v[q] = *reinterpret_cast<const f32x4*>(&S[row * NT + quad * 4]);
-                const int co = co0 + ((row >> 5) * TM + h) * 32 + (row & 31);
-                const int p = quad * 4;
-                const int ty = p >> twsh, tx = p & (TW - 1);
-                cos_[q] = co;
-                off[q] = (unsigned)co * (unsigned)out_plane + (unsigned)((oy0 + ty) * a.Wout + ox0 + tx);
-            }
-            if (rb || accu) {
-#pragma unroll
-                for (int q = 0; q < NTASK; ++q) {
-                    f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
-                    if (rb) t4 = *reinterpret_cast<const f32x4*>(rb + off[q]);
-                    if (accu) t4 += *reinterpret_cast<const f32x4*>(ob + off[q]);
-                    rv[q] = t4;
-                }
-#pragma unroll
-                for (int q = 0; q < NTASK; ++q) v[q] += rv[q];
-            }
-#pragma unroll
-            for (int q = 0; q < NTASK; ++q) {
-                float add = 0.f;
-                if (b1) add += b1[cos_[q]];
-                if (b2) add += b2[cos_[q]];
-                v[q] += add;
-                __builtin_nontemporal_store(v[q], reinterpret_cast<f32x4*>(ob + off[q]));   // streamed once: keep L2 for the shared primal cache / weights
-            }
-            // Forward GroupNorm statistics of the finished tile for the norm that consumes this tensor (kernels.h
-            // ConvArgs::st_part): the NQ lanes of a task row hold one cout over the tile's NT pixels; sums about a pivot
-            // inside the row's data (its first value in this tile: no cancellation of sum x^2 - n mean^2 when |mean| >> std),
-            // butterfly over the row's lanes, one lane writes {mean, M2} of the row tile.  (The tangent / cotangent means
-            // were tried here too: they need the {S, xhat} records of the output tile, 8 more bytes per element read in the
-            // latency-exposed epilogue -- 9-26 us per launch against the 16-21 us of the standalone pass, not adopted.)
-            if (a.st_kind == ST_FWD && !part) {
-                const int ntile = (a.Hout * a.Wout) / NT;
-                float* const sp = a.st_part + (long)b * a.Cout * ntile * 2;
-#pragma unroll
-                for (int q = 0; q < NTASK; ++q) {
-                    const float pivot = __shfl(v[q][0], lane & ~(NQ - 1) & 63, 64);
-                    const float d0 = v[q][0] - pivot, d1 = v[q][1] - pivot, d2 = v[q][2] - pivot, d3 = v[q][3] - pivot;
-                    float s1 = (d0 + d1) + (d2 + d3);
-                    float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-#pragma unroll
-                    for (int m = 1; m < (NQ < 64 ? NQ : 64); m <<= 1) {
-                        s1 += __shfl_xor(s1, m, 64);
-                        s2 += __shfl_xor(s2, m, 64);
-                    }
-                    const float m = s1 * (1.0f / NT);
-                    const int t = q * NTHR + tid;
-                    if ((t & (NQ - 1)) == 0)
-                        *reinterpret_cast<f32x2*>(sp + ((long)cos_[q] * ntile + tile_id) * 2) = f32x2{pivot + m, s2 - s1 * m};
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int p = (wn * TN + j) * 32 + l31;
-        int ty = p / TW, tx = p - ty * TW;
-        int oy = oy0 + ty, ox = ox0 + tx;
-        const unsigned pix = (unsigned)(oy * a.Wout + ox);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int cob = co0 + (wm * TM + i) * 32 + 4 * khalf;
-            if (a.nsplit > 1) {
-                float* pb = a.partial + (((long)split * a.B + b) * a.Cout) * out_plane;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int co = cob + (r & 3) + 8 * (r >> 2);
-                    if (full_co || co < a.Cout) pb[(long)co * out_plane + pix] = acc[i][j][r];
-                }
-            } else {
-                float* ob = a.out + (long)b * a.out_bs;
-                const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
-                const float* b2 = a.bias2 ? a.bias2 + (long)b * a.bias2_bs : nullptr;
-                if (rb || a.accumulate) {
-                    // The residual may alias the output (nin shortcut written in place), so the compiler cannot
-                    // move a residual load above the previous store: gather the 16 residual / accumulate values of
-                    // the tile first (each thread only touches its own elements), then add and store.
-                    float rv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int co = cob + (r & 3) + 8 * (r >> 2);
-                        const bool ok = full_co || co < a.Cout;
-                        const long off = (long)(ok ? co : a.Cout - 1) * out_plane + pix;
-                        float t = 0.f;
-                        if (rb) t = rb[off];
-                        if (a.accumulate) t += ob[off];
-                        rv[r] = t;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int co = cob + (r & 3) + 8 * (r >> 2);
-                        if (!(full_co || co < a.Cout)) continue;
-                        float v = acc[i][j][r] + rv[r];
-                        if (a.bias) v += a.bias[co];
-                        if (b2) v += b2[co];
-                        __builtin_nontemporal_store(v, &ob[(long)co * out_plane + pix]);   // streamed once: keep L2 for the shared primal cache / weights (2 ms per step)
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int co = cob + (r & 3) + 8 * (r >> 2);
-                        if (!(full_co || co < a.Cout)) continue;
-                        float v = acc[i][j][r];
-                        if (a.bias) v += a.bias[co];
-                        if (b2) v += b2[co];
-                        __builtin_nontemporal_store(v, &ob[(long)co * out_plane + pix]);   // streamed once: keep L2 for the shared primal cache / weights (2 ms per step)
-                    }
-                }
-            }
-        }
-    }
+    conv_lowp_epilogue<WM, WN, TM, TN>(a, acc, smem_b, co0, oy0, ox0, TW, tile_id, b, split);
 }
 
 // ---------------------------------------------------------------------------
@@ -1074,11 +1101,22 @@ static void launch_one_b(const ConvArgs& a, hipStream_t st) {
 
 int bf16_tile_of(const ConvArgs& a);     // conv_bf16.hip
 
+}  // namespace loco
+#include "conv_spec_kernel.h"
+namespace loco {
+
 template <int PR, int TAPS, int MODE>
 void launch_tile_b(const ConvArgs& a, hipStream_t st) {
     const int tile = bf16_tile_of(a);
     switch (tile) {
-        case 5: launch_one_b<PR, TAPS, 2, 4, 2, 2, MODE>(a, st); break;   // 128 x 256, 8 waves (64 x 64 each)
+        case 5:                                                           // 128 x 256, 8 compute waves (64 x 64 each)
+            if constexpr (TAPS == 9) {
+                // stride-1 convs on padded arena tensors: the role-split kernel (conv_spec_kernel.h; LOCO_CONV_SPEC=0 keeps
+                // every launch on the lock-step kernel below)
+                if (conv_lowp_uses_spec(a, TAPS)) { launch_conv_spec<PR, MODE>(a, st); break; }
+            }
+            launch_one_b<PR, TAPS, 2, 4, 2, 2, MODE>(a, st);
+            break;
         case 0: launch_one_b<PR, TAPS, 2, 2, 2, 2, MODE>(a, st); break;
         case 1: launch_one_b<PR, TAPS, 4, 1, 1, 2, MODE>(a, st); break;
         case 2: launch_one_b<PR, TAPS, 1, 4, 1, 1, MODE>(a, st); break;

@@ -2722,6 +2722,13 @@ int loco_mask_gather(loco_ctx* c, const float* U, int32_t k, float* out, void* s
     return 0;
 }
 
+int loco_clock_stamp(loco_ctx* c, uint64_t* out2, void* stream) {
+    if (!c || !out2) return -2;
+    launch_clock_stamp(reinterpret_cast<unsigned long long*>(out2), (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 double loco_unet_flops(loco_ctx* c) {
     if (!c) return 0.0;
     if (!c->finalized && finalize_params(c)) return 0.0;

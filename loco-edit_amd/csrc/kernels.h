@@ -85,6 +85,8 @@ void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st);
 // can a launch with these arguments feed a.st_part from its epilogue?  (whole cout tiles of the chosen variant, no split-K)
 bool conv_lowp_can_fuse_stats(const ConvArgs& a);
 int conv_bf16_tile_couts(const ConvArgs& a);
+// does the low-precision launch with these arguments run on the role-split kernel (conv_spec_kernel.h)?
+bool conv_lowp_uses_spec(const ConvArgs& a, int taps);
 int conv_pick_tile(int Cout, int HW);
 extern int g_bf16_tile_override;
 void launch_fill_random(float* p, long count, unsigned seed, float scale, hipStream_t st);
@@ -215,6 +217,7 @@ void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w
                  const float* add = nullptr,      // add[temb_ch]: conditioning embedding added to emb before the SiLU
                  const float* t_ptr = nullptr);   // non-null: read the timestep from device memory (graph replay)
 void launch_set_scalar(float* p, float v, hipStream_t st);
+void launch_clock_stamp(unsigned long long* out2, hipStream_t st);   // {s_memtime, s_memrealtime}
 void launch_temb_proj(const float* tact, int temb_ch, const float* w, const float* b, int cout,
                       float* out, hipStream_t st);
 // out[b][c][y][x] = sum of the 2x2 block of in[b][c][2y..][2x..]   (adjoint of nearest x2)

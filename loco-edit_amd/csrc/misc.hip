@@ -682,6 +682,16 @@ void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w
                        w0, b0, w1, b1, scratch, cos_first, add, t_ptr);
 }
 __global__ void set_scalar_kernel(float* p, float v) { *p = v; }
+// {shader-clock counter, 100 MHz wall counter} of the CU this one-lane launch lands on: two of these around a timed
+// region give the average shader clock the chip held over it (MI355X guide, DVFS give-back item 6), so a kernel time
+// taken on one box can be compared with another box's at the clock each of them ran at
+__global__ void clock_stamp_kernel(unsigned long long* out) {
+    out[0] = __builtin_amdgcn_s_memtime();
+    out[1] = __builtin_amdgcn_s_memrealtime();
+}
+void launch_clock_stamp(unsigned long long* out2, hipStream_t st) {
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, st, out2);
+}
 void launch_set_scalar(float* p, float v, hipStream_t st) {
     hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, p, v);
 }

@@ -28,7 +28,7 @@ SYMBOLS = [
     "loco_load_param", "loco_params_missing", "loco_unet_forward", "loco_ddim_step", "loco_sched_step",
     "loco_pmp_primal", "loco_pmp_set_second_mask", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
     "loco_convergence", "loco_convergence_rows", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
-    "loco_unet_flops", "loco_workspace_bytes", "loco_timer_start", "loco_timer_stop",
+    "loco_unet_flops", "loco_workspace_bytes", "loco_clock_stamp", "loco_timer_start", "loco_timer_stop",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision", "loco_set_streams",
     "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby", "loco_latent_sample",
 ]
@@ -87,6 +87,7 @@ def load_library():
     lib.loco_mask_gather.argtypes = [vp, vp, i32, vp, vp]
     lib.loco_mask_count.argtypes = [vp]
     lib.loco_mask_count.restype = i64
+    lib.loco_clock_stamp.argtypes = [vp, vp, vp]
     lib.loco_unet_flops.argtypes = [vp]
     lib.loco_unet_flops.restype = C.c_double
     lib.loco_workspace_bytes.argtypes = [vp]
@@ -404,6 +405,18 @@ class LocoEngine:
     # ---- introspection
     def version(self) -> str:
         return self.lib.loco_version().decode()
+
+    def clock_stamp(self) -> torch.Tensor:
+        """Enqueue a {s_memtime, s_memrealtime} stamp on the current stream; returns the device int64[2] it lands in."""
+        out = torch.zeros(2, device=self.device, dtype=torch.int64)
+        self._check(self.lib.loco_clock_stamp(self._ctx, _ptr(out), _stream()), "loco_clock_stamp")
+        return out
+
+    @staticmethod
+    def sclk_mhz(stamp0: torch.Tensor, stamp1: torch.Tensor) -> float:
+        """Average shader clock between two stamps (after a synchronize)."""
+        d = (stamp1 - stamp0).tolist()
+        return 100.0 * d[0] / max(d[1], 1)
 
     def unet_flops(self) -> float:
         return float(self.lib.loco_unet_flops(self._ctx))

@@ -250,10 +250,11 @@ def _ldm_spatial_transformer(p, name, x, context, cfg):
     BasicTransformerBlock, CrossAttention, FeedForward / GEGLU; un-vendored by the reference, which reaches it through
     diffusers' UNet2DConditionModel -- the same arithmetic under other parameter names), depth 1:
     GroupNorm(32, eps 1e-6) -> 1x1 proj_in -> tokens [B, HW, C] -> x + attn1(LN(x)); x + attn2(LN(x), context);
-    x + Linear(GEGLU(LN(x))) -> 1x1 proj_out -> + input.  Heads = cfg.num_heads, scale = head_dim^-1/2, to_q/k/v without
+    x + Linear(GEGLU(LN(x))) -> 1x1 proj_out -> + input.  Heads = cfg.num_heads (or C / cfg.num_head_channels), scale = head_dim^-1/2, to_q/k/v without
     bias, LayerNorm eps 1e-5, GEGLU: proj to 8C, value * gelu(gate) (erf form)."""
     b, c, hh, ww = x.shape
-    nh = cfg.num_heads
+    # v1: a fixed head count per block (num_heads = 8); 2.x: a fixed head width (num_head_channels = 64)
+    nh = cfg.num_heads if cfg.num_heads > 0 else c // cfg.num_head_channels
     d = c // nh
     h = F.group_norm(x, cfg.gn_groups, p[name + ".norm.weight"], p[name + ".norm.bias"], 1e-6)
     h = F.conv2d(h, p[name + ".proj_in.weight"], p[name + ".proj_in.bias"])

@@ -336,11 +336,18 @@ def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
     assert float(JV[:, ~mask.reshape(-1).to(DEV)].abs().max()) == 0.0 and op.dec.mask_count() == int(mask.sum())
     comb = op.jvp((V[0:1] * 0.5 - V[1:2] * 2.0).contiguous())
     assert rel(comb, JV[0:1] * 0.5 - JV[1:2] * 2.0) < 1e-3
-    u, s, vT = ed.local_encoder_decoder_pullback_zt(z, t, ed.edit_t_idx, F, E, N, pca_rank=3, min_iter=2, max_iter=2,
-                                                    mask=mask.to(DEV), mode="null+(for-null)", verbose=False)
-    assert u.shape == (int(mask.sum()), 3) and vT.shape == (3, 16384) and bool((s[:-1] >= s[1:]).all())
+    # ---- the workload bench.py times as `tloco_sd15`: top-5 basis, 12 power iterations (the reference's minimum);
+    # s_i against an independent product ||J v_i|| (the check config 5 carries), orthonormal descending rows
+    v0 = torch.randn(4 * 64 * 64, 5, generator=g).to(DEV)
+    u, s, vT = ed.local_encoder_decoder_pullback_zt(z, t, ed.edit_t_idx, F, E, N, pca_rank=5, min_iter=12, max_iter=12,
+                                                    mask=mask.to(DEV), mode="null+(for-null)", v0=v0, verbose=False)
+    assert ed.last_n_iter == 12 and u.shape == (int(mask.sum()), 5) and vT.shape == (5, 16384)
+    assert bool((s[:-1] >= s[1:] * (1 - 1e-5)).all()) and bool(torch.isfinite(vT).all())
     vd = vT.double()
-    assert (vd @ vd.T - torch.eye(3, device=DEV, dtype=torch.float64)).abs().max().item() < 2e-6
+    assert (vd @ vd.T - torch.eye(5, device=DEV, dtype=torch.float64)).abs().max().item() < 2e-6
+    nrm = op.jvp(vT.contiguous()).norm(dim=1)
+    print(f"SD15 12-iteration top-5 solve: s = {s.tolist()}, ||J v_i|| = {nrm.tolist()}")
+    assert torch.allclose(nrm.cpu(), s.cpu(), rtol=2e-2)
     del ed, op
     torch.cuda.empty_cache()
     # ---- finite difference of the decoded x0_hat along a probe, exact-fp32 engine
@@ -354,6 +361,61 @@ def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
         xm = ed.get_x0(z - h * v.view_as(z), t, ed.edit_t_idx, F, E, N, mask=None, mode="null+(for-null)")
         best = min(best, rel(((xp - xm) / (2 * h)).reshape(1, -1), jv))
     print(f"SD15 composed operator, finite difference vs J v (f32 engine): {best:.2e}")
+    assert best < 2.5e-2
+
+
+def test_stable_diffusion_2_1_base_denoiser_at_size():
+    """`config.SD21_BASE_UNET`, the architecture of the model id the shipped scripts name
+    (scripts/main_T2I_StableDiffusion_null_space_projection*.sh:4): 1024-wide prompt states, 64-channel heads at every level
+    (5 / 10 / 20 / 20 heads: all of them on the flash-attention kernels), nn.Linear proj_in / proj_out loaded as the 1x1
+    operator (865.9 M parameters, synthetic weights).  Forward at full size against the CPU restatement; J V / J^T U of the
+    raw network: adjointness, linearity, and J V against a central finite difference of the forward (exact-fp32 engine).
+    Parity against diffusers' weights stays unpinned (no diffusers, no weights)."""
+    from loco_edit_amd.checkpoints import ldm_to_hf_unet2d_condition, normalize_unet_state_dict
+    from loco_edit_amd.config import SD21_BASE_UNET
+    from loco_edit_amd.hip import LocoEngine
+    cfg = SD21_BASE_UNET
+    params = synth_params(cfg, 0)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(1, 4, 64, 64, generator=g)
+    ctx = torch.randn(77, 1024, generator=g)
+    t = 703.0
+    p = orc.to_torch(params)
+    with torch.no_grad():
+        ref = orc.unet_forward_adm(p, cfg, z, torch.tensor(t), context=ctx)
+    # the weights arrive the way a diffusers 2.x checkpoint stores them: UNet2DConditionModel names, Linear proj_in / proj_out
+    hf = ldm_to_hf_unet2d_condition(p, cfg)
+    hf = {k: (v[:, :, 0, 0] if k.endswith(("proj_in.weight", "proj_out.weight")) else v) for k, v in hf.items()}
+    del p
+    sd = normalize_unet_state_dict(hf, cfg)
+    eng = LocoEngine(cfg, max_batch=3, device=torch.device(DEV))
+    eng.load_state_dict(sd)
+    del sd, hf
+    eng.set_context(ctx.to(DEV).contiguous())
+    for prec in ("bf16x3", "f32"):
+        eng.set_precision(prec)
+        e = rel(eng.unet_forward(z.to(DEV), t), ref)
+        print(f"SD 2.1-base U-Net forward at size, {prec} vs CPU restatement: rel err {e:.2e}")
+        assert e < TOL[prec]
+    eng.set_precision("bf16x3")
+    eng.pmp_primal(z.to(DEV), t, 0.5, None, use_et=True)
+    V = torch.randn(3, cfg.n, generator=g).to(DEV)
+    U = torch.randn(3, cfg.n, generator=g).to(DEV)
+    JV, JtU = eng.pmp_jvp(V), eng.pmp_vjp(U)
+    lhs, rhs = (JV.double() * U.double()).sum(dim=1), (V.double() * JtU.double()).sum(dim=1)
+    assert ((lhs - rhs).abs() / (JV.norm(dim=1) * U.norm(dim=1)).double()).max().item() < 2e-4
+    comb = eng.pmp_jvp((V[0:1] * 0.5 - V[1:2] * 2.0).contiguous())
+    assert rel(comb, JV[0:1] * 0.5 - JV[1:2] * 2.0) < 1e-3
+    eng.set_precision("f32")
+    eng.pmp_primal(z.to(DEV), t, 0.5, None, use_et=True)
+    v = (V[0:1] / V[0:1].norm()).contiguous()
+    jv = eng.pmp_jvp(v)
+    best = 1.0
+    for h in (2e-2, 1e-2):
+        fp = eng.unet_forward((z.to(DEV) + h * v.view(1, 4, 64, 64)).contiguous(), t)
+        fm = eng.unet_forward((z.to(DEV) - h * v.view(1, 4, 64, 64)).contiguous(), t)
+        best = min(best, rel(((fp - fm) / (2 * h)).reshape(1, -1), jv))
+    print(f"SD 2.1-base denoiser, finite difference vs J v (f32 engine): {best:.2e}")
     assert best < 2.5e-2
 
 

@@ -763,6 +763,44 @@ def test_two_stream_probe_groups_match_single_stream(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["adm64", "ldm40"])
+def test_two_stream_probe_groups_on_the_flash_attention_path(which, monkeypatch):
+    """LOCO_STREAMS=2 on heads the flash kernels take (64-channel ADM heads at 1024 / 256 tokens, 40-channel
+    SpatialTransformer heads): the cotangent's delta_i = <g_o_i, o_i> scratch is indexed by the lane-local probe, so each
+    lane must own its samples' slots (engine.hip LaneSwap) -- with a shared scratch lane 1's second kernel reads lane 0's
+    deltas.  J V and J^T U of 6 probes (two lanes of 3) equal the single-stream engine, repeatedly (the race, when
+    present, is intermittent)."""
+    from loco_edit_amd.config import FLASH_ADM, FLASH_LDM
+    from loco_edit_amd.hip import LocoEngine
+    cfg = FLASH_ADM if which == "adm64" else FLASH_LDM
+    params = synth_params(cfg, 0)
+    gen = torch.Generator().manual_seed(29)
+    x = torch.randn(1, cfg.in_channels, cfg.resolution, cfg.resolution, generator=gen).to(DEV)
+    V = torch.randn(6, cfg.n, generator=gen).to(DEV)
+    Uc = torch.randn(6, cfg.n, generator=gen).to(DEV)
+    ctx = torch.randn(cfg.context_len, cfg.context_dim, generator=gen).to(DEV) if cfg.context_dim else None
+    out = {}
+    for ns in ("1", "2"):
+        monkeypatch.setenv("LOCO_STREAMS", ns)
+        eng = LocoEngine(cfg, max_batch=8, device=torch.device(DEV))
+        eng.load_state_dict(params)
+        eng.set_precision("bf16x3")
+        if ctx is not None:
+            eng.set_context(ctx.contiguous())
+        eng.pmp_primal(x, 603.0, 0.5, None, use_et=True)
+        res = []
+        for _ in range(4 if ns == "2" else 1):
+            U = eng.pmp_jvp(V)
+            A = eng.pmp_vjp(Uc)
+            torch.cuda.synchronize()
+            res.append((U.cpu(), A.cpu()))
+        out[ns] = res
+        del eng
+    for U2, A2 in out["2"]:
+        assert rel(U2, out["1"][0][0]) < 1e-5 and rel(A2, out["1"][0][1]) < 1e-5
+
+
+@pytest.mark.gpu
 def test_graph_replay_matches_eager(monkeypatch):
     """Denoiser evaluations replayed as HIP graphs (opt-in, LOCO_GRAPH=1) are bit-identical to the eager launch list
     (default): a DDIM chain with a changing timestep (read from device memory by the captured time-embedding
