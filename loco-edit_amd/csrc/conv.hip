@@ -356,6 +356,12 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
     if (prec && t == 4) t = 5;
     if (prec && a.stride == 2 && t == 5) t = 0;
     if (t < 0 || t > 5) t = 0;
+    if (prec && taps == 9 && a.Cin2 > 0) {
+        static char kn2[3][5][40];
+        const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;
+        if (!kn2[prec][mm][0]) snprintf(kn2[prec][mm], 40, "%s<2,4,2,2,%d>", prec == 1 ? "conv_kcat_bf16x3" : "conv_kcat_f16", mm);
+        return kn2[prec][mm];
+    }
     if (prec && conv_lowp_uses_spec(a, taps)) {
         static char sn[3][5][40];
         const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;

@@ -69,14 +69,27 @@ bool conv_lowp_uses_spec(const ConvArgs& a, int taps) {
     return conv_spec_enabled() && taps == 9 && bf16_tile_of(a) == 5 && a.stride == 1 && !a.upsample && !a.zins &&
            (a.Cin % BKC) == 0 && a.in_padded && a.pad == 1;
 }
+bool conv_lowp_can_kcat(const ConvArgs& a) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("LOCO_KCAT"); on = e ? (atoi(e) != 0) : 1; }
+    return on && a.Cin2 > 0 && a.nsplit == 1 && bf16_tile_of(a) == 5 && a.stride == 1 && !a.upsample && !a.zins && a.pad == 1 &&
+           (a.Cin % BKC) == 0 && (a.Cin2 % BKC) == 0 && a.in_padded && (a.mode == CM_GN_SILU || a.mode == CM_TAN_SILU);
+}
 // the epilogue statistics exist on the LDS-staged path of whole cout tiles (conv_bf16_kernel.h) and need the finished
 // sums, i.e. no split-K
 bool conv_lowp_can_fuse_stats(const ConvArgs& a) {
     return a.nsplit <= 1 && (a.Cout % conv_bf16_tile_couts(a)) == 0;
 }
 
+template <int PR, int MODE> void launch_kcat_b(const ConvArgs& a, hipStream_t st);   // conv_bf16_inst_*.hip
+
 template <int PR>
 static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
+    if (taps == 9 && a.Cin2 > 0) {       // the caller checked conv_lowp_can_kcat
+        if (a.mode == CM_GN_SILU) launch_kcat_b<PR, CM_GN_SILU>(a, st);
+        else launch_kcat_b<PR, CM_TAN_SILU>(a, st);
+        return;
+    }
     if (taps == 9) {
         switch (a.mode) {
             case CM_NONE: launch_tile_b<PR, 9, CM_NONE>(a, st); break;

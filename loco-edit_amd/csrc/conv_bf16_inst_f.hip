@@ -1,0 +1,7 @@
+// Explicit instantiations of the K-concatenated conv launcher (see conv_bf16_kernel.h).
+#include "conv_bf16_kernel.h"
+
+namespace loco {
+template void launch_kcat_b<PR_BF16X3, CM_GN_SILU>(const ConvArgs&, hipStream_t);
+template void launch_kcat_b<PR_BF16X3, CM_TAN_SILU>(const ConvArgs&, hipStream_t);
+}  // namespace loco

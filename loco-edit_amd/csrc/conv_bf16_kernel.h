@@ -279,8 +279,11 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
     }
 }
 
-template <int PR, int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
-__device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
+// PHASE 0: the whole kernel.  K-concatenated pair (ResBlock conv2 + its 1x1 shortcut on the block input, one accumulator
+// tile, one write-out): PHASE 1 = the first operator's stage loop only (accumulators zeroed, no epilogue), PHASE 2 = the
+// second operator's stage loop on top of the same accumulators, then the epilogue.
+template <int PR, int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG, int PHASE = 0>
+__device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[TM][TN]) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int HP = halo_pitch<PR>();
     constexpr int RB = rec_bytes<PR>();               // bytes of one operand record (16 k-values of one pixel / cout)
@@ -464,13 +467,14 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
         aoff_lo[i] = PR == PR_F16 ? 0 : rec_off<PR>(p, 2 + khalf);
     }
 
-    f32x16 acc[TM][TN];
+    if constexpr (PHASE != 2) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    }
 
     const int nchunks = (a.Cin + BKC - 1) / BKC;
     const int cps = __builtin_amdgcn_readfirstlane((nchunks + a.nsplit - 1) / a.nsplit);
@@ -1043,6 +1047,13 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
 
     }
 
+    if constexpr (PHASE == 1) {
+        // the second operator's prologue overwrites the operand buffers: every wave has left the last stage (its closing
+        // barrier); the fragment reads issued ahead for a stage that does not exist are retired here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
     conv_lowp_epilogue<WM, WN, TM, TN>(a, acc, smem_b, co0, oy0, ox0, TW, tile_id, b, split);
 }
 
@@ -1050,12 +1061,31 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a) {
 // Kernel entry points: one name per arithmetic so profiles tell them apart.
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
 __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
-    conv_lowp_body<PR_BF16X3, TAPS, WM, WN, TM, TN, MODE, STG>(a);
+    f32x16 acc[TM][TN];
+    conv_lowp_body<PR_BF16X3, TAPS, WM, WN, TM, TN, MODE, STG>(a, acc);
 }
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
 __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f16(ConvArgs a) {
-    conv_lowp_body<PR_F16, TAPS, WM, WN, TM, TN, MODE, STG>(a);
+    f32x16 acc[TM][TN];
+    conv_lowp_body<PR_F16, TAPS, WM, WN, TM, TN, MODE, STG>(a, acc);
 }
+
+// K-concatenated ResBlock tail: out = conv3x3(map(in)) + conv1x1(in2) + biases (+ residual): the 3x3 operator of `a` (vector
+// staging, MODE) and, on the same accumulator tile, the 1x1 operator {in2, Cin2, wb2} on the RAW block input (per-pixel
+// staging with the register ring) -- reference models/ddpm/diffusion.py:887-912 (`x = nin_shortcut(x); return x + h`): one
+// write-out instead of the shortcut's store and conv2's read-modify-write of the block output, one launch instead of two.
+template <int PR, int WM, int WN, int TM, int TN, int MODE>
+__device__ __forceinline__ void conv_lowp_kcat(const ConvArgs& a) {
+    f32x16 acc[TM][TN];
+    conv_lowp_body<PR, 9, WM, WN, TM, TN, MODE, 0, 1>(a, acc);
+    ConvArgs a2 = a;
+    a2.in = a.in2; a2.in_bs = a.in2_bs; a2.Cin = a.Cin2; a2.wb = a.wb2; a2.mode = CM_NONE; a2.pad = 0; a2.in_padded = a.in2_padded;
+    conv_lowp_body<PR, 1, WM, WN, TM, TN, CM_NONE, 1, 2>(a2, acc);
+}
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(WM * WN * 64) void conv_kcat_bf16x3(ConvArgs a) { conv_lowp_kcat<PR_BF16X3, WM, WN, TM, TN, MODE>(a); }
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(WM * WN * 64) void conv_kcat_f16(ConvArgs a) { conv_lowp_kcat<PR_F16, WM, WN, TM, TN, MODE>(a); }
 
 template <int PR, int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
 static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
@@ -1098,6 +1128,20 @@ static void launch_one_b(const ConvArgs& a, hipStream_t st) {
     launch_one_b2<PR, TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
 }
 
+
+template <int PR, int MODE>
+void launch_kcat_b(const ConvArgs& a, hipStream_t st) {
+    constexpr int WM = 2, WN = 4, TM = 2, TN = 2, MT = 128, NT = 256;
+    const int TW = a.Wout < 32 ? a.Wout : 32, TH = NT / TW;
+    // LDS of the 3x3 phase (three weight stages + two halo buffers); the 1x1 phase and the epilogue tile fit inside it
+    size_t lds = (size_t)3 * 3 * MT * rec_bytes<PR>() + 2 * ((size_t)(TW + 2) * (TH + 2) + NDUMMY) * halo_pitch<PR>();
+    dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
+    auto kern = PR == PR_F16 ? &conv_kcat_f16<WM, WN, TM, TN, MODE> : &conv_kcat_bf16x3<WM, WN, TM, TN, MODE>;
+    static DeviceOnce once;
+    if (first_on_device(once))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, a);
+}
 
 int bf16_tile_of(const ConvArgs& a);     // conv_bf16.hip
 

@@ -1197,7 +1197,31 @@ void stats_standalone(loco_ctx* c, const StatReq& rq, const float* x, long xbs, 
 }
 
 // run a conv with automatic split-K selection
-void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq* rq = nullptr) {
+// `second`: a prepared 1x1 operator on the same output tensor (the ResBlock shortcut, `second->out == a.out`) that `a` then
+// reads as its residual.  Where the launch allows it is K-concatenated into `a`'s kernel (conv_lowp_kcat: one write-out, no
+// read-modify-write of the block output, one launch less); otherwise it runs first and `a` takes its result as residual.
+void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq* rq = nullptr, ConvArgs* second = nullptr) {
+    if (second) {
+        const size_t span = (size_t)c->cfg.max_batch * c->per_sample;
+        ConvArgs t = a;
+        t.taps = taps;
+        t.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B) : 2;
+        t.in_padded = (a.in >= c->arenaP && a.in < c->arenaP + span) || (a.in >= c->arenaT && a.in < c->arenaT + span);
+        t.in2 = second->in; t.in2_bs = second->in_bs; t.Cin2 = second->Cin;
+        const long per_probe = (long)((a.Hout * a.Wout) / 256) * ((a.Cout + 127) / 128), total = per_probe * a.B;
+        const bool whole_rounds = total <= 256 || total % 256 == 0 || total % 256 > 160;      // no tail-probe split (below)
+        if (c->prec >= 1 && taps == 9 && whole_rounds && !a.bias2 && conv_lowp_can_kcat(t)) {
+            a.in2 = second->in; a.in2_bs = second->in_bs; a.Cin2 = second->Cin;
+            a.in2_padded = (second->in >= c->arenaP && second->in < c->arenaP + span) ||
+                           (second->in >= c->arenaT && second->in < c->arenaT + span);
+            a.wb2 = c->prec == 2 ? second->wh : second->wb;
+            a.bias2 = second->bias; a.bias2_bs = 0;          // the shortcut's bias (the forward pass; tangents carry none)
+            a.res = nullptr;
+        } else {
+            run_conv(c, *second, 1, st);
+            a.res = second->out; a.res_bs = second->out_bs;
+        }
+    }
     if (c->prec == 2) a.wb = a.wh;
     a.taps = taps;
     a.no_deep = c->deep1 ? 0 : 1;
@@ -1265,7 +1289,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
         loco_ctx::ProfRec r, rr;
         if (c->prof_on) {
             r.name = conv_variant_name(x, taps, c->prec);
-            r.flops = 2.0 * x.Cin * x.Cout * taps * (double)x.Hout * x.Wout * x.B;
+            r.flops = 2.0 * (x.Cin * taps + x.Cin2) * x.Cout * (double)x.Hout * x.Wout * x.B;
             if (x.zins) r.flops *= 0.25;     // algorithmic work of the stride-2 data gradient
             r.cin = x.Cin; r.cout = x.Cout; r.h = x.Hout; r.b = x.B; r.ns = x.nsplit; r.mode = x.mode; r.taps = taps;
             r.e0 = c->next_event(); r.e1 = c->next_event();
@@ -1581,22 +1605,19 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 }
                 NS s2 = nstats(c, stats, op.n2);
                 const float* xin = op.updown ? p.T(op.xu) : p.T(op.in);   // shortcut input after x_upd
-                const float* res = xin;
+                ConvArgs n; conv_defaults(n);                             // the 1x1 shortcut (diffusion.py:887-912), if any
                 if (op.has_nin) {
-                    ConvArgs n; conv_defaults(n);
                     n.in = xin; n.in_bs = p.bs(); n.Cin = ti.C; n.Hin = to.H; n.Win = to.W;
                     setw(n, op.nin, false); n.bias = op.nin.bias; n.pad = 0;
                     n.out = p.T(op.out); n.out_bs = p.bs(); n.Cout = to.C; n.Hout = to.H; n.Wout = to.W; n.B = B;
-                    run_conv(c, n, 1, st);
-                    res = p.T(op.out);
                 }
                 ConvArgs b; conv_defaults(b);
                 b.in = p.T(op.h1); b.in_bs = p.bs(); b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
-                setw(b, op.c2, false); b.bias = op.c2.bias; b.res = res; b.res_bs = p.bs();
+                setw(b, op.c2, false); b.bias = op.c2.bias; b.res = xin; b.res_bs = p.bs();
                 b.mode = CM_GN_SILU; b.sc = s2.sc; b.sh = s2.sh; b.scsh_bs = SB;
                 b.out = p.T(op.out); b.out_bs = p.bs(); b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
                 const StatReq rq = next_fwd(op.out);
-                run_conv(c, b, 9, st, &rq);
+                run_conv(c, b, 9, st, &rq, op.has_nin ? &n : nullptr);     // shortcut K-concatenated, or run first as the residual
                 break;
             }
             case OP_ATTN: {
@@ -1814,22 +1835,19 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                     op.n2.ready = false;
                 }
                 const float* xin = op.updown ? TT(op.xu) : TT(op.in);
-                const float* res = xin;
+                ConvArgs n; conv_defaults(n);
                 if (op.has_nin) {
-                    ConvArgs n; conv_defaults(n);
                     n.in = xin; n.in_bs = PS; n.Cin = ti.C; n.Hin = to.H; n.Win = to.W;
                     setw(n, op.nin, false); n.pad = 0;
                     n.out = TT(op.out); n.out_bs = PS; n.Cout = to.C; n.Hout = to.H; n.Wout = to.W; n.B = B;
-                    run_conv(c, n, 1, st);
-                    res = TT(op.out);
                 }
                 ConvArgs b; conv_defaults(b);
                 b.in = TT(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
-                setw(b, op.c2, false); b.res = res; b.res_bs = PS;
+                setw(b, op.c2, false); b.res = xin; b.res_bs = PS;
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.out = TT(op.out); b.out_bs = PS; b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
                 const StatReq rq = next_tan(op.out);
-                run_conv(c, b, 9, st, &rq);
+                run_conv(c, b, 9, st, &rq, op.has_nin ? &n : nullptr);
                 break;
             }
             case OP_ATTN: {

@@ -75,6 +75,10 @@ struct ConvArgs {
     int B;
     // forward-statistics sink (st_kind == ST_FWD): {mean, M2} per (cout row, pixel tile), [B][Cout][pixel tiles][2]
     float* st_part; int st_kind;
+    // K-concatenated second operator (conv_bf16_kernel.h conv_lowp_kcat): a 1x1 conv of the RAW tensor in2 [B][Cin2][Hout][Wout]
+    // accumulated into the same output tile; its bias travels in `bias2` (bias2_bs = 0).  Cin2 == 0: none.
+    const float* in2; long in2_bs; int Cin2; int in2_padded;
+    const void* wb2;
 };
 
 // the conv kernel only; when a.nsplit > 1 the caller follows with launch_conv_splitk_reduce (run_conv does)
@@ -87,6 +91,9 @@ bool conv_lowp_can_fuse_stats(const ConvArgs& a);
 int conv_bf16_tile_couts(const ConvArgs& a);
 // does the low-precision launch with these arguments run on the role-split kernel (conv_spec_kernel.h)?
 bool conv_lowp_uses_spec(const ConvArgs& a, int taps);
+// can the low-precision launch `a` (3x3, its split-K factor already chosen) carry the 1x1 operator a.in2 / a.Cin2 / a.wb2 in the
+// same kernel?  (128 x 256 tiles, stride 1, whole 16-channel chunks of both inputs, no split-K)
+bool conv_lowp_can_kcat(const ConvArgs& a);
 int conv_pick_tile(int Cout, int HW);
 extern int g_bf16_tile_override;
 void launch_fill_random(float* p, long count, unsigned seed, float scale, hipStream_t st);
