@@ -43,6 +43,12 @@ namespace {
 struct Tens {
     long off; int C, H, W;
     int cons_op = -1, cons_norm = 0;   // op whose norm (1: n1, 2: nx) takes its statistics over exactly this tensor, or -1
+    // channel concatenation [cat_a | cat_b] consumed by a norm (the up-path ResBlocks read torch.cat([h, skip])): the two
+    // parts are tensors of their own, each written by its own conv.  A part keeps the {mean, M2} tile partials its producer's
+    // epilogue took (keep, keep_ntile > 0 in the forward pass that wrote them) so the norm over the concatenation can be
+    // finalised from both parts' partials instead of re-reading the tensor (gn_fused_finalize_cat_kernel).
+    int cat_a = -1, cat_b = -1, cat_of = -1;
+    float* keep = nullptr; size_t keep_floats = 0; int keep_ntile = 0;
 };
 
 struct ConvP {       // one convolution's parameters in kernel layouts
@@ -1178,6 +1184,9 @@ struct StatReq {
     float* stats = nullptr;                   // stats arena receiving the result (FWD: this pass's; TAN / COT: statsT)
     const float* prim = nullptr;              // primal of the conv's output tensor, B = 1 (TAN / COT)
     const float* ss_scale = nullptr; const float* ss_shift = nullptr;   // FWD: scale-shift norm (ADM)
+    // FWD, output tensor is one part of a concatenation: its tile partials go to (and stay in) `keep`; *keep_ntile receives
+    // the tile count, 0 when this launch could not take them.  n may be nullptr (no norm over the part alone).
+    float* keep = nullptr; size_t keep_floats = 0; int* keep_ntile = nullptr;
 };
 
 void stats_standalone(loco_ctx* c, const StatReq& rq, const float* x, long xbs, int B, int HW, int s0, hipStream_t st) {
@@ -1258,19 +1267,23 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     const int HWo = a.Hout * a.Wout, Gn = c->cfg.gn_groups;
     const long SBs = c->stats_per_sample;
     // statistics of samples [s0, s0 + x.B) of the launch `x`, by the cheapest route that applies
-    auto stats_of = [&](ConvArgs& x, int s0) -> int {      // 0: none asked; 1: in the conv epilogue; 2: in the split-K epilogue; 3: standalone
+    auto stats_of = [&](ConvArgs& x, int s0) -> int {      // 0: none asked; 1: in the conv epilogue; 2: in the split-K epilogue; 3: standalone; 4: partials only
         if (!rq || rq->kind == ST_NONE) return 0;
-        if (!want) return 3;
-        if (x.nsplit > 1) return (HWo % 4 == 0) ? 2 : 3;
-        const size_t need = (size_t)x.B * x.Cout * (HWo / conv_bf16_tile_pixels(x)) * 2;
-        if (rq->kind == ST_FWD && conv_lowp_can_fuse_stats(x) && need <= c->stpart_floats) {
-            x.st_part = c->stpart; x.st_kind = ST_FWD;
-            return 1;
+        if (rq->keep_ntile) *rq->keep_ntile = 0;
+        if (!want) return rq->n ? 3 : 0;
+        if (x.nsplit > 1) return !rq->n ? 0 : ((HWo % 4 == 0) ? 2 : 3);
+        const int ntile = HWo / conv_bf16_tile_pixels(x);
+        const size_t need = (size_t)x.B * x.Cout * ntile * 2;
+        const bool kept = rq->keep && s0 == 0 && x.B == a.B && need <= rq->keep_floats;      // the whole batch in one launch
+        if (rq->kind == ST_FWD && conv_lowp_can_fuse_stats(x) && (kept || (rq->n && need <= c->stpart_floats))) {
+            x.st_part = kept ? rq->keep : c->stpart; x.st_kind = ST_FWD;
+            if (kept) *rq->keep_ntile = ntile;
+            return rq->n ? 1 : 4;
         }
-        return 3;
+        return rq->n ? 3 : 0;
     };
     auto stats_after = [&](const ConvArgs& x, int s0, int how) {
-        if (how == 0 || how == 2) return;
+        if (how == 0 || how == 2 || how == 4) return;
         const NormP& n = *rq->n;
         if (how == 3) { stats_standalone(c, *rq, x.out, x.out_bs, x.B, HWo, s0, st); return; }
         NS so = nstats(c, rq->stats + (long)s0 * SBs, n);
@@ -1310,11 +1323,12 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
         }
         stats_after(x, s0, how);
     };
-    if (rq && rq->kind != ST_NONE) rq->n->ready = true;
+    if (rq && rq->kind != ST_NONE && rq->n) rq->n->ready = true;
     if (!tail_probes) { one(a, 0); return; }
     // tail-probe split: two launches finish the tensor; their statistics are taken once over the whole batch behind them
     // (separate statistics for the few tail probes would add a reduce-with-statistics and a finalize launch per conv)
-    const StatReq* rq_all = (rq && rq->kind != ST_NONE) ? rq : nullptr;
+    const StatReq* rq_all = (rq && rq->kind != ST_NONE && rq->n) ? rq : nullptr;
+    if (rq && rq->keep_ntile) *rq->keep_ntile = 0;
     rq = nullptr;
     ConvArgs m = a, t = a;
     const int nb = a.B - tail_probes;
@@ -1358,6 +1372,31 @@ StatReq req_lin(loco_ctx* c, int kind, NormP* n, const float* prim) {       // t
 }
 void clear_ready(loco_ctx* c) {
     for (auto& op : c->ops) op.n1.ready = op.n2.ready = op.nx.ready = false;
+    for (auto& t : c->tens) t.keep_ntile = 0;
+}
+// forward statistics for the consumer of tensor `tid` and / or, when `tid` is one part of a concatenation, its tile partials
+StatReq req_fwd_of(loco_ctx* c, int tid, float* stats) {
+    StatReq r = req_fwd(consumer_norm(c, tid), stats);
+    Tens& t = c->tens[tid];
+    if (t.cat_of >= 0 && t.keep) {
+        r.kind = ST_FWD; r.stats = stats;
+        r.keep = t.keep; r.keep_floats = t.keep_floats; r.keep_ntile = &t.keep_ntile;
+    }
+    return r;
+}
+// norm over a concatenation whose two parts both kept their producers' tile partials in this pass: finalise from those
+bool cat_fused_stats(loco_ctx* c, const NormP& n, int tid, float* stats, int B, hipStream_t st) {
+    const Tens& q = c->tens[tid];
+    static int on = -1;                      // LOCO_FUSE_CAT=0: A/B switch (the parts' partials are still taken, not used)
+    if (on < 0) { const char* e = getenv("LOCO_FUSE_CAT"); on = e ? (atoi(e) != 0) : 1; }
+    if (q.cat_a < 0 || c->prec < 1 || !c->fuse_stats || !on) return false;
+    const Tens& A = c->tens[q.cat_a];
+    const Tens& Bt = c->tens[q.cat_b];
+    if (A.keep_ntile <= 0 || Bt.keep_ntile <= 0) return false;
+    NS s = nstats(c, stats, n);
+    launch_gn_fused_finalize_cat(A.keep, A.C, A.keep_ntile, Bt.keep, Bt.keep_ntile, B, q.C, q.H * q.W, c->cfg.gn_groups,
+                                 eps_of(c, n), n.gamma, n.beta, s.mr, s.sc, s.sh, c->stats_per_sample, st);
+    return true;
 }
 
 void gn_forward_stats(const Pass& p, const NormP& n, const float* x, long xbs, int HW) {
@@ -1540,7 +1579,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
     Pass p{c, st, B, arena, stats};
     const long SB = c->stats_per_sample;
     clear_ready(c);
-    auto next_fwd = [&](int tid) { return req_fwd(consumer_norm(c, tid), stats); };   // forward statistics for the consumer of `tid`
+    auto next_fwd = [&](int tid) { return req_fwd_of(c, tid, stats); };   // forward statistics for the consumer of `tid` (+ kept partials of a concatenation part)
     if (cfg.arch < 2) {
         launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st, cfg.arch == 1,
                     c->has_cond ? c->cond_add : nullptr, t_ptr);
@@ -1574,7 +1613,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
             case OP_RES: {
                 const Tens& ti = c->tens[op.in];
                 const int HWi = ti.H * ti.W;
-                if (!op.n1.ready) gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HWi);
+                if (!op.n1.ready && !cat_fused_stats(c, op.n1, op.in, stats, B, st)) gn_forward_stats(p, op.n1, p.T(op.in), p.bs(), HWi);
                 op.n1.ready = false;
                 NS s1 = nstats(c, stats, op.n1);
                 ConvArgs a; conv_defaults(a);
@@ -2341,6 +2380,26 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         }
         if (op.kind == OP_ATTN && op.has_x) { c->tens[op.xmid].cons_op = (int)i; c->tens[op.xmid].cons_norm = 2; }
     }
+    // concatenations consumed by a norm: Q = [P1 | P2] with P1, P2 tensors of their own inside Q's storage
+    for (size_t q = 0; q < c->tens.size(); ++q) {
+        Tens& Q = c->tens[q];
+        if (Q.cons_op < 0) continue;
+        int p1 = -1, p2 = -1;
+        for (size_t i = 0; i < c->tens.size(); ++i) {
+            const Tens& P = c->tens[i];
+            if (i == q || P.H != Q.H || P.W != Q.W || P.C >= Q.C) continue;
+            if (P.off == Q.off) p1 = (int)i;
+        }
+        if (p1 < 0) continue;
+        for (size_t i = 0; i < c->tens.size(); ++i) {
+            const Tens& P = c->tens[i];
+            if (i != q && P.H == Q.H && P.W == Q.W && P.C == Q.C - c->tens[p1].C &&
+                P.off == Q.off + (long)c->tens[p1].C * Q.H * Q.W) p2 = (int)i;
+        }
+        if (p2 < 0) continue;
+        Q.cat_a = p1; Q.cat_b = p2;
+        c->tens[p1].cat_of = (int)q; c->tens[p2].cat_of = (int)q;
+    }
     declare_all(c);
     const size_t MB = (size_t)cfg->max_batch;
     {   // 64-float guard bands: the vector halo loads of the convs may touch 1 float before / 3 after a tensor
@@ -2355,6 +2414,11 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         for (const Tens& t : c->tens) big = std::max(big, (long)t.C * t.H * t.W);
         c->stpart_floats = MB * (size_t)(big / 64 + 1) * 2;
         if (dalloc(c, &c->stpart, c->stpart_floats) || dalloc(c, &c->stpart2, c->stpart_floats)) return -1;
+        for (Tens& t : c->tens)          // kept tile partials of the concatenation parts: [B][C][<= HW / 64 tiles][2]
+            if (t.cat_of >= 0) {
+                t.keep_floats = MB * (size_t)t.C * ((size_t)t.H * t.W / 64 + 1) * 2;
+                if (dalloc(c, &t.keep, t.keep_floats)) return -1;
+            }
         const char* e = getenv("LOCO_FUSE_STATS");
         c->fuse_stats = !(e && atoi(e) == 0);
         e = getenv("LOCO_DEEP1");

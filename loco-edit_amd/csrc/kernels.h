@@ -180,6 +180,9 @@ void launch_gn_stats(const float* x, long bs, int B, int C, int HW, int G, float
                      float* mr, float* sc, float* sh, long stats_bs, double* scratch, hipStream_t st,
                      const float* ss_scale = nullptr, const float* ss_shift = nullptr);
 // row-tile partials of a conv epilogue (ConvArgs::st_part, [B][C][ntile]{mean, M2}) -> the arrays of launch_gn_stats
+void launch_gn_fused_finalize_cat(const float* partA, int C1, int ntA, const float* partB, int ntB, int B, int C, int HW, int G,
+                                  float eps, const float* gamma, const float* beta, float* mr, float* sc, float* sh,
+                                  long stats_bs, hipStream_t st);
 void launch_gn_fused_finalize(const float* part, int ntile, int B, int C, int HW, int G, float eps, const float* gamma,
                               const float* beta, float* mr, float* sc, float* sh, long stats_bs, const float* ss_scale,
                               const float* ss_shift, hipStream_t st);

@@ -293,6 +293,57 @@ __global__ __launch_bounds__(64) void gn_fused_finalize_kernel(const float* part
     }
 }
 
+// The same for a norm over the channel concatenation [A (C1 channels) | B (C - C1)] of two tensors whose producers each left
+// their own {mean, M2} tile partials (the up-path ResBlocks' norm1 over torch.cat([h, skip]), diffusion.py:182-190): a group's
+// channels come from one part or from both, the parts may have been written with different tile sizes (weights n_a, n_b).
+__global__ __launch_bounds__(64) void gn_fused_finalize_cat_kernel(const float* partA, int C1, int ntA, const float* partB, int ntB,
+                                                                   int C, int G, int HW, float eps, const float* gamma,
+                                                                   const float* beta, float* mr, float* sc, float* sh, long sbs) {
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / G, C2 = C - C1;
+    const double nA = (double)HW / ntA, nB = (double)HW / ntB;            // elements per tile partial
+    const float2* pa = reinterpret_cast<const float2*>(partA) + (long)b * C1 * ntA;
+    const float2* pb = reinterpret_cast<const float2*>(partB) + (long)b * C2 * ntB;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+        const int c = g * cpg + k;
+        const float2* p = c < C1 ? pa + (long)c * ntA : pb + (long)(c - C1) * ntB;
+        const int nt = c < C1 ? ntA : ntB;
+        const double w = c < C1 ? nA : nB;
+        for (int i = threadIdx.x; i < nt; i += 64) { const float2 v = p[i]; s1 += w * (double)v.x; s2 += (double)v.y; }
+    }
+    s1 = __shfl(wave_sum(s1), 0, 64);
+    s2 = __shfl(wave_sum(s2), 0, 64);
+    const double n = (double)cpg * HW, mean = s1 / n;
+    double dev = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+        const int c = g * cpg + k;
+        const float2* p = c < C1 ? pa + (long)c * ntA : pb + (long)(c - C1) * ntB;
+        const int nt = c < C1 ? ntA : ntB;
+        const double w = c < C1 ? nA : nB;
+        for (int i = threadIdx.x; i < nt; i += 64) { const double d = (double)p[i].x - mean; dev += w * d * d; }
+    }
+    dev = __shfl(wave_sum(dev), 0, 64);
+    double var = (s2 + dev) / n;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        mr[(long)b * sbs + g * 2] = meanf;
+        mr[(long)b * sbs + g * 2 + 1] = rstd;
+    }
+    for (int k = threadIdx.x; k < cpg; k += 64) {
+        const int c = g * cpg + k;
+        const float gm = gamma[c];
+        sc[(long)b * sbs + c] = gm * rstd;
+        sh[(long)b * sbs + c] = beta[c] - meanf * rstd * gm;
+    }
+}
+void launch_gn_fused_finalize_cat(const float* partA, int C1, int ntA, const float* partB, int ntB, int B, int C, int HW, int G,
+                                  float eps, const float* gamma, const float* beta, float* mr, float* sc, float* sh,
+                                  long stats_bs, hipStream_t st) {
+    hipLaunchKernelGGL(gn_fused_finalize_cat_kernel, dim3(G, B), dim3(64), 0, st, partA, C1, ntA, partB, ntB, C, G, HW, eps,
+                       gamma, beta, mr, sc, sh, stats_bs);
+}
+
 void launch_gn_fused_finalize(const float* part, int ntile, int B, int C, int HW, int G, float eps, const float* gamma,
                               const float* beta, float* mr, float* sc, float* sh, long stats_bs, const float* ss_scale,
                               const float* ss_shift, hipStream_t st) {
