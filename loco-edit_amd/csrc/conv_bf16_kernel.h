@@ -182,6 +182,30 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
 #pragma unroll
                 for (int q = 0; q < NTASK; ++q) v[q] += rv[q];
             }
+            if (a.cot_d && !part) {
+                // norm-cotangent term of the tensor this conv finishes (kernels.h ConvArgs::cot_d): a task row is one channel,
+                // its constants are wave-uniform per group of NQ lanes
+                const float* const db = a.cot_d + (long)b * a.cot_d_bs;
+                const float* const tb = a.cot_tst + (long)b * a.cot_tst_bs;
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    const int co = cos_[q], g = co / a.cot_cpg;
+                    const float scc = a.cot_sc[co], shc = a.cot_sh[co];
+                    const float mean = a.cot_mr[2 * g], rstd = a.cot_mr[2 * g + 1];
+                    const float m1 = tb[2 * g], m2 = tb[2 * g + 1];
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(db + off[q]);
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.cot_x + off[q]);
+                    const float gm = scc / rstd;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float y = fmaf(scc, xv[j], shc);
+                        const float sg = 1.0f / (1.0f + __expf(-y));
+                        const float ds = sg * (1.0f + y * (1.0f - sg));               // silu'(y)
+                        const float xh = (xv[j] - mean) * rstd;
+                        v[q][j] += rstd * (gm * ds * dv[j] - m1 - xh * m2);
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NTASK; ++q) {
                 float add = 0.f;

@@ -132,6 +132,7 @@ struct loco_ctx {
     float *arenaP = nullptr, *arenaT = nullptr;
     float *statsP = nullptr, *statsT = nullptr;
     double* red = nullptr;         // reduction scratch (doubles)
+    bool fuse_cot = true;          // norm-cotangent term in the shortcut conv's epilogue (LOCO_FUSE_COT=0: standalone gn_apply pass)
     float *stpart = nullptr, *stpart2 = nullptr;   // row partials of the statistics taken in conv epilogues (lane 0 / lane 1)
     size_t stpart_floats = 0;
     bool fuse_stats = true;        // LOCO_FUSE_STATS=0: every statistics pass as its own kernels (A/B timing)
@@ -2127,17 +2128,34 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 int acc = op.in_is_skip ? 1 : 0;
                 // shortcut cotangent at the block's output resolution: identity or nin^T
                 const float* gsk = TG(op.out);
+                bool cot_in_epilogue = false;
                 if (op.has_nin) {
                     ConvArgs n; conv_defaults(n);
                     n.in = TG(op.out); n.in_bs = PS; n.Cin = to.C; n.Hin = to.H; n.Win = to.W;
                     setw(n, op.nin, true); n.pad = 0;
                     n.Cout = ti.C; n.Hout = to.H; n.Wout = to.W; n.B = B; n.out_bs = PS;
                     n.out = TG(op.in); n.accumulate = acc;      // (resampling blocks never change channels: no nin there)
+                    if (op.updown == 0 && c->prec >= 1 && c->fuse_cot) {
+                        // g_in = nin^T g_out + norm1^T g_a1: the norm-cotangent term in the shortcut conv's epilogue instead of
+                        // a read-modify-write pass of gn_apply_kernel<2> over g_in -- one unsplit launch of whole cout tiles only
+                        ConvArgs t = n;
+                        t.taps = 1;
+                        t.nsplit = conv_bf16_pick_nsplit(n.Cin, n.Cout, n.Hout, n.Wout, n.B);
+                        const long per_probe = (long)((n.Hout * n.Wout) / conv_bf16_tile_pixels(t)) * ((n.Cout + 127) / 128);
+                        const long total = per_probe * n.B, r = total % 256;
+                        if (t.nsplit == 1 && (total <= 256 || r == 0 || r > 160) && conv_lowp_can_fuse_stats(t)) {
+                            n.cot_d = TG(op.a1); n.cot_d_bs = PS; n.cot_x = TP(op.in);
+                            n.cot_sc = sp.sc; n.cot_sh = sp.sh; n.cot_mr = sp.mr;
+                            n.cot_tst = stt.tst; n.cot_tst_bs = c->stats_per_sample; n.cot_cpg = ti.C / G;
+                            cot_in_epilogue = true;
+                        }
+                    }
                     run_conv(c, n, 1, st);
                     gsk = nullptr;
                 }
                 if (op.updown == 0) {
-                    if (op.has_nin)
+                    if (cot_in_epilogue) { /* done by the shortcut conv */ }
+                    else if (op.has_nin)
                         launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 1, B, ti.C, HWi, G,
                                         sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
                     else
@@ -2421,6 +2439,8 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
             }
         const char* e = getenv("LOCO_FUSE_STATS");
         c->fuse_stats = !(e && atoi(e) == 0);
+        e = getenv("LOCO_FUSE_COT");
+        c->fuse_cot = !(e && atoi(e) == 0);
         e = getenv("LOCO_DEEP1");
         c->deep1 = !(e && atoi(e) == 0);
         e = getenv("LOCO_FUSE_XATTN");

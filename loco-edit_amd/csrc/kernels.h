@@ -79,6 +79,13 @@ struct ConvArgs {
     // accumulated into the same output tile; its bias travels in `bias2` (bias2_bs = 0).  Cin2 == 0: none.
     const float* in2; long in2_bs; int Cin2; int in2_padded;
     const void* wb2;
+    // Norm-cotangent term added in the epilogue (conv_lowp_epilogue, whole cout tiles, no split-K): the cotangent of a
+    // GroupNorm + SiLU whose INPUT is this conv's output tensor,  out += rstd * ((sc / rstd) silu'(sc x + sh) d - m1 - xhat m2)
+    // with d = cot_d (cotangent behind the norm, [B][Cout][H][W]), x = cot_x (primal input of the norm, B = 1), per-channel
+    // cot_sc / cot_sh, per-group {mean, rstd} cot_mr and {m1, m2} cot_tst -- what gn_apply_kernel<2> computes as its own
+    // pass over the tensor (ResBlock cotangent: g_in = nin^T g_out + norm1^T g_a1 in one write-out).  nullptr: none.
+    const float* cot_d; long cot_d_bs; const float* cot_x;
+    const float* cot_sc; const float* cot_sh; const float* cot_mr; const float* cot_tst; long cot_tst_bs; int cot_cpg;
 };
 
 // the conv kernel only; when a.nsplit > 1 the caller follows with launch_conv_splitk_reduce (run_conv does)
