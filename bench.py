@@ -542,10 +542,10 @@ def main():
             # the same solve with the probe groups of a pass on two HIP streams (loco_set_streams): statistics / apply kernels
             # of one group beside the convolutions of the other.  An extra line, not the headline: kernels that overlap
             # have no per-kernel duration, so the roofline above is taken on one stream
-            eng.set_streams(2)
+            n_st = eng.set_streams_measured(2)      # side stream picked by measurement (loco_set_side_stream): not queue luck
             el, (_, s2, vT2, _) = timed(w["step"], 2, 1)
             eng.set_streams(1)
-            extra["celeba_top5_two_streams"] = {"value": round(keep / (el / 2), 4), "unit": "edit-directions/s",
+            extra["celeba_top5_two_streams"] = {"value": round(keep / (el / 2), 4), "unit": "edit-directions/s", "streams": n_st,
                                                 "ms_per_step": round(el / 2 * 1e3, 3), "dtype": DTYPE_NOTE[a.precision],
                                                 "parity": parity_vs_fixture(s2, vT2, "celeba256")}
         # BASELINE config 5 next to the headline: T-LOCO null-space basis on the IF-shaped stand-in, 2 CFG branches

@@ -207,6 +207,11 @@ int  loco_set_precision(loco_ctx* ctx, int32_t mode);
  * value.  Per-kernel durations measured while two streams overlap are not kernel properties: bench.py keeps n = 1 for
  * the headline and its roofline, and reports n = 2 as an extra line. */
 int  loco_set_streams(loco_ctx* ctx, int32_t n);
+/* The second stream of the n = 2 mode, supplied by the caller (nullptr: the context's own).  HIP hands hardware queues out
+ * round-robin over a few (GPU_MAX_HW_QUEUES, 4 by default): a stream created by the library may land on the queue of the
+ * caller's stream and then runs strictly behind it -- same results, no overlap.  The host can measure which of its streams
+ * runs beside its current one (loco_edit_amd.tloco.BranchStreams._pick: two spin kernels) and hand that one over. */
+int  loco_set_side_stream(loco_ctx* ctx, void* stream);
 int  loco_get_precision(loco_ctx* ctx);
 
 /* Conditional denoisers (T-LOCO, reference edit.py:1286-1373 `self.unet(x, t, encoder_hidden_states=...)`): a

@@ -180,7 +180,8 @@ struct loco_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second lane (probe groups of one tangent / cotangent pass on two streams, see run_lanes)
     int n_streams = 1;
-    hipStream_t st2 = nullptr;
+    hipStream_t st2 = nullptr;       // the context's own second stream
+    hipStream_t st2_user = nullptr;  // caller-supplied second stream (loco_set_side_stream): used instead of st2 when set
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double* red2 = nullptr;
     // B = 1..max_batch denoiser evaluations replayed as HIP graphs (loco_unet_forward / loco_ddim_step): the DDIM
@@ -2341,13 +2342,14 @@ int run_lanes(loco_ctx* c, int B, hipStream_t st, F body) {      // body(first s
     int rc = body(0, nA, st);
     c->partial_floats = pf;
     if (rc) return rc;
-    HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+    hipStream_t s2 = c->st2_user ? c->st2_user : c->st2;
+    HIPCHK(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
     {
         LaneSwap sw(c, nA);
-        rc = body(nA, B - nA, c->st2);
+        rc = body(nA, B - nA, s2);
     }
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_join, c->st2));
+    HIPCHK(c, hipEventRecord(c->ev_join, s2));
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
     return 0;
 }
@@ -2991,6 +2993,12 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
 int loco_set_streams(loco_ctx* c, int32_t n) {
     if (!c || (n != 1 && n != 2)) return -2;
     c->n_streams = n;
+    return 0;
+}
+
+int loco_set_side_stream(loco_ctx* c, void* stream) {
+    if (!c) return -2;
+    c->st2_user = (hipStream_t)stream;          // nullptr: back to the context's own stream
     return 0;
 }
 

@@ -28,7 +28,7 @@ SYMBOLS = [
     "loco_load_param", "loco_params_missing", "loco_unet_forward", "loco_ddim_step", "loco_sched_step",
     "loco_pmp_primal", "loco_pmp_set_second_mask", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
     "loco_convergence", "loco_convergence_rows", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
-    "loco_unet_flops", "loco_workspace_bytes", "loco_clock_stamp", "loco_timer_start", "loco_timer_stop",
+    "loco_unet_flops", "loco_workspace_bytes", "loco_clock_stamp", "loco_set_side_stream", "loco_timer_start", "loco_timer_stop",
     "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision", "loco_set_streams",
     "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby", "loco_latent_sample",
 ]
@@ -88,6 +88,7 @@ def load_library():
     lib.loco_mask_count.argtypes = [vp]
     lib.loco_mask_count.restype = i64
     lib.loco_clock_stamp.argtypes = [vp, vp, vp]
+    lib.loco_set_side_stream.argtypes = [vp, vp]
     lib.loco_unet_flops.argtypes = [vp]
     lib.loco_unet_flops.restype = C.c_double
     lib.loco_workspace_bytes.argtypes = [vp]
@@ -442,6 +443,26 @@ class LocoEngine:
     def set_streams(self, n: int):
         """Probe groups of a tangent / cotangent pass on 1 (default) or 2 HIP streams (identical results)."""
         self._check(self.lib.loco_set_streams(self._ctx, int(n)), "loco_set_streams")
+
+    def set_side_stream(self, stream: "Optional[torch.cuda.Stream]"):
+        """The second stream of `set_streams(2)`: a stream the caller measured to run BESIDE its current stream (HIP hands
+        hardware queues out round-robin; `tloco.BranchStreams._pick` does the measurement).  None: the context's own."""
+        self._side_stream = stream            # keep the torch object alive while the context may enqueue on it
+        ptr = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._check(self.lib.loco_set_side_stream(self._ctx, ptr), "loco_set_side_stream")
+
+    def set_streams_measured(self, n: int):
+        """`set_streams(n)`; for n = 2 the side stream is chosen by measurement (falls back to one stream when no stream of
+        this process runs beside the current one)."""
+        if n == 2:
+            from .tloco import BranchStreams
+            side = BranchStreams._pick(1, self.device)
+            if not side:
+                self.set_streams(1)
+                return 1
+            self.set_side_stream(side[0])
+        self.set_streams(n)
+        return n
 
     def get_precision(self) -> str:
         m = self.lib.loco_get_precision(self._ctx)

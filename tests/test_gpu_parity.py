@@ -760,6 +760,20 @@ def test_two_stream_probe_groups_match_single_stream(monkeypatch):
         out[ns] = (U.cpu(), A.cpu())
         del eng
     assert rel(out["2"][0], out["1"][0]) < 1e-5 and rel(out["2"][1], out["1"][1]) < 1e-5
+    # the second stream handed over by the caller (loco_set_side_stream), chosen by measurement on the host
+    monkeypatch.setenv("LOCO_STREAMS", "1")
+    eng = LocoEngine(cfg, max_batch=8, device=torch.device(DEV))
+    eng.load_state_dict(synth_params(cfg, 0))
+    eng.set_precision("bf16x3")
+    n = eng.set_streams_measured(2)
+    assert n in (1, 2)
+    eng.pmp_primal(x, t, at, mask.to(DEV))
+    U = eng.pmp_jvp(V)
+    A = eng.pmp_vjp(U)
+    torch.cuda.synchronize()
+    assert rel(U.cpu(), out["1"][0]) < 1e-5 and rel(A.cpu(), out["1"][1]) < 1e-5
+    eng.set_side_stream(None)
+    eng.set_streams(1)
 
 
 @pytest.mark.gpu
