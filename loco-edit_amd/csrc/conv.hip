@@ -352,7 +352,7 @@ int conv_bf16_pick_tile(int Cout, int HW, int Bsplit);   // conv_bf16.hip
 const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
     static const char* tiles[6] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1", "2,2,2,4", "2,4,2,2"};
     static char names[3][2][6][5][56];
-    int t = prec ? conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B * a.nsplit) : pick_tile(a.Cout, a.Hout * a.Wout);
+    int t = prec ? conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B) : pick_tile(a.Cout, a.Hout * a.Wout);
     if (prec && t == 4) t = 5;
     if (prec && a.stride == 2 && t == 5) t = 0;
     if (t < 0 || t > 5) t = 0;

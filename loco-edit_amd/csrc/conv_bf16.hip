@@ -12,8 +12,13 @@ enum : int { PR_BF16X3 = 0, PR_F16 = 1 };
 
 int g_bf16_tile_override = -1;   // debug / tuning: force a tile variant for the big-image case
 
-int conv_bf16_pick_tile(int Cout, int HW, int Bsplit) {
-    (void)Bsplit;
+// B = samples of the launch (NOT multiplied by a split-K factor: the choice must not depend on the factor it determines)
+int conv_bf16_pick_tile(int Cout, int HW, int B) {
+    static int b1 = -1;
+    if (b1 < 0) { const char* e = getenv("LOCO_B1_TILE"); b1 = e ? atoi(e) : 1024; }
+    // single-sample passes (the B = 1 inversion / to-t chains) at 64x64 and below: 64 x 64 tiles fill the chip with a quarter
+    // of the split-K of the 128 x 256 tile (LOCO_B1_TILE: largest H*W it applies to, default 32 x 32: 4.29 vs 4.51 ms per evaluation; 0 = off)
+    if (b1 > 0 && B == 1 && HW <= b1 && HW >= 64 && (Cout % 64) == 0) return 3;
     int t = conv_pick_tile(Cout, HW);
     if (t == 0 && HW >= 256) {
         if (g_bf16_tile_override >= 0) return g_bf16_tile_override;
@@ -39,7 +44,7 @@ int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B) {
 }
 
 int bf16_tile_of(const ConvArgs& a) {
-    int tile = conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B * a.nsplit);
+    int tile = conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B);
     if (tile == 4) tile = 5;
     if (a.stride == 2 && tile == 5) tile = 0;   // the double-buffered stride-2 halo of a 256-pixel tile exceeds LDS
     return tile;

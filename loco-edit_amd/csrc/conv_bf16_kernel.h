@@ -106,7 +106,8 @@ constexpr int max_halo(int NT, int taps, bool s2) {
         int th = NT / 32;
         return s2 ? (2 * th + 1) * 65 : (th + 2) * 34;
     }
-    return s2 ? 17 * 17 : 10 * 10;   // NT = 64 : 8x8 output tile
+    // NT = 64: an 8x8 output tile (8x8 images) or two rows of 32 (wider images: 4 x 34 halo, stride 2: 5 x 65)
+    return s2 ? 5 * 65 : 4 * 34;
 }
 
 // Epilogue of the low-precision conv kernels (shared by the lock-step kernel below and the role-split kernel of
