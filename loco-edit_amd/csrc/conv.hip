@@ -348,11 +348,14 @@ static void launch_tile(const ConvArgs& a, hipStream_t st) {
 }
 
 int conv_bf16_pick_tile(int Cout, int HW, int Bsplit);   // conv_bf16.hip
+int bf16_tile_of(const ConvArgs& a);                       // conv_bf16.hip
+static inline int bf16_tile_of_(const ConvArgs& a) { return bf16_tile_of(a); }
 
 const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
     static const char* tiles[6] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1", "2,2,2,4", "2,4,2,2"};
     static char names[3][2][6][5][56];
     int t = prec ? conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B) : pick_tile(a.Cout, a.Hout * a.Wout);
+    if (prec) { ConvArgs q = a; q.taps = taps; if (bf16_tile_of_(q) == 6) t = 0; }     // the two-per-CU variant is a 128 x 128 tile too
     if (prec && t == 4) t = 5;
     if (prec && a.stride == 2 && t == 5) t = 0;
     if (t < 0 || t > 5) t = 0;

@@ -32,7 +32,7 @@ int conv_bf16_pick_tile(int Cout, int HW, int B) {
 int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B) {
     const int HW = Hout * Wout;
     int t = conv_bf16_pick_tile(Cout, HW, B);
-    static const int MTs[6] = {128, 128, 32, 64, 128, 128}, NTs[6] = {128, 64, 128, 64, 256, 256};
+    static const int MTs[7] = {128, 128, 32, 64, 128, 128, 128}, NTs[7] = {128, 64, 128, 64, 256, 256, 128};
     long blocks = (long)(HW / NTs[t]) * ((Cout + MTs[t] - 1) / MTs[t]) * B;
     int nchunks = (Cin + BKC - 1) / BKC;
     if (blocks >= 128 || nchunks < 8) return 1;
@@ -43,19 +43,28 @@ int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B) {
     return want < 1 ? 1 : want;
 }
 
+// A/B switch (default off): the big-image 3x3 convs on 128 x 128 tiles of four waves in the compact LDS layout (STG 3 of
+// conv_bf16_kernel.h, 81 920 B), two workgroups per CU, instead of one 128 x 256 workgroup of eight waves
+static int conv_two_per_cu() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LOCO_CONV_2WG"); v = e ? (atoi(e) != 0) : 0; }
+    return v;
+}
 int bf16_tile_of(const ConvArgs& a) {
     int tile = conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B);
     if (tile == 4) tile = 5;
+    if (tile == 5 && conv_two_per_cu() && a.taps == 9 && a.stride == 1 && !a.upsample && !a.zins && (a.Cin % BKC) == 0 &&
+        a.in_padded && a.pad == 1 && a.Wout >= 32) return 6;
     if (a.stride == 2 && tile == 5) tile = 0;   // the double-buffered stride-2 halo of a 256-pixel tile exceeds LDS
     return tile;
 }
 int conv_bf16_tile_pixels(const ConvArgs& a) {
-    static const int NTs[6] = {128, 64, 128, 64, 256, 256};
+    static const int NTs[7] = {128, 64, 128, 64, 256, 256, 128};
     return NTs[bf16_tile_of(a)];
 }
 
 int conv_bf16_tile_couts(const ConvArgs& a) {
-    static const int MTs[6] = {128, 128, 32, 64, 128, 128};
+    static const int MTs[7] = {128, 128, 32, 64, 128, 128, 128};
     return MTs[bf16_tile_of(a)];
 }
 // Role-split 3x3 kernel (conv_spec_kernel.h): 128 x 256 tiles of stride-1 convs whose input lives in a padded engine

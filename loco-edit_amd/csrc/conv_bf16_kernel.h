@@ -321,15 +321,18 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     constexpr bool NEEDP = (MODE == CM_TAN_SILU || MODE == CM_COT_SILU);
     // GEN: general per-pixel staging (stride 2, upsample, zero insertion, partial channel chunks, caller-owned
     // tensors); !GEN: 16-byte loads of 4 consecutive pixels from padded arena tensors (stride-1 convs)
+    // STG 3: vector staging in the compact LDS layout of the 128 x 128 tile that fits TWO workgroups per CU (<= 81 920 B: two
+    //        weight buffers, i.e. no cross-stage operand prefetch, and one 64-byte dump record per halo buffer);
     // STG 0: vector staging; 1: per-pixel staging, stride 1 (also upsample / zero-insert / partial chunks /
     // caller-owned tensors); 2: per-pixel staging sized for the stride-2 halo
-    constexpr bool GEN = STG != 0;
+    constexpr bool GEN = (STG == 1 || STG == 2);
+    constexpr bool COMPACT = (STG == 3);
     constexpr int NITEM = GEN ? (2 * max_halo(NT, TAPS, STG == 2) + NTHR - 1) / NTHR : 1;
     constexpr int WTOT = NTS * MT * NPC;             // 16-byte pieces of one weight stage
     constexpr int NWV = (WTOT + NTHR - 1) / NTHR;
     // cross-stage operand prefetch (see the stage loop): 3x3 stride-1 variants; the stride-2 halo leaves no LDS for a
     // third weight buffer, and the 1x1 convs are HBM-bound
-    constexpr bool XPF = (TAPS == 9 && STG != 2);
+    constexpr bool XPF = (TAPS == 9 && STG != 2 && STG != 3);
     constexpr int NWB = XPF ? 3 : 2;                 // weight stage buffers
     // 1x1 operators on the per-pixel path: a stage is only TM*TN MFMA groups long, far shorter than a memory latency, so
     // the operands of DEEP_D chunks are kept in flight in a register ring (pixels AND weights by plain loads: the
@@ -391,7 +394,8 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     const int halo_w = (TW - 1) * S + KS;
     const int halo_h = (TH - 1) * S + KS;
     const int halo_sz = halo_h * halo_w;
-    const int HBYTES = (halo_sz + NDUMMY) * HP;     // + dump records for the lanes without a halo item
+    // + dump records for the lanes without a halo item (compact layout: ONE, cut to the 64 bytes a record's data takes)
+    const int HBYTES = COMPACT ? halo_sz * HP + RB : (halo_sz + NDUMMY) * HP;
     Hsb = smem_b + NWB * WBYTES;
 
     const int LH = (a.upsample || a.zins) ? a.Hin * 2 : a.Hin;
@@ -468,7 +472,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         }
 #pragma unroll
         for (int pxi = 0; pxi < 4; ++pxi)
-            v_rec[pxi] = (v_pos0 >= 0 && pxi < v_cnt) ? v_pos0 + pxi : (NDUMMY ? halo_sz + (tid & (NDUMMY - 1)) : 0);
+            v_rec[pxi] = (v_pos0 >= 0 && pxi < v_cnt) ? v_pos0 + pxi : (COMPACT ? halo_sz : halo_sz + (tid & (NDUMMY - 1)));
         // the row start may sit one float before the plane (left border): bias by 16 floats so the offset stays >= 0
         v_goff = (unsigned)(((long)v_q4 * 4 * in_plane + v_voff + 16) * 4);
     }
@@ -1085,12 +1089,12 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
 // ---------------------------------------------------------------------------
 // Kernel entry points: one name per arithmetic so profiles tell them apart.
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
-__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_bf16x3(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, STG == 3 ? 2 : 1) void conv_mfma_bf16x3(ConvArgs a) {
     f32x16 acc[TM][TN];
     conv_lowp_body<PR_BF16X3, TAPS, WM, WN, TM, TN, MODE, STG>(a, acc);
 }
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
-__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f16(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, STG == 3 ? 2 : 1) void conv_mfma_f16(ConvArgs a) {
     f32x16 acc[TM][TN];
     conv_lowp_body<PR_F16, TAPS, WM, WN, TM, TN, MODE, STG>(a, acc);
 }
@@ -1119,8 +1123,9 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     int TW = a.Wout < 32 ? a.Wout : 32;
     int TH = NT / TW;
     int halo_w = (TW - 1) * a.stride + KS, halo_h = (TH - 1) * a.stride + KS;
-    const int nwb = (TAPS == 9 && STG != 2) ? 3 : 2;
+    const int nwb = (TAPS == 9 && STG != 2 && STG != 3) ? 3 : 2;
     size_t lds = (size_t)nwb * KS * MT * rec_bytes<PR>() + 2 * ((size_t)halo_w * halo_h + NDUMMY) * halo_pitch<PR>();
+    if (STG == 3) lds = (size_t)nwb * KS * MT * rec_bytes<PR>() + 2 * ((size_t)halo_w * halo_h * halo_pitch<PR>() + rec_bytes<PR>());
     const size_t stage_bytes = (size_t)WM * 32 * NT * 4;      // epilogue staging tile S[WM*32 couts][NT pixels]
     if (lds < stage_bytes) lds = stage_bytes;
     dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
@@ -1185,6 +1190,10 @@ void launch_tile_b(const ConvArgs& a, hipStream_t st) {
                 if (conv_lowp_uses_spec(a, TAPS)) { launch_conv_spec<PR, MODE>(a, st); break; }
             }
             launch_one_b<PR, TAPS, 2, 4, 2, 2, MODE>(a, st);
+            break;
+        case 6:                                                           // 128 x 128, 4 waves, compact LDS: two workgroups per CU (LOCO_CONV_2WG=1)
+            if constexpr (TAPS == 9) { launch_one_b2<PR, TAPS, 2, 2, 2, 2, MODE, 3>(a, st); break; }
+            launch_one_b<PR, TAPS, 2, 2, 2, 2, MODE>(a, st);
             break;
         case 0: launch_one_b<PR, TAPS, 2, 2, 2, 2, MODE>(a, st); break;
         case 1: launch_one_b<PR, TAPS, 4, 1, 1, 2, MODE>(a, st); break;

@@ -2961,7 +2961,7 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     a.prim = c->arenaP; a.prim_bs = 0; a.sx = c->sxcache;
     a.w = wf; a.wb = wf; a.wh = wf;
     a.out = out; a.out_bs = out_e; a.Cout = cout; a.Hout = H; a.Wout = W; a.B = B;
-    a.mode = mode; a.pad = taps == 9 ? 1 : 0; a.in_padded = 1;
+    a.mode = mode; a.pad = taps == 9 ? 1 : 0; a.in_padded = 1; a.taps = taps;
     a.sc = c->statsP; a.sh = c->statsP + cin; a.scsh_bs = 0; a.mr = c->statsP + 2 * cin; a.mr_bs = 0;
     a.gamma_ = c->statsP; a.tst = c->statsT; a.tst_bs = c->stats_per_sample; a.cpg = cin / c->cfg.gn_groups;
     a.tc = c->statsT + 64; a.tc_bs = c->stats_per_sample;
