@@ -26,8 +26,14 @@ def norm(name):
     m = re.match(r"void loco::(conv_mfma_\w+)<([\d, ]+?)(?:, (?:true|false))?>\(", name)
     if not m:
         return None
-    # bench.py names a variant by <TAPS,WM,WN,TM,TN,MODE>; the staging flavour (7th parameter) is merged
-    return f"{m.group(1)}<{','.join(m.group(2).replace(' ', '').split(',')[:6])}>"
+    p = m.group(2).replace(' ', '').split(',')
+    # the no-doubling calibration was made on the vector-staged path (16-byte runs of halo rows, 7th parameter 0 / 3); the
+    # per-pixel staging variants (1, 2: 4-byte loads) are NOT calibrated -- a conv cannot fetch less than it stores, and the raw
+    # counter says it does for them -- so they get no traffic.json entry (their rows stay in the per-kernel csv, marked)
+    if len(p) > 6 and p[6] not in ("0", "3"):
+        return None
+    # bench.py names a variant by <TAPS,WM,WN,TM,TN,MODE>
+    return f"{m.group(1)}<{','.join(p[:6])}>"
 
 fd, wd, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 outdir = sys.argv[4] if len(sys.argv) > 4 else os.path.dirname(os.path.abspath(__file__))
@@ -58,7 +64,7 @@ res["_source"] = (f"profiles/{tag}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_S
                   "64-byte-run access pattern: profiles/r03_fetch_size_calibration.md), WRITE exact for 16-byte streaming stores")
 json.dump(res, open(os.path.join(here, "traffic.json"), "w"), indent=1)
 with open(os.path.join(here, f"{tag}_pmc_traffic_per_kernel.csv"), "w") as fh:
-    fh.write("kernel,launches,fetch_bytes_per_launch_corrected,write_bytes_per_launch\n")
+    fh.write("kernel,launches,fetch_bytes_per_launch_raw,write_bytes_per_launch,calibrated\n")
     for k, n, f, w in sorted(rows, key=lambda r: -r[1] * (r[2] + r[3])):
-        fh.write(f"\"{k}\",{n},{f:.0f},{w:.0f}\n")
+        fh.write(f"\"{k}\",{n},{f:.0f},{w:.0f},{'yes' if norm(k) else 'no'}\n")
 print(json.dumps({k: round(v['bytes'] / 1e6, 1) for k, v in out.items()}, indent=1))
