@@ -248,9 +248,16 @@ def e2e_phases(eng, cfg, sched_cls, solver, device):
             x = torch.cat([eng.ddim_step(x[b0:b0 + mb].contiguous(), float(t), a0, a1, 0.0, None)
                            for b0 in range(0, x.shape[0], mb)], dim=0) if x.shape[0] > mb else eng.ddim_step(x, float(t), a0, a1, 0.0, None)
         return x
-    chain_chunked(xall, fwd, 40, 41)                                     # warm the 25-frame launch shapes
+    # ... the way EditUncondDiffusion._decode_frames does it: the middle frame of every walk is the unedited xt, five
+    # identical images; one copy goes through the deterministic steps (to index 79 = performance_boosting_t 0.2 of the
+    # shipped script), the copies are put back where the reference's decode turns stochastic (eta = 1, one draw per frame)
+    keep = [i for i in range(25) if not (i % 5 == 2 and i > 2)]
+    src = [keep.index(i) if i in keep else keep.index(2) for i in range(25)]
+    assert all(torch.equal(xall[i], xall[2]) for i in range(25) if i not in keep)
+    xuniq = xall[keep].contiguous()
+    chain_chunked(xall, fwd, 40, 41); chain_chunked(xuniq, fwd, 40, 41)   # warm the 25- and 21-frame launch shapes
     sync(); t0 = time.perf_counter()
-    dec_all = chain_chunked(xall, fwd, 40, 99)
+    dec_all = chain_chunked(chain_chunked(xuniq, fwd, 40, 79)[src].contiguous(), fwd, 79, 99)
     sync(); out["decode_all_directions_s"] = time.perf_counter() - t0
     out = {k: round(v, 4) for k, v in out.items()}
     out["basis_plus_edit_s"] = round(out["two_solves_s"] + out["projection_edit_s"], 4)
@@ -261,7 +268,9 @@ def e2e_phases(eng, cfg, sched_cls, solver, device):
     out["decode_batch"] = f"{xall.shape[0]} frames, engine max_batch {mb}"
     out["note"] = ("synthetic weights; image_total_s = the reference's flow for one image (inversion 98 evaluations, 40 to "
                    "t, the modify + null solves with 12 iterations each, projection + edit walk, decode of ALL five "
-                   "directions = 59 steps x 25 frames, eta = 0); finite output: "
+                   "directions = 39 deterministic steps x 21 distinct frames (the five walks share their unedited middle frame: "
+                   "one copy until the reference's decode turns stochastic at index 79) + 20 steps x 25 frames; eta = 0 "
+                   "throughout in this timing); finite output: "
                    + str(bool(torch.isfinite(dec).all() and torch.isfinite(dec_all).all())))
     return out
 

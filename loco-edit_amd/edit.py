@@ -352,8 +352,7 @@ class EditUncondDiffusion(object):
             # as before.  Only the assignment of the eta = 1 draws to frames differs (one draw per step for the batch).
             frames = [self.edit_batch(original_xt, vT[pc_idx, :], vis_num) for pc_idx in range(n_pc)]
             per = frames[0].shape[0]
-            dec = self.DDIMforwardsteps(torch.cat(frames, dim=0), t_start_idx=self.edit_t_idx, t_end_idx=-1,
-                                        performance_boosting=True, save_image=False)
+            dec = self._decode_frames(torch.cat(frames, dim=0), n_pc, per)
             for pc_idx, name in enumerate(names):
                 self.EXP_NAME = name
                 image = (dec[pc_idx * per:(pc_idx + 1) * per] / 2 + 0.5).clamp(0, 1)
@@ -364,6 +363,36 @@ class EditUncondDiffusion(object):
             xt = self.edit_batch(original_xt, vT[pc_idx, :], vis_num)
             self.DDIMforwardsteps(xt, t_start_idx=self.edit_t_idx, t_end_idx=-1, performance_boosting=True)
         return xt
+
+    def _decode_frames(self, batch, n_pc, per):
+        """Decode the frames of all directions (``n_pc`` walks of ``per`` frames) from the edit step to x0.
+
+        The middle frame of every walk is the unedited ``xt`` itself (zero steps along the direction), i.e. the same
+        image ``n_pc`` times.  Through the deterministic part of the decode (eta = 0: up to ``performance_boosting_t_idx``,
+        edit.py:2556-2559) identical inputs stay identical, so only ONE copy goes through those steps; the copies are put
+        back where the stochastic part starts (eta = 1: every frame then gets its own draw, as in the reference) or at the
+        end.  ``LOCO_DEDUP_DECODE=0`` decodes all copies."""
+        mid = per // 2
+        dup = [d * per + mid for d in range(1, n_pc)]
+        dedup = (os.environ.get("LOCO_DEDUP_DECODE", "1") != "0" and per % 2 == 1 and n_pc > 1
+                 and all(torch.equal(batch[i], batch[mid]) for i in dup))
+        n_t = len(self.scheduler.timesteps)
+        pb = self.performance_boosting_t_idx
+        stochastic = pb < n_t - 1                      # DDIMforwardsteps switches to eta = 1 from index pb on
+        if not dedup or (stochastic and pb <= self.edit_t_idx):
+            return self.DDIMforwardsteps(batch, t_start_idx=self.edit_t_idx, t_end_idx=-1, performance_boosting=True,
+                                         save_image=False)
+        keep = [i for i in range(batch.shape[0]) if i not in set(dup)]
+        src = [keep.index(i) if i not in dup else keep.index(mid) for i in range(batch.shape[0])]     # full index -> unique index
+        uniq = batch[keep].contiguous()
+        if stochastic:
+            uniq, _, _ = self.DDIMforwardsteps(uniq, t_start_idx=self.edit_t_idx, t_end_idx=pb, performance_boosting=True,
+                                               save_image=False)
+            return self.DDIMforwardsteps(uniq[src].contiguous(), t_start_idx=pb, t_end_idx=-1, performance_boosting=True,
+                                         save_image=False)
+        dec = self.DDIMforwardsteps(uniq, t_start_idx=self.edit_t_idx, t_end_idx=-1, performance_boosting=True,
+                                    save_image=False)
+        return dec[src].contiguous()
 
     def edit_batch(self, original_xt, vk_row, vis_num):
         """The +/- direction walk of edit.py:2346-2363 in one kernel: the S-fold

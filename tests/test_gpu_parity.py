@@ -539,6 +539,42 @@ def test_run_edit_null_space_projection_end_to_end(tmp_path):
     assert any("Edit-random" in f for f in pngs)
 
 
+@pytest.mark.parametrize("pbt", [0.2, 0.0])
+def test_decode_shares_the_unedited_middle_frame(pbt, tmp_path, monkeypatch):
+    """EditUncondDiffusion._decode_frames: the walks of all directions contain the unedited x_t as their middle frame;
+    one copy goes through the deterministic steps and the copies are restored where the decode turns stochastic
+    (performance_boosting_t = 0.2: index 79; 0: never, restored at the end).  Against LOCO_DEDUP_DECODE=0 with the same
+    injected draws: the same images (the frames of a batch are independent; a batch of 7 instead of 9 only changes
+    batch-dependent split-K factors, i.e. fp32 rounding of the non-contractive untrained chain), and the number of
+    denoiser evaluations of the deterministic part drops from 9 to 7 frames per step."""
+    ed = _edit_obj(None, TINY_DDPM, tmp_path, pbt=pbt, prec="f32")
+    g = torch.Generator().manual_seed(5)
+    xt = torch.randn(1, 3, 32, 32, generator=g).to(DEV)
+    v = torch.randn(3, TINY_DDPM.n, generator=g).to(DEV)
+    v = v / v.norm(dim=1, keepdim=True)
+    frames = torch.cat([ed.edit_batch(xt, v[i], 1) for i in range(3)], dim=0)          # 3 walks of 3 frames: -S, 0, +S
+    assert frames.shape[0] == 9 and torch.equal(frames[4], frames[1]) and torch.equal(frames[7], frames[1])
+    noises = {i: torch.randn(9, 3, 32, 32, generator=g) for i in range(100)}
+    sizes = []
+    real_step = ed._step
+    monkeypatch.setattr(ed, "_step", lambda x, t, eta, noise=None: (sizes.append((x.shape[0], eta)), real_step(x, t, eta, noise))[1])
+    real_fwd = ed.DDIMforwardsteps
+    monkeypatch.setattr(ed, "DDIMforwardsteps", lambda *a, **k: real_fwd(*a, **dict(k, noises=noises)))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LOCO_DEDUP_DECODE", mode)
+        sizes.clear()
+        out[mode] = (ed._decode_frames(frames.clone(), 3, 3).cpu(), list(sizes))
+    n_det = (79 if pbt > 0 else 99) - ed.edit_t_idx
+    assert [b for b, _ in out["0"][1]] == [9] * (99 - ed.edit_t_idx)
+    assert [b for b, _ in out["1"][1]] == [7] * n_det + [9] * (99 - ed.edit_t_idx - n_det)
+    assert [e for _, e in out["1"][1]] == [e for _, e in out["0"][1]]
+    assert out["1"][0].shape == out["0"][0].shape == (9, 3, 32, 32)
+    assert psnr(out["1"][0], out["0"][0], peak=float(out["0"][0].abs().max())) > 60
+    if pbt == 0.0:                                                                      # no draws at all: the copies stay identical
+        assert torch.equal(out["1"][0][4], out["1"][0][1]) and torch.equal(out["1"][0][7], out["1"][0][1])
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_eta1_decode_with_injected_noise_vs_reference(prec, golden, tmp_path):
     """Fixture family 6, stochastic half (tests/golden/tiny_eta1.pt): DDIMforwardsteps from the edit step to x0 with
