@@ -149,6 +149,11 @@ TINY_LDM = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=32, ch_mult=(1,
 FLASH_LDM = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=160, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(16,),
                        gn_eps=1e-5, arch="adm", learn_sigma=False, context_dim=16, context_len=7, scale_shift_norm=False,
                        resblock_updown=False, num_heads=4, transformer_depth=1)
+# a SpatialTransformer with 80-channel heads (Stable Diffusion v1's width at its 1024-token level) over 256 tokens: the
+# three-channel-tile form of the flash attention kernels
+FLASH_LDM80 = UNetConfig(resolution=16, in_channels=4, out_ch=4, ch=320, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(16,),
+                         gn_eps=1e-5, arch="adm", learn_sigma=False, context_dim=16, context_len=7, scale_shift_norm=False,
+                         resblock_updown=False, num_heads=4, transformer_depth=1)
 # one level of Stable Diffusion's own width (320 channels, 8 heads of 40) over 64 tokens: the register-resident LayerNorm
 # kernels (C = 64 * 5) and the 1-tap tile choice of the transformer's linear layers, at a size autodiff finishes in seconds
 WIDE_LDM = UNetConfig(resolution=8, in_channels=4, out_ch=4, ch=320, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(8,),

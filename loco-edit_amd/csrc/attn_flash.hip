@@ -19,8 +19,11 @@
 // (records written by THIS kernel's staging) simply adopts.  No LDS round trip for the score tile.
 //
 // Heads of up to 64 channels (the ADM / IF-shaped denoisers' 64, Stable Diffusion's 40 at its 4096-token level: narrower
-// heads run zero-padded to 64); token counts that are multiples of 128.  Other shapes stay on the generic path.
+// heads run zero-padded to 64; two workgroups per CU) and, round 4, up to 96 channels (Stable Diffusion v1's 80-channel heads
+// at its 1024-token level: three 32-channel output tiles, one workgroup per CU); token counts that are multiples of 128.
+// Other shapes stay on the generic path.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace loco {
 
@@ -32,10 +35,11 @@ typedef short s16x8a __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int RP = 80;            // record pitch: 64-byte record [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] + 16 (conflict-free b128 reads)
-constexpr int CHD = 64;           // head channels
+constexpr int CHD = 96;           // widest head (channels): NCT = 2 channel tiles of 32 up to 64 channels, 3 up to 96
 constexpr int NOWN = 128;         // own tokens per workgroup (32 per wave)
 constexpr int NBLK = 64;          // streamed tokens per block
-constexpr int REGION = 2 * 4 * NBLK * RP;   // bytes of one operand region: 2 tensors x 4 records x 64 rows
+// bytes of one operand region for heads padded to 32 * NCT channels: 2 tensors x 2 NCT records (16 channels each) x 64 rows
+constexpr int region_bytes(int nct) { return 2 * (2 * nct) * NBLK * RP; }
 
 __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
     unsigned h[8], l[8];
@@ -52,11 +56,12 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
 
 // token-major records of X[c][t] (row stride T): tokens t0 .. t0+ntok-1, 64 channels -> dst[(chunk16 * ntok + tok) * RP].
 // Load and store halves are separate so the streamed block t+1 is in flight (registers) while block t multiplies.
-template <int NTOK> struct TokRegs { float v[(NTOK * 8) / 256][8]; };
-template <int NTOK>
-__device__ __forceinline__ void load_tokens(TokRegs<NTOK>& R, const float* X, int T, int t0, int tid, int nch) {
+// NOCT = octets (8 channels) of the padded head = 4 * NCT
+template <int NTOK, int NOCT> struct TokRegs { float v[(NTOK * NOCT) / 256][8]; };
+template <int NTOK, int NOCT>
+__device__ __forceinline__ void load_tokens(TokRegs<NTOK, NOCT>& R, const float* X, int T, int t0, int tid, int nch) {
 #pragma unroll
-    for (int it = 0; it < (NTOK * 8) / 256; ++it) {
+    for (int it = 0; it < (NTOK * NOCT) / 256; ++it) {
         const int e = tid + it * 256;
         const int tok = e % NTOK, oct = e / NTOK;              // lanes run over tokens: coalesced 4-byte loads
 #pragma unroll
@@ -64,10 +69,10 @@ __device__ __forceinline__ void load_tokens(TokRegs<NTOK>& R, const float* X, in
             R.v[it][k] = (oct * 8 + k < nch) ? X[(long)(oct * 8 + k) * T + t0 + tok] : 0.f;
     }
 }
-template <int NTOK>
-__device__ __forceinline__ void store_tokens(const TokRegs<NTOK>& R, unsigned char* dst, int tid) {
+template <int NTOK, int NOCT>
+__device__ __forceinline__ void store_tokens(const TokRegs<NTOK, NOCT>& R, unsigned char* dst, int tid) {
 #pragma unroll
-    for (int it = 0; it < (NTOK * 8) / 256; ++it) {
+    for (int it = 0; it < (NTOK * NOCT) / 256; ++it) {
         const int e = tid + it * 256;
         const int tok = e % NTOK, oct = e / NTOK;
         uint4 hi, lo;
@@ -77,36 +82,49 @@ __device__ __forceinline__ void store_tokens(const TokRegs<NTOK>& R, unsigned ch
         *reinterpret_cast<uint4*>(r + 32) = lo;
     }
 }
-template <int NTOK>
+template <int NTOK, int NOCT>
 __device__ __forceinline__ void stage_tokens(const float* X, int T, int t0, unsigned char* dst, int tid, int nch) {
-    TokRegs<NTOK> R;
-    load_tokens<NTOK>(R, X, T, t0, tid, nch);
-    store_tokens<NTOK>(R, dst, tid);
+    TokRegs<NTOK, NOCT> R;
+    load_tokens<NTOK, NOCT>(R, X, T, t0, tid, nch);
+    store_tokens<NTOK, NOCT>(R, dst, tid);
 }
-// channel-major records of X[c][t]: 64 channels x tokens t0 .. t0+63 in 4 blocks of 16, the 16 tokens of a record in the
-// D-fragment order j = (t&3) + 8(t>>2) + 4*khalf (slot = khalf*8 + t) -> dst[(jb * 64 + c) * RP]
-struct ChRegs { f32x4a a[4]; };
-__device__ __forceinline__ void load_channels(ChRegs& R, const float* X, int T, int t0, int tid, int nch) {
-    const int c = tid >> 2, jb = tid & 3;                      // 4 lanes cover 64 consecutive floats of one row
-    if (c < nch) {
-        const f32x4a* p = reinterpret_cast<const f32x4a*>(X + (long)c * T + t0 + jb * 16);
-        R.a[0] = p[0]; R.a[1] = p[1]; R.a[2] = p[2]; R.a[3] = p[3];   // tokens 0-3, 4-7, 8-11, 12-15
-    } else {
-        R.a[0] = R.a[1] = R.a[2] = R.a[3] = f32x4a{0.f, 0.f, 0.f, 0.f};
+// channel-major records of X[c][t]: CHP = 32 NCT channels x tokens t0 .. t0+63 in 4 blocks of 16, the 16 tokens of a record
+// in the D-fragment order j = (t&3) + 8(t>>2) + 4*khalf (slot = khalf*8 + t) -> dst[(jb * CHP + c) * RP]; the 256 threads
+// cover 64 channels per pass (4 lanes = 64 consecutive floats of one row), NCP = ceil(CHP / 64) passes
+template <int NCP> struct ChRegs { f32x4a a[NCP][4]; };
+template <int NCP>
+__device__ __forceinline__ void load_channels(ChRegs<NCP>& R, const float* X, int T, int t0, int tid, int nch) {
+    const int jb = tid & 3;
+#pragma unroll
+    for (int ps = 0; ps < NCP; ++ps) {
+        const int c = ps * 64 + (tid >> 2);
+        if (c < nch) {
+            const f32x4a* p = reinterpret_cast<const f32x4a*>(X + (long)c * T + t0 + jb * 16);
+            R.a[ps][0] = p[0]; R.a[ps][1] = p[1]; R.a[ps][2] = p[2]; R.a[ps][3] = p[3];   // tokens 0-3, 4-7, 8-11, 12-15
+        } else {
+            R.a[ps][0] = R.a[ps][1] = R.a[ps][2] = R.a[ps][3] = f32x4a{0.f, 0.f, 0.f, 0.f};
+        }
     }
 }
-__device__ __forceinline__ void store_channels(const ChRegs& R, unsigned char* dst, int tid) {
-    const int c = tid >> 2, jb = tid & 3;
-    const float k0[8] = {R.a[0][0], R.a[0][1], R.a[0][2], R.a[0][3], R.a[2][0], R.a[2][1], R.a[2][2], R.a[2][3]};   // khalf 0: 0-3, 8-11
-    const float k1[8] = {R.a[1][0], R.a[1][1], R.a[1][2], R.a[1][3], R.a[3][0], R.a[3][1], R.a[3][2], R.a[3][3]};   // khalf 1: 4-7, 12-15
-    uint4 h0, l0, h1, l1;
-    split8(k0, h0, l0);
-    split8(k1, h1, l1);
-    unsigned char* r = dst + (jb * 64 + c) * RP;
-    *reinterpret_cast<uint4*>(r) = h0;
-    *reinterpret_cast<uint4*>(r + 16) = h1;
-    *reinterpret_cast<uint4*>(r + 32) = l0;
-    *reinterpret_cast<uint4*>(r + 48) = l1;
+template <int NCP, int CHP>
+__device__ __forceinline__ void store_channels(const ChRegs<NCP>& R, unsigned char* dst, int tid) {
+    const int jb = tid & 3;
+#pragma unroll
+    for (int ps = 0; ps < NCP; ++ps) {
+        const int c = ps * 64 + (tid >> 2);
+        if (c >= CHP) continue;                                // the last pass of a 96-channel head: half of the threads
+        const f32x4a* a = R.a[ps];
+        const float k0[8] = {a[0][0], a[0][1], a[0][2], a[0][3], a[2][0], a[2][1], a[2][2], a[2][3]};   // khalf 0: 0-3, 8-11
+        const float k1[8] = {a[1][0], a[1][1], a[1][2], a[1][3], a[3][0], a[3][1], a[3][2], a[3][3]};   // khalf 1: 4-7, 12-15
+        uint4 h0, l0, h1, l1;
+        split8(k0, h0, l0);
+        split8(k1, h1, l1);
+        unsigned char* r = dst + (jb * CHP + c) * RP;
+        *reinterpret_cast<uint4*>(r) = h0;
+        *reinterpret_cast<uint4*>(r + 16) = h1;
+        *reinterpret_cast<uint4*>(r + 32) = l0;
+        *reinterpret_cast<uint4*>(r + 48) = l1;
+    }
 }
 
 struct Frag { s16x8a hi, lo; };
@@ -140,17 +158,26 @@ enum : int { M_TAN = 0, M_COTQ = 1, M_COTK = 2 };
 
 // NCK: 16-channel k-steps of the score products that hold channels (heads of <= 48 channels skip the all-zero fourth
 // step at compile time; a run-time skip splits the block's scheduling region and measured 3.4 % slower)
-template <int MODE, int NCK>
+// NCT: 32-channel output tiles of the padded head (2: heads up to 64 channels, two workgroups per CU; 3: up to 96 channels
+// -- Stable Diffusion v1's 80-channel heads at its 1024-token level -- one workgroup per CU: 120 KB of operand regions)
+template <int MODE, int NCK, int NCT>
 __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
+    constexpr int NREC = 2 * NCT;                  // 16-channel records per token
+    constexpr int NOCT = 4 * NCT;                  // octets per token
+    constexpr int CHP = 32 * NCT;                  // padded head width
+    constexpr int NCP = (CHP + 63) / 64;
+    constexpr int REGION = region_bytes(NCT);
+    constexpr int T2 = NREC * NBLK * RP;           // offset of the second tensor inside a region
+    static_assert(NCK <= NREC, "k-steps of the score product");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const RA = lds;                 // token-major operands of the streamed block (GEMM 1)
     unsigned char* const RB = lds + REGION;        // channel-major operands of the streamed block (GEMM 2)
-    float* const DL = reinterpret_cast<float*>(lds + 4 * NBLK * RP); // COTK: delta of the 64 streamed queries (RA holds one tensor there)
+    float* const DL = reinterpret_cast<float*>(lds + T2); // COTK: delta of the 64 streamed queries (RA holds one tensor there)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
     const int T = a.T, h = blockIdx.y, b = blockIdx.z;
     const int own0 = blockIdx.x * NOWN;            // first own token of the workgroup
     const int mytok = own0 + wave * 32 + l31;      // the lane's own token (column of every D fragment)
-    const int nch = a.CH;                          // head width (<= 64; narrower heads run zero-padded)
+    const int nch = a.CH;                          // head width (<= CHP; narrower heads run zero-padded)
     const long HS = a.hs, HO = (long)nch * T;
     const float* q = a.q + h * HS;  const float* k = a.k + h * HS;  const float* v = a.v + h * HS;
     const float* P = a.P + (long)h * T * T;
@@ -161,58 +188,58 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     const float* go = MODE != M_TAN ? a.go + (long)b * a.bs_go + h * HO : nullptr;
 
     // ---- own-token B fragments (constant over the stream): staged once through the operand regions
-    Frag y1[4], y2[MODE == M_TAN ? 4 : 1];
+    Frag y1[NREC], y2[MODE == M_TAN ? NREC : 1];
     {
         const float* Y1 = MODE == M_TAN ? dq : (MODE == M_COTQ ? go : v);
-        stage_tokens<NOWN>(Y1, T, own0, lds, tid, nch);
-        if (MODE == M_TAN) stage_tokens<NOWN>(q, T, own0, lds + 4 * NOWN * RP, tid, nch);
+        stage_tokens<NOWN, NOCT>(Y1, T, own0, lds, tid, nch);
+        if (MODE == M_TAN) stage_tokens<NOWN, NOCT>(q, T, own0, lds + NREC * NOWN * RP, tid, nch);
         __syncthreads();
 #pragma unroll
-        for (int ck = 0; ck < 4; ++ck) {
+        for (int ck = 0; ck < NREC; ++ck) {
             y1[ck] = ld_frag(lds + (ck * NOWN + wave * 32 + l31) * RP, khalf);
-            if (MODE == M_TAN) y2[ck] = ld_frag(lds + 4 * NOWN * RP + (ck * NOWN + wave * 32 + l31) * RP, khalf);
+            if (MODE == M_TAN) y2[ck] = ld_frag(lds + NREC * NOWN * RP + (ck * NOWN + wave * 32 + l31) * RP, khalf);
         }
     }
     float delta_own = 0.f;                          // COTQ: delta_i = <g_o_i, o_i> of the lane's own query
     if (MODE == M_COTQ) {
         float s = 0.f;
-        for (int c = khalf * 32; c < khalf * 32 + 32 && c < nch; ++c) s += go[(long)c * T + mytok] * o[(long)c * T + mytok];
+        for (int c = khalf * (CHP / 2); c < khalf * (CHP / 2) + CHP / 2 && c < nch; ++c) s += go[(long)c * T + mytok] * o[(long)c * T + mytok];
         s += __shfl_xor(s, 32, 64);
         delta_own = s;
         if (khalf == 0) a.delta[((long)b * a.NH + h) * T + mytok] = s;
     }
 
-    f32x16 acc[2], acc2[MODE == M_COTK ? 2 : 1];    // [c tile]: GEMM 2 accumulators (COTK: g_v and g_k)
+    f32x16 acc[NCT], acc2[MODE == M_COTK ? NCT : 1];    // [c tile]: GEMM 2 accumulators (COTK: g_v and g_k)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NCT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; if (MODE == M_COTK) acc2[i][r] = 0.f; }
     float rsum = 0.f;                               // TAN: r_i partial of this lane (its khalf's rows)
 
     // streamed operands of a block: loaded into registers one block ahead, converted into LDS records at the top of the block
-    TokRegs<NBLK> ta, tb;
-    ChRegs ca, cb;
+    TokRegs<NBLK, NOCT> ta, tb;
+    ChRegs<NCP> ca, cb;
     float dreg = 0.f;
     auto fetch = [&](int t0) {
         if (MODE == M_TAN) {
-            load_tokens<NBLK>(ta, k, T, t0, tid, nch); load_tokens<NBLK>(tb, dk, T, t0, tid, nch);
-            load_channels(ca, v, T, t0, tid, nch); load_channels(cb, dv, T, t0, tid, nch);
+            load_tokens<NBLK, NOCT>(ta, k, T, t0, tid, nch); load_tokens<NBLK, NOCT>(tb, dk, T, t0, tid, nch);
+            load_channels<NCP>(ca, v, T, t0, tid, nch); load_channels<NCP>(cb, dv, T, t0, tid, nch);
         } else if (MODE == M_COTQ) {
-            load_tokens<NBLK>(ta, v, T, t0, tid, nch);
-            load_channels(ca, k, T, t0, tid, nch);
+            load_tokens<NBLK, NOCT>(ta, v, T, t0, tid, nch);
+            load_channels<NCP>(ca, k, T, t0, tid, nch);
         } else {
-            load_tokens<NBLK>(ta, go, T, t0, tid, nch);
-            load_channels(ca, go, T, t0, tid, nch); load_channels(cb, q, T, t0, tid, nch);
+            load_tokens<NBLK, NOCT>(ta, go, T, t0, tid, nch);
+            load_channels<NCP>(ca, go, T, t0, tid, nch); load_channels<NCP>(cb, q, T, t0, tid, nch);
             if (tid < NBLK) dreg = a.delta[((long)b * a.NH + h) * T + t0 + tid];
         }
     };
     fetch(0);
     for (int t0 = 0; t0 < T; t0 += NBLK) {
         __syncthreads();                            // the previous block's fragment reads (and the prologue's) are done
-        store_tokens<NBLK>(ta, RA, tid);
-        store_channels(ca, RB, tid);
-        if (MODE == M_TAN) { store_tokens<NBLK>(tb, RA + 4 * NBLK * RP, tid); store_channels(cb, RB + 4 * NBLK * RP, tid); }
-        if (MODE == M_COTK) { store_channels(cb, RB + 4 * NBLK * RP, tid); if (tid < NBLK) DL[tid] = dreg; }
+        store_tokens<NBLK, NOCT>(ta, RA, tid);
+        store_channels<NCP, CHP>(ca, RB, tid);
+        if (MODE == M_TAN) { store_tokens<NBLK, NOCT>(tb, RA + T2, tid); store_channels<NCP, CHP>(cb, RB + T2, tid); }
+        if (MODE == M_COTK) { store_channels<NCP, CHP>(cb, RB + T2, tid); if (tid < NBLK) DL[tid] = dreg; }
         if (t0 + NBLK < T) fetch(t0 + NBLK);        // in flight under this block's MFMAs
         // primal probabilities of the tile in the D-fragment layout (rows = streamed tokens, column = own token)
         f32x16 pt[2];
@@ -243,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
 #pragma unroll
             for (int ck = 0; ck < NCK; ++ck) {
                 mma3(s_[mt], ld_frag(RA + (ck * NBLK + 32 * mt + l31) * RP, khalf), y1[ck]);
-                if (MODE == M_TAN) mma3(s_[mt], ld_frag(RA + 4 * NBLK * RP + (ck * NBLK + 32 * mt + l31) * RP, khalf), y2[ck]);
+                if (MODE == M_TAN) mma3(s_[mt], ld_frag(RA + T2 + (ck * NBLK + 32 * mt + l31) * RP, khalf), y2[ck]);
             }
         }
         // ---- elementwise: W = s P o S (TAN), G = s P o (S - delta) (COT)
@@ -267,16 +294,16 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
                 Frag fp;
                 if (MODE != M_COTQ) fp = frag_of(pt[mt], bb);
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const unsigned char* r1 = RB + (jb * 64 + 32 * ct + l31) * RP;
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const unsigned char* r1 = RB + (jb * CHP + 32 * ct + l31) * RP;
                     if (MODE == M_TAN) {
                         mma3(acc[ct], ld_frag(r1, khalf), fw);                           // v W
-                        mma3(acc[ct], ld_frag(r1 + 4 * NBLK * RP, khalf), fp);           // dv P
+                        mma3(acc[ct], ld_frag(r1 + T2, khalf), fp);                      // dv P
                     } else if (MODE == M_COTQ) {
                         mma3(acc[ct], ld_frag(r1, khalf), fw);                           // k G
                     } else {
                         mma3(acc[ct], ld_frag(r1, khalf), fp);                           // g_o P  -> g_v
-                        mma3(acc2[ct], ld_frag(r1 + 4 * NBLK * RP, khalf), fw);          // q G    -> g_k
+                        mma3(acc2[ct], ld_frag(r1 + T2, khalf), fw);                     // q G    -> g_k
                     }
                 }
             }
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     // ---- epilogue.  D[row = channel][col = own token]
     if (MODE == M_TAN) rsum += __shfl_xor(rsum, 32, 64);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -303,15 +330,19 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
 
 }  // namespace
 
-bool attn_flash_supported(int T, int CH) { return CH >= 8 && CH <= CHD && T >= NOWN && (T % NOWN) == 0; }
+bool attn_flash_supported(int T, int CH) {
+    static int wide = -1;                 // LOCO_FLASH_WIDE=0: heads wider than 64 channels stay on the generic path (A/B switch)
+    if (wide < 0) { const char* e = getenv("LOCO_FLASH_WIDE"); wide = e ? (atoi(e) != 0) : 1; }
+    return CH >= 8 && CH <= (wide ? CHD : 64) && T >= NOWN && (T % NOWN) == 0;
+}
 
-template <int NCK>
+template <int NCK, int NCT>
 static void attn_flash_launch_n(int mode, const AttnFlashArgs& a, hipStream_t st) {
     dim3 grid(a.T / NOWN, a.NH, a.B);
-    const size_t ldsb = 2 * REGION;       // 80 KB: two workgroups per CU
-    auto k0 = &attn_flash_kernel<M_TAN, NCK>;
-    auto k1 = &attn_flash_kernel<M_COTQ, NCK>;
-    auto k2 = &attn_flash_kernel<M_COTK, NCK>;
+    const size_t ldsb = 2 * region_bytes(NCT);       // NCT 2: 80 KB, two workgroups per CU; NCT 3: 120 KB, one
+    auto k0 = &attn_flash_kernel<M_TAN, NCK, NCT>;
+    auto k1 = &attn_flash_kernel<M_COTQ, NCK, NCT>;
+    auto k2 = &attn_flash_kernel<M_COTK, NCK, NCT>;
     static DeviceOnce once;
     if (first_on_device(once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
@@ -323,8 +354,10 @@ static void attn_flash_launch_n(int mode, const AttnFlashArgs& a, hipStream_t st
     else hipLaunchKernelGGL(k2, grid, dim3(256), ldsb, st, a);
 }
 static void attn_flash_launch(int mode, const AttnFlashArgs& a, hipStream_t st) {
-    if (a.CH <= 48) attn_flash_launch_n<3>(mode, a, st);
-    else attn_flash_launch_n<4>(mode, a, st);
+    if (a.CH <= 48) attn_flash_launch_n<3, 2>(mode, a, st);
+    else if (a.CH <= 64) attn_flash_launch_n<4, 2>(mode, a, st);
+    else if (a.CH <= 80) attn_flash_launch_n<5, 3>(mode, a, st);
+    else attn_flash_launch_n<6, 3>(mode, a, st);
 }
 
 void launch_attn_flash_tangent(const AttnFlashArgs& a, hipStream_t st) { attn_flash_launch(M_TAN, a, st); }

@@ -151,7 +151,7 @@ struct AttnFlashArgs {
     float *gq, *gk, *gv; long bs_g;           // cotangent results per probe
     float* delta;                             // scratch [B][NH][T]: delta_i = <g_o_i, o_i>
 };
-bool attn_flash_supported(int T, int CH);     // heads of <= 64 channels, token counts that are multiples of 128
+bool attn_flash_supported(int T, int CH);     // heads of <= 96 channels, token counts that are multiples of 128
 void launch_attn_flash_tangent(const AttnFlashArgs& a, hipStream_t st);
 void launch_attn_flash_cotangent(const AttnFlashArgs& a, hipStream_t st);
 

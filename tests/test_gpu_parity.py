@@ -980,18 +980,18 @@ def test_statistics_fused_into_epilogues_equal_the_standalone_kernels(cfg, monke
     assert max(errs[:6]) < 3e-5 and max(errs[6:]) < 3e-3, errs
 
 
-@pytest.mark.parametrize("which", ["adm64", "ldm40"])
+@pytest.mark.parametrize("which", ["adm64", "ldm40", "ldm80"])
 @pytest.mark.parametrize("prec", ["bf16x3", "f16"])
 def test_flash_attention_tangent_and_cotangent(prec, which, monkeypatch):
     """The tangent and cotangent of the multi-head attention blocks without per-probe [T x T] matrices (attn_flash.hip:
     64-channel heads, 1024 and 256 tokens here) against (1) autodiff of the CPU restatement of the reference network
     (guided_diffusion/unet.py:330-356 under jvp / grad) and (2) the generic GEMM + softmax-Jacobian path of the same engine
     (LOCO_FLASH_ATTN=0); adjointness of the pair."""
-    from loco_edit_amd.config import FLASH_ADM, FLASH_LDM
+    from loco_edit_amd.config import FLASH_ADM, FLASH_LDM, FLASH_LDM80
     from loco_edit_amd.hip import LocoEngine
     # adm64: AttentionBlock, 64-channel heads, 1024 and 256 tokens; ldm40: SpatialTransformer, 40-channel heads (zero-padded
-    # to the kernel's 64), 256 tokens
-    cfg = FLASH_ADM if which == "adm64" else FLASH_LDM
+    # to the kernel's 64), 256 tokens; ldm80: 80-channel heads (Stable Diffusion v1's 32x32 level: three channel tiles), 256 tokens
+    cfg = {"adm64": FLASH_ADM, "ldm40": FLASH_LDM, "ldm80": FLASH_LDM80}[which]
     params = synth_params(cfg, 0)
     p = orc.to_torch(params)
     gen = torch.Generator().manual_seed(17)
