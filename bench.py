@@ -229,6 +229,14 @@ def e2e_phases(eng, cfg, sched_cls, solver, device):
     (_, _, vTm, _), (_, _, vTn, _) = solver.local_basis_pair(eng, xt, t, at, 5, mask, 5, ~mask, min_iter=N_ITER, max_iter=N_ITER,
                                                              v0_a=v0m, v0_b=v0n, verbose=False)
     sync(); out["two_solves_s"] = time.perf_counter() - t0
+    # the same pair under the reference's own arguments (edit.py:2292-2310: min_iter=10, max_iter=50) and its stop rule: with
+    # five probes the reference's allclose never holds (LAPACK's sign flips, tests/golden/converge.pt), so both solves run 50
+    t0 = time.perf_counter()
+    (_, _, _, n50a), (_, _, _, n50b) = solver.local_basis_pair(eng, xt, t, at, 5, mask, 5, ~mask, min_iter=10, max_iter=50,
+                                                               convergence_threshold=1e-4, v0_a=v0m, v0_b=v0n, verbose=False,
+                                                               stop_rule="reference")
+    sync(); out["two_solves_reference_stop_rule_s"] = time.perf_counter() - t0
+    assert (n50a, n50b) == (50, 50)
     t0 = time.perf_counter()
     vT = eng.null_project(vTm, vTn)
     xb = eng.edit_axpy(xt, vT[0].contiguous(), [-8.0, -4.0, 0.0, 4.0, 8.0])
@@ -265,9 +273,11 @@ def e2e_phases(eng, cfg, sched_cls, solver, device):
                                                                      "projection_edit_s", "decode_one_direction_s")), 4)
     out["image_total_s"] = round(sum(out[k] for k in ("inversion_s", "to_t_s", "two_solves_s", "projection_edit_s",
                                                       "decode_all_directions_s")), 4)
+    out["image_total_reference_stop_rule_s"] = round(out["image_total_s"] - out["two_solves_s"] + out["two_solves_reference_stop_rule_s"], 4)
     out["decode_batch"] = f"{xall.shape[0]} frames, engine max_batch {mb}"
     out["note"] = ("synthetic weights; image_total_s = the reference's flow for one image (inversion 98 evaluations, 40 to "
-                   "t, the modify + null solves with 12 iterations each, projection + edit walk, decode of ALL five "
+                   "t, the modify + null solves with 12 iterations each -- image_total_reference_stop_rule_s: with the 50 iterations "
+                   "each that the reference's stop rule gives five-probe solves --, projection + edit walk, decode of ALL five "
                    "directions = 39 deterministic steps x 21 distinct frames (the five walks share their unedited middle frame: "
                    "one copy until the reference's decode turns stochastic at index 79) + 20 steps x 25 frames; eta = 0 "
                    "throughout in this timing); finite output: "
