@@ -44,6 +44,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));      // 16-byte operand
 enum : int { PR_BF16X3 = 0, PR_F16 = 1 };
 
 constexpr int BKC = 16;
+constexpr bool EARLY_W = true;   // 3x3 stride-1 kernels: first two weight stages issued before the index setup (see conv_lowp_body)
 constexpr int NDUMMY = 8;   // spare halo records per buffer: lanes without a halo item store there instead of branching
 
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~10 VALU instructions fewer per element of the halo
@@ -391,6 +392,35 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     const int b = __builtin_amdgcn_readfirstlane(zid / a.nsplit);
     const int split = __builtin_amdgcn_readfirstlane(zid % a.nsplit);
 
+    if constexpr (XPF && PHASE != 2 && EARLY_W) {
+        // The first two weight stages leave BEFORE the per-thread index setup below (a dozen run-time integer divisions,
+        // ~1 us): their L2 -> LDS latency then runs under it instead of after it.  Same addresses as dma_w() further down.
+        const int nchunks_ = (a.Cin + BKC - 1) / BKC;
+        const int cps_ = __builtin_amdgcn_readfirstlane((nchunks_ + a.nsplit - 1) / a.nsplit);
+        const int cbeg_ = split * cps_;
+        const int cend_ = (cbeg_ + cps_ < nchunks_) ? cbeg_ + cps_ : nchunks_;
+        if (cend_ > cbeg_) {
+            typedef __attribute__((address_space(3))) unsigned char lds_u8_;
+            typedef const __attribute__((address_space(1))) unsigned char glb_u8_;
+            const int wpitch_ = (a.Cout + 31) & ~31;
+            const unsigned char* wbase0 = reinterpret_cast<const unsigned char*>(a.wb) +
+                                          (unsigned)(cbeg_ * TAPS) * ((unsigned)wpitch_ * (unsigned)RB);
+#pragma unroll
+            for (int st_ = 0; st_ < 2; ++st_)              // kernel rows 0 and 1 of the first chunk
+#pragma unroll
+                for (int i = 0; i < NWV; ++i) {
+                    int e = tid + i * NTHR;
+                    if (e >= WTOT) e = WTOT - 1;
+                    const int tap = e / (MT * NPC), rem = e - tap * (MT * NPC);
+                    int rec = co0 + rem / NPC;
+                    if (rec >= wpitch_) rec = wpitch_ - 1;
+                    const unsigned rel = (unsigned)(((st_ * NTS + tap) * wpitch_ + rec) * NPC + (rem % NPC)) * 16u;
+                    const int e0 = wave * 64 + i * NTHR;
+                    if ((WTOT % NTHR) == 0 || e0 < WTOT)
+                        __builtin_amdgcn_global_load_lds((glb_u8_*)(wbase0 + rel), (lds_u8_*)(smem_b + st_ * WBYTES + e0 * 16), 16, 0, 0);
+                }
+        }
+    }
     const int halo_w = (TW - 1) * S + KS;
     const int halo_h = (TH - 1) * S + KS;
     const int halo_sz = halo_h * halo_w;
@@ -829,10 +859,12 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
             r_out = row_ % NROW;
         };
         if (nch > 0) {
-            int c1, r1;
-            dma_w(cbeg, 0, Wsb);
-            stage_of(0, 1, c1, r1);
-            dma_w(c1, r1, Wsb + WBYTES);
+            if constexpr (!(PHASE != 2 && EARLY_W)) {      // (otherwise issued at the top of the kernel)
+                int c1, r1;
+                dma_w(cbeg, 0, Wsb);
+                stage_of(0, 1, c1, r1);
+                dma_w(c1, r1, Wsb + WBYTES);
+            }
             Hs = Hsb;
             if constexpr (!GEN && NPART == 2) {
                 // both parts of the first chunk are loaded together (a second register set that only lives here) so

@@ -1327,11 +1327,14 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     };
     if (rq && rq->kind != ST_NONE && rq->n) rq->n->ready = true;
     if (!tail_probes) { one(a, 0); return; }
-    // tail-probe split: two launches finish the tensor; their statistics are taken once over the whole batch behind them
-    // (separate statistics for the few tail probes would add a reduce-with-statistics and a finalize launch per conv)
-    const StatReq* rq_all = (rq && rq->kind != ST_NONE && rq->n) ? rq : nullptr;
+    // tail-probe split: two launches finish the tensor.  Tangent / cotangent statistics are taken once over the whole batch
+    // behind them (separate statistics for the few tail probes would add a reduce-with-statistics and a finalize launch per
+    // conv).  FORWARD statistics are per sample and come for free with both launches: the main launch's epilogue partials
+    // (+ one merge launch for its samples), the tail's split-K epilogue -- no pass over the finished tensor.
+    const bool per_part = want && rq && rq->kind == ST_FWD && rq->n;
+    const StatReq* rq_all = (!per_part && rq && rq->kind != ST_NONE && rq->n) ? rq : nullptr;
     if (rq && rq->keep_ntile) *rq->keep_ntile = 0;
-    rq = nullptr;
+    if (!per_part) rq = nullptr;
     ConvArgs m = a, t = a;
     const int nb = a.B - tail_probes;
     m.B = nb;
