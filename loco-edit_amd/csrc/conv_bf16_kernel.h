@@ -44,6 +44,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));      // 16-byte operand
 enum : int { PR_BF16X3 = 0, PR_F16 = 1 };
 
 constexpr int BKC = 16;
+constexpr bool LIVE_MASK = true;   // loads issued for chunks past the end of the range read one address instead of the last chunk again
 constexpr bool EARLY_W = true;   // 3x3 stride-1 kernels: first two weight stages issued before the index setup (see conv_lowp_body)
 constexpr int NDUMMY = 8;   // spare halo records per buffer: lanes without a halo item store there instead of branching
 
@@ -580,6 +581,11 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         else return R.cq[0][2 + kk];
     };
     HaloRegs hr;                                      // the part in flight inside the stage loop
+    // Past the end of the chunk range the stage body keeps issuing its loads (it is branch-free: one scheduling region); they
+    // used to re-read the LAST chunk -- one chunk of halo data and two weight stages per tile that nobody consumes (12 % of a
+    // 128-channel conv's halo bytes through the CU's vector-memory path).  `pf_live == false` (wave-uniform) collapses such
+    // a load onto one address: every lane reads the same 16 bytes, one cache line per instruction.
+    bool pf_live = true, dma_live = true;
     auto prefetch_hv = [&](HaloRegs& R, int chunk, int part) {
         // wave-uniform chunk base (SGPR pair) + 32-bit per-lane byte offset: global_load saddr form, no 64-bit VALU
         // (32-bit scalar offset arithmetic: one sample's tensor is far below 4 GB)
@@ -589,7 +595,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         const unsigned pl = (unsigned)in_plane * 4u;
 #pragma unroll
         for (int kk = 0; kk < KP; ++kk) {
-            const unsigned po = v_goff + (unsigned)(part * KP + kk) * pl;
+            const unsigned po = pf_live ? v_goff + (unsigned)(part * KP + kk) * pl : 64u;     // 64 = the first element itself
             // 4-byte aligned 16-byte loads (global memory tolerates dword alignment)
             R.dq[kk] = *reinterpret_cast<const f32x4_u*>(pk + po);
             if constexpr (NEEDP) {
@@ -668,8 +674,8 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                 const float2* sk = NEEDP ? sxb + (long)(c0 + k) * in_plane : nullptr;
 #pragma unroll
                 for (int i = 0; i < NITEM; ++i) {
-                    hvd[i][k] = pk[ivoff[i]];
-                    if constexpr (NEEDP) pv[i][k] = sk[ivoff[i]];
+                    hvd[i][k] = pk[pf_live ? ivoff[i] : 0u];
+                    if constexpr (NEEDP) pv[i][k] = sk[pf_live ? ivoff[i] : 0u];
                 }
             }
         } else {
@@ -719,7 +725,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         for (int i = 0; i < NWV; ++i) {
             const int e0 = (wave * 64 + i * NTHR);                 // first piece of this wave's 1 KiB slab
             if ((WTOT % NTHR) == 0 || e0 < WTOT)                   // wave-uniform
-                __builtin_amdgcn_global_load_lds((glb_u8*)(wbase + wrel[i]), (lds_u8*)(Wdst + e0 * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_u8*)(wbase + (dma_live ? wrel[i] : 0u)), (lds_u8*)(Wdst + e0 * 16), 16, 0, 0);
         }
     };
     auto stage_regs = [&](const float (&hvs)[NITEM][8], int chunk, unsigned char* Hd) {
@@ -907,7 +913,9 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                 {
                     int c2, r2;
                     stage_of(ci, row + 2, c2, r2);
+                    dma_live = LIVE_MASK ? (chunk + (row + 2) / NROW <= clast) : true;
                     dma_w(c2, r2, Wnx2);               // weights of the stage after next
+                    dma_live = true;
                 }
                 Frag& fa = fr[(P + row) & 1];          // taps 0 and 2 of this stage
                 Frag& fb = fr[(P + row + 1) & 1];      // tap 1, then tap 0 of the next stage
@@ -919,7 +927,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                 __builtin_amdgcn_sched_barrier(0);
                 load_frag(fb, row, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (ld0 >= 0) prefetch_h(cclamp(chunk + 2), ld0);
+                if (ld0 >= 0) { pf_live = LIVE_MASK ? (chunk + 2 <= clast) : true; prefetch_h(cclamp(chunk + 2), ld0); pf_live = true; }
                 mma_frag_tail(fa);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_frag_head(fb);
@@ -939,7 +947,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                 // conversion and re-load never share a scheduling region: the loads then land directly in the registers
                 // the conversion has finished reading (no copies behind a vmcnt wait)
                 if (cv2 >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), cv2); }
-                if (ld2 >= 0) prefetch_h(cclamp(chunk + 1), ld2);
+                if (ld2 >= 0) { pf_live = LIVE_MASK ? (chunk + 1 <= clast) : true; prefetch_h(cclamp(chunk + 1), ld2); pf_live = true; }
                 mma_frag_tail(fa);
                 __builtin_amdgcn_sched_barrier(0);
                 // the LDS-DMA of this stage (older than the part loads issued in it) must have landed before the barrier
@@ -947,7 +955,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lde >= 0) prefetch_h(cclamp(chunk + 2), lde);
+                    if (lde >= 0) { pf_live = LIVE_MASK ? (chunk + 2 <= clast) : true; prefetch_h(cclamp(chunk + 2), lde); pf_live = true; }
                 }
                 stage_end();
             }
@@ -972,18 +980,23 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         float hvr[D][NITEM][8];
         f32x4 wr[D][NWV];
         const unsigned char* const wgb = reinterpret_cast<const unsigned char*>(wg);
-        auto issue = [&](auto stag, int chunk) {
+        // `chunk` may lie past the range (the ring keeps D chunks in flight to the last stage): such loads are collapsed onto
+        // one address per instruction instead of re-reading the last chunk (`LIVE_MASK`; with D = 4 that was half a 128-channel
+        // operator's input again)
+        auto issue = [&](auto stag, int chunk_raw) {
             constexpr int sl = decltype(stag)::value;
+            const bool live = LIVE_MASK ? (chunk_raw <= clast) : true;
+            const int chunk = cclamp(chunk_raw);
             const int c0 = chunk * BKC;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {       // wave-uniform plane base + per-lane 32-bit offset (ivoff holds the octet)
                 const float* pk = inb + (long)(c0 + k) * in_plane;
 #pragma unroll
-                for (int i = 0; i < NITEM; ++i) hvr[sl][i][k] = pk[ivoff[i]];
+                for (int i = 0; i < NITEM; ++i) hvr[sl][i][k] = pk[live ? ivoff[i] : 0u];
             }
             const unsigned char* wbase = wgb + (unsigned)(chunk * TAPS) * ((unsigned)wpitch * (unsigned)RB);
 #pragma unroll
-            for (int i = 0; i < NWV; ++i) wr[sl][i] = *reinterpret_cast<const f32x4*>(wbase + wrel[i]);
+            for (int i = 0; i < NWV; ++i) wr[sl][i] = *reinterpret_cast<const f32x4*>(wbase + (live ? wrel[i] : 0u));
         };
         auto commit = [&](auto stag, int chunk, unsigned char* Hd, unsigned char* Wd) {
             constexpr int sl = decltype(stag)::value;
@@ -999,11 +1012,11 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         static_assert(D == 4, "ring slots are spelled out below");
         if (nch > 0) {
             issue(S0{}, cbeg);
-            issue(S1{}, cclamp(cbeg + 1));
-            issue(S2{}, cclamp(cbeg + 2));
-            issue(S3{}, cclamp(cbeg + 3));
+            issue(S1{}, cbeg + 1);
+            issue(S2{}, cbeg + 2);
+            issue(S3{}, cbeg + 3);
             commit(S0{}, cbeg, Hsb, Wsb);
-            issue(S0{}, cclamp(cbeg + 4));
+            issue(S0{}, cbeg + 4);
             stage_end();
         }
         auto body = [&](auto stag, const int ci) {        // stag = ring slot of chunk ci + 1
@@ -1018,7 +1031,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
             __builtin_amdgcn_sched_barrier(0);
             mma_frag(f0);
             commit(stag, cclamp(chunk + 1), Hnxt, Wnxt);
-            issue(stag, cclamp(chunk + 1 + D));
+            issue(stag, chunk + 1 + D);
             stage_end();
         };
         int ci = 0;
@@ -1076,7 +1089,9 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
             // before its first use and expose one LDS latency per operand.
             {
                 const int r1 = (row + 1) % NROW, dc = (row + 1) / NROW;
+                dma_live = LIVE_MASK ? (chunk + dc <= clast) : true;
                 dma_w(cclamp(chunk + dc), r1, Wnxt);
+                dma_live = true;
             }
             Ws = Wcur; Hs = Hcur;
             Frag f0, f1;
@@ -1091,7 +1106,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
             // halo conversion, then the re-load of its registers, share one scheduling region with the MFMAs of taps
             // 1 and 2 (a fence between them measured 2.7 ms/step slower; conversion under tap 0 13 ms slower)
             if (st_part >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), st_part); Hs = Hcur; }
-            if (MIDLOAD && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+            if (MIDLOAD && ld_part >= 0) { pf_live = LIVE_MASK ? (ld_chunk <= clast) : true; prefetch_h(cclamp(ld_chunk), ld_part); pf_live = true; }
             if (NTS > 2) mma_frag(f0);
             __builtin_amdgcn_sched_barrier(0);
             // the LDS-DMA of this stage (older than the part loads just issued) must have landed before the barrier
@@ -1099,7 +1114,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!MIDLOAD && ld_part >= 0) prefetch_h(cclamp(ld_chunk), ld_part);
+                if (!MIDLOAD && ld_part >= 0) { pf_live = LIVE_MASK ? (ld_chunk <= clast) : true; prefetch_h(cclamp(ld_chunk), ld_part); pf_live = true; }
             }
             stage_end();
         }
