@@ -710,7 +710,7 @@ def test_bench_two_ranks_share_one_gpu():
     GPU over gloo; the 8-GPU RCCL run itself is the driver's."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LOCO_BENCH_BACKEND="gloo")
+    env = dict(os.environ, LOCO_BENCH_BACKEND="gloo", LOCO_BENCH_MAX_BATCH="8")     # two 8-sample arenas on the one GPU (not 2 x 32)
     env.pop("WORLD_SIZE", None)
     # the driver's own command form: no external launcher, bench.py starts its ranks itself
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
