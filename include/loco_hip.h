@@ -79,6 +79,20 @@ typedef struct loco_unet_cfg {
     int32_t resblock_updown;
     int32_t num_heads;
     int32_t transformer_depth;
+    /* arch 1, the DeepFloyd-IF stage-I denoiser (`self.unet = self.stage_1.unet`, src/modules/edit.py:1213-1222: diffusers
+     * UNet2DConditionModel with ResnetDownsampleBlock2D / SimpleCrossAttn*Block2D, un-vendored; the same tree as the
+     * UNetModel of the deepfloyd_if package) = the guided-diffusion skeleton with scale-shift norm and ResBlock resampling plus:
+     *   act        0: SiLU   1: exact (erf) GELU in every norm -> activation -> conv chain and in the time embedding
+     *                 (`act_fn = "gelu"`; the per-block embedding projections read act(emb) once: `resnet_skip_time_act`)
+     *   res_scale  ResBlock output = (shortcut + h) * res_scale (`resnet_out_scale_factor` = sqrt 2 -> 0.70710678);
+     *                 0 reads as 1
+     *   added_kv   1: every AttentionBlock attends over [text ; image] keys / values in ONE softmax
+     *                 (`AttnAddedKVProcessor`: key = cat([add_k_proj(GN(ctx)), to_k(h)])): the context_len x context_dim
+     *                 states of loco_set_context (after the host's `encoder_hid_proj`) go through the block's own
+     *                 GroupNorm (`norm_encoder`) and `encoder_kv` projection; needs context_dim > 0, transformer_depth = 0 */
+    int32_t act;
+    float   res_scale;
+    int32_t added_kv;
 } loco_unet_cfg;
 
 /* Library / device probes (no ctx). */

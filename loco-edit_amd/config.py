@@ -51,6 +51,17 @@ class UNetConfig:
     resblock_updown: bool = True
     num_heads: int = -1
     transformer_depth: int = 0
+    # adm, the DeepFloyd-IF stage-I denoiser (deepfloyd_if UNetModel = diffusers UNet2DConditionModel with
+    # ResnetDownsampleBlock2D / SimpleCrossAttn*Block2D): exact GELU instead of SiLU ("efficient activation": the blocks'
+    # embedding projections read gelu(emb) once), ResBlock output (skip + h) * res_scale, and attention blocks whose keys /
+    # values are [text ; image] in one softmax (`added_kv`: the context_len x context_dim states, already through the
+    # model's encoder_proj, pass the block's norm_encoder GroupNorm and its encoder_kv projection).  `encoder_dim` is the
+    # width of the text encoder's states (T5-XXL: 4096) that the host-side conditioning reads (tloco.IFTextConditioner:
+    # encoder_proj -> context, encoder_pooling -> the embedding added to the time embedding)
+    act: str = "silu"
+    res_scale: float = 1.0
+    added_kv: bool = False
+    encoder_dim: int = 0
 
     @property
     def temb_ch(self) -> int:
@@ -165,6 +176,24 @@ MID_IF64 = UNetConfig(resolution=64, ch=64, ch_mult=(1, 2, 3, 4), num_res_blocks
                       gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=True)
 
 
+# BASELINE config 5 on the architecture the shipped script names (scripts/main_T2I_DeepFloydIF_null_space_projection.sh:4,
+# "DeepFloyd/IF-I-M-v1.0"): the stage-I U-Net of DeepFloyd IF = the guided-diffusion skeleton at 192 x (1,2,3,4) with 3
+# ResBlocks per level, scale-shift norm, ResBlock resampling, 64-channel heads at 32 / 16 / 8, learned variance -- plus exact
+# GELU, (skip + h) / sqrt 2, and attention over [text ; image] keys with the 77 x 4096 T5-XXL states projected to 768
+IF_I_M_UNET = UNetConfig(resolution=64, ch=192, ch_mult=(1, 2, 3, 4), num_res_blocks=3, attn_resolutions=(32, 16, 8),
+                         gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=True, context_dim=768, context_len=77,
+                         act="gelu", res_scale=0.7071067811865476, added_kv=True, encoder_dim=4096)
+# the same switches at sizes autodiff on the CPU finishes in seconds (two attention levels, a resampling ResBlock each way,
+# a channel-changing shortcut, 16-channel heads, 7 text states of width 24 -> 32)
+TINY_IF = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16, 8), gn_eps=1e-5,
+                     arch="adm", num_head_channels=16, learn_sigma=True, context_dim=32, context_len=7, act="gelu",
+                     res_scale=0.7071067811865476, added_kv=True, encoder_dim=24)
+# config 5's geometry (64 x 64, four levels, the 1024-token attention level, 64-channel heads) at a third of the width
+MID_IF = UNetConfig(resolution=64, ch=64, ch_mult=(1, 2, 3, 4), num_res_blocks=2, attn_resolutions=(32, 16, 8), gn_eps=1e-5,
+                    arch="adm", num_head_channels=64, learn_sigma=True, context_dim=256, context_len=77, act="gelu",
+                    res_scale=0.7071067811865476, added_kv=True, encoder_dim=128)
+
+
 def adm_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     """state_dict layout of guided_diffusion ``UNetModel`` (unet.py:398-617) for the P2 flavour:
     ``time_embed.{0,2}``, ``input_blocks.N.{0,1}``, ``middle_block.{0,1,2}``, ``output_blocks.N.{0,1,2}``, ``out.{0,2}``;
@@ -209,6 +238,10 @@ def adm_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
         shapes[name + ".norm.weight"] = (c,); shapes[name + ".norm.bias"] = (c,)
         shapes[name + ".qkv.weight"] = (3 * c, c, 1); shapes[name + ".qkv.bias"] = (3 * c,)
         shapes[name + ".proj_out.weight"] = (c, c, 1); shapes[name + ".proj_out.bias"] = (c,)
+        if cfg.added_kv:            # DeepFloyd-IF AttentionBlock: GroupNorm + Conv1d of the text states, per head [k_h | v_h]
+            shapes[name + ".norm_encoder.weight"] = (cfg.context_dim,); shapes[name + ".norm_encoder.bias"] = (cfg.context_dim,)
+            shapes[name + ".encoder_kv.weight"] = (2 * c, cfg.context_dim, 1); shapes[name + ".encoder_kv.bias"] = (2 * c,)
+            return
         if cfg.context_dim > 0:     # cross-attention stage (not part of guided_diffusion: stand-in for the diffusers blocks)
             x = name + ".xattn"
             shapes[x + ".norm.weight"] = (c,); shapes[x + ".norm.bias"] = (c,)
@@ -219,6 +252,17 @@ def adm_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
 
     shapes["time_embed.0.weight"] = (ted, mc); shapes["time_embed.0.bias"] = (ted,)
     shapes["time_embed.2.weight"] = (ted, ted); shapes["time_embed.2.bias"] = (ted,)
+    if cfg.encoder_dim > 0:
+        # host-side text conditioning of the IF U-Net (tloco.IFTextConditioner; diffusers `encoder_hid_proj` and
+        # `add_embedding` = TextTimeEmbedding: LayerNorm, AttentionPooling, Linear, LayerNorm)
+        E = cfg.encoder_dim
+        shapes["encoder_proj.weight"] = (cfg.context_dim, E); shapes["encoder_proj.bias"] = (cfg.context_dim,)
+        shapes["encoder_pooling.0.weight"] = (E,); shapes["encoder_pooling.0.bias"] = (E,)
+        shapes["encoder_pooling.1.positional_embedding"] = (1, E)
+        for n in ("k_proj", "q_proj", "v_proj"):
+            shapes[f"encoder_pooling.1.{n}.weight"] = (E, E); shapes[f"encoder_pooling.1.{n}.bias"] = (E,)
+        shapes["encoder_pooling.2.weight"] = (ted, E); shapes["encoder_pooling.2.bias"] = (ted,)
+        shapes["encoder_pooling.3.weight"] = (ted,); shapes["encoder_pooling.3.bias"] = (ted,)
     ch = mc * cfg.ch_mult[0]
     shapes["input_blocks.0.0.weight"] = (ch, cfg.in_channels, 3, 3); shapes["input_blocks.0.0.bias"] = (ch,)
     chans = [ch]
@@ -435,6 +479,12 @@ def synth_params(cfg: UNetConfig, seed: int = 0) -> Dict[str, np.ndarray]:
     """
     out: Dict[str, np.ndarray] = {}
     for name, shape in param_shapes(cfg).items():
+        if cfg.encoder_dim >= 1024 and name.startswith("encoder_pooling.1.") and len(shape) == 2 and shape[0] == shape[1]:
+            # the three E x E maps of the attention pooling (3 x 16.8 M values at E = 4096): a cheap deterministic fill
+            rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+            row = rng.standard_normal(shape[1]).astype(np.float32) / np.sqrt(shape[1])
+            out[name] = np.ascontiguousarray(np.stack([np.roll(row, i) for i in range(shape[0])]).astype(np.float32))
+            continue
         rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
         z = rng.standard_normal(shape).astype(np.float32)
         if name.endswith(".bias"):

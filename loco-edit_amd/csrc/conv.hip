@@ -26,23 +26,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 8;
 
-__device__ __forceinline__ float sigmoidf_(float y) { return 1.0f / (1.0f + __expf(-y)); }
-
+// `act`: ConvArgs::act (kernels.h ActKind), wave-uniform; this exact-fp32 kernel takes the activation at run time (CM_GN_GELU
+// is dispatched as CM_GN_SILU with act = ACT_GELU)
 template <int MODE>
 __device__ __forceinline__ float prologue(float d, float x, float sc, float sh, float gamma, float mean,
-                                          float rstd, float m1, float m2) {
+                                          float rstd, float m1, float m2, int act) {
     if constexpr (MODE == CM_NONE) {
         return d;
     } else if constexpr (MODE == CM_GN_SILU) {
-        float y = fmaf(sc, d, sh);
-        return y * sigmoidf_(y);
+        return act_fwd(fmaf(sc, d, sh), act);
     } else if constexpr (MODE == CM_GN) {
         return fmaf(sc, d, sh);
     } else {
         float xh = (x - mean) * rstd;
-        float y = fmaf(sc, x, sh);
-        float sg = sigmoidf_(y);
-        float ds = sg * (1.0f + y * (1.0f - sg));
+        float ds = act_der(fmaf(sc, x, sh), act);
         if constexpr (MODE == CM_TAN_SILU) {
             return ds * sc * (d - m1 - xh * m2);
         } else {  // CM_COT_SILU
@@ -199,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(ConvArgs a) {
                 if (pos < halo_sz) {
                     float v = 0.0f;
                     if (poff[i] >= 0 && c0 + k < a.Cin)
-                        v = prologue<MODE>(hv[i][k], NEEDP ? pv[i][k] : 0.f, sc, sh, gm, mean, rstd, m1, m2);
+                        v = prologue<MODE>(hv[i][k], NEEDP ? pv[i][k] : 0.f, sc, sh, gm, mean, rstd, m1, m2, a.act);
                     Hs[k * halo_sz + pos] = v;
                 }
             }
@@ -262,7 +259,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(ConvArgs a) {
                 } else {
                     if (a.bias) v += a.bias[co];
                     if (a.bias2) v += a.bias2[(long)b * a.bias2_bs + co];
-                    if (a.res) v += a.res[(long)b * a.res_bs + co * out_plane + pix];
+                    if (a.res) v += a.res_scale * a.res[(long)b * a.res_bs + co * out_plane + pix];
                     float* o = a.out + (long)b * a.out_bs + co * out_plane + pix;
                     if (a.accumulate) v += *o;
                     *o = v;
@@ -283,7 +280,7 @@ __global__ void conv_splitk_reduce(ConvArgs a, long total) {
         for (int s = 0; s < a.nsplit; ++s) v += a.partial[(long)s * total + i];
         if (a.bias) v += a.bias[co];
         if (a.bias2) v += a.bias2[(long)b * a.bias2_bs + co];
-        if (a.res) v += a.res[(long)b * a.res_bs + rem];
+        if (a.res) v += a.res_scale * a.res[(long)b * a.res_bs + rem];
         float* o = a.out + (long)b * a.out_bs + rem;
         if (a.accumulate) v += *o;
         *o = v;
@@ -353,7 +350,7 @@ static inline int bf16_tile_of_(const ConvArgs& a) { return bf16_tile_of(a); }
 
 const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
     static const char* tiles[6] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1", "2,2,2,4", "2,4,2,2"};
-    static char names[3][2][6][5][56];
+    static char names[3][2][6][6][56];
     int t = prec ? conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B) : pick_tile(a.Cout, a.Hout * a.Wout);
     if (prec) { ConvArgs q = a; q.taps = taps; if (bf16_tile_of_(q) == 6) t = 0; }     // the two-per-CU variant is a 128 x 128 tile too
     if (prec && t == 4) t = 5;
@@ -374,7 +371,8 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
     int ti = taps == 9 ? 0 : 1;
     int m = a.mode;
     if (taps != 9 && m != CM_NONE) m = CM_GN;
-    if (m < 0 || m > 4) m = 2;
+    if (!prec && m == CM_GN_GELU) m = CM_GN_SILU;      // the exact-fp32 kernel takes the activation at run time
+    if (m < 0 || m > 5) m = 2;
     char* n = names[prec][ti][t][m];
     static const char* kn[3] = {"conv_mfma_f32", "conv_mfma_bf16x3", "conv_mfma_f16"};
     if (!n[0]) snprintf(n, 56, "%s<%d,%s,%d>", kn[prec], taps, tiles[t], m);
@@ -385,7 +383,7 @@ void launch_conv(const ConvArgs& a, int taps, hipStream_t st) {
     if (taps == 9) {
         switch (a.mode) {
             case CM_NONE: launch_tile<9, CM_NONE>(a, st); break;
-            case CM_GN_SILU: launch_tile<9, CM_GN_SILU>(a, st); break;
+            case CM_GN_SILU: case CM_GN_GELU: launch_tile<9, CM_GN_SILU>(a, st); break;
             case CM_TAN_SILU: launch_tile<9, CM_TAN_SILU>(a, st); break;
             case CM_COT_SILU: launch_tile<9, CM_COT_SILU>(a, st); break;
             default: launch_tile<9, CM_GN>(a, st); break;
@@ -422,7 +420,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce4(ConvArgs a, long tota
         if (a.bias) add += a.bias[co];
         if (a.bias2) add += a.bias2[(long)b * a.bias2_bs + co];
         v += add;
-        if (a.res) v += *reinterpret_cast<const f32x4_r*>(a.res + (long)b * a.res_bs + rem);
+        if (a.res) v += a.res_scale * *reinterpret_cast<const f32x4_r*>(a.res + (long)b * a.res_bs + rem);
         float* o = a.out + (long)b * a.out_bs + rem;
         if (a.accumulate) v += *reinterpret_cast<const f32x4_r*>(o);
         *reinterpret_cast<f32x4_r*>(o) = v;

@@ -108,6 +108,7 @@ static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
         switch (a.mode) {
             case CM_NONE: launch_tile_b<PR, 9, CM_NONE>(a, st); break;
             case CM_GN_SILU: launch_tile_b<PR, 9, CM_GN_SILU>(a, st); break;
+            case CM_GN_GELU: launch_tile_b<PR, 9, CM_GN_GELU>(a, st); break;
             case CM_TAN_SILU: launch_tile_b<PR, 9, CM_TAN_SILU>(a, st); break;
             case CM_COT_SILU: launch_tile_b<PR, 9, CM_COT_SILU>(a, st); break;
             default: launch_tile_b<PR, 9, CM_GN>(a, st); break;

@@ -178,7 +178,7 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
 #pragma unroll
                 for (int q = 0; q < NTASK; ++q) {
                     f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
-                    if (rb) t4 = *reinterpret_cast<const f32x4*>(rb + off[q]);
+                    if (rb) t4 = a.res_scale * *reinterpret_cast<const f32x4*>(rb + off[q]);
                     if (accu) t4 += *reinterpret_cast<const f32x4*>(ob + off[q]);
                     rv[q] = t4;
                 }
@@ -277,7 +277,7 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
                         const bool ok = full_co || co < a.Cout;
                         const long off = (long)(ok ? co : a.Cout - 1) * out_plane + pix;
                         float t = 0.f;
-                        if (rb) t = rb[off];
+                        if (rb) t = a.res_scale * rb[off];
                         if (a.accumulate) t += ob[off];
                         rv[r] = t;
                     }
@@ -543,8 +543,8 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
 
     const float* inb = a.in + (long)b * a.in_bs;
     const float2* sxb = NEEDP ? a.sx : nullptr;                     // primal (S, xhat) cache, B = 1
-    const float* scb = (MODE == CM_GN_SILU || MODE == CM_GN) ? a.sc + (long)b * a.scsh_bs : nullptr;
-    const float* shb = (MODE == CM_GN_SILU || MODE == CM_GN) ? a.sh + (long)b * a.scsh_bs : nullptr;
+    const float* scb = (MODE == CM_GN_SILU || MODE == CM_GN || MODE == CM_GN_GELU) ? a.sc + (long)b * a.scsh_bs : nullptr;
+    const float* shb = (MODE == CM_GN_SILU || MODE == CM_GN || MODE == CM_GN_GELU) ? a.sh + (long)b * a.scsh_bs : nullptr;
     const int wpitch = (a.Cout + 31) & ~31;                         // records per tap in the global layout
     const uint4* wg = reinterpret_cast<const uint4*>(a.wb);
 
@@ -629,6 +629,8 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                 if constexpr (MODE == CM_GN_SILU) {
                     float y = fmaf(cq_a(R, kk), d, cq_b(R, kk));
                     v = y * sigmoidf2_(y);
+                } else if constexpr (MODE == CM_GN_GELU) {
+                    v = act_fwd(fmaf(cq_a(R, kk), d, cq_b(R, kk)), ACT_GELU);
                 } else if constexpr (MODE == CM_GN) {
                     v = fmaf(cq_a(R, kk), d, cq_b(R, kk));
                 } else if constexpr (NEEDP) {
@@ -748,6 +750,8 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                         if constexpr (MODE == CM_GN_SILU) {
                             float y = fmaf(ca, d, cb);
                             r = y * sigmoidf2_(y);
+                        } else if constexpr (MODE == CM_GN_GELU) {
+                            r = act_fwd(fmaf(ca, d, cb), ACT_GELU);
                         } else if constexpr (MODE == CM_GN) {
                             r = fmaf(ca, d, cb);
                         } else {
@@ -1199,7 +1203,7 @@ static void launch_one_b(const ConvArgs& a, hipStream_t st) {
         else launch_one_b2<PR, TAPS, WM, WN, TM, TN, MODE, 1>(a, st);
         return;
     }
-    if constexpr (MODE == CM_GN_SILU || MODE == CM_TAN_SILU) {
+    if constexpr (MODE == CM_GN_SILU || MODE == CM_TAN_SILU || MODE == CM_GN_GELU) {
         if (general) { launch_one_b2<PR, TAPS, WM, WN, TM, TN, MODE, 1>(a, st); return; }
     }
     launch_one_b2<PR, TAPS, WM, WN, TM, TN, MODE, 0>(a, st);
@@ -1231,7 +1235,7 @@ void launch_tile_b(const ConvArgs& a, hipStream_t st) {
     const int tile = bf16_tile_of(a);
     switch (tile) {
         case 5:                                                           // 128 x 256, 8 compute waves (64 x 64 each)
-            if constexpr (TAPS == 9) {
+            if constexpr (TAPS == 9 && MODE != CM_GN_GELU) {
                 // stride-1 convs on padded arena tensors: the role-split kernel (conv_spec_kernel.h; LOCO_CONV_SPEC=0 keeps
                 // every launch on the lock-step kernel below)
                 if (conv_lowp_uses_spec(a, TAPS)) { launch_conv_spec<PR, MODE>(a, st); break; }

@@ -94,6 +94,11 @@ struct Op {
     ConvP xqc, xproj;
     float *xkw = nullptr, *xkb = nullptr, *xvw = nullptr, *xvb = nullptr;   // key / value projections of the context [C][D], [C]
     float *xK = nullptr, *xV = nullptr;                                     // projected context [C][Lp] (loco_set_context)
+    // DeepFloyd-IF attention (cfg.added_kv): keys / values = [text ; image] in one softmax.  The text part reuses xkw .. xV
+    // (encoder_kv rows of head h: [k_h | v_h]) behind the block's own GroupNorm of the states (xng / xnb, `norm_encoder`);
+    // S is [heads][T][Lp + T] with the (padded, masked) text columns first
+    bool added_kv = false;
+    float *xng = nullptr, *xnb = nullptr;
     bool in_is_skip = false;
     bool has_nin = false;
     bool has_temb = true;         // RES: false for the embedding-free blocks of the decoder (arch 2)
@@ -156,6 +161,8 @@ struct loco_ctx {
     float* ctx_colbias = nullptr;  // [Lp]: 0 for real tokens, -1e30 for the padding
     bool has_ctx = false;
     float* cond_add = nullptr;     // [temb_ch] conditioning embedding of the time embedding (loco_set_cond)
+    float* ctx_norm = nullptr;     // [context_len][context_dim] scratch: the states behind one block's norm_encoder (added_kv)
+    float res_scale = 1.f;         // cfg.res_scale (0 -> 1): ResBlock output = (shortcut + h) * res_scale
     bool has_cond = false;
     float2* sxcache = nullptr;     // primal {S, xhat} per GroupNorm+SiLU input (bf16x3 path)
     long sx_total = 0;
@@ -482,11 +489,12 @@ int build_program_adm(loco_ctx* c) {
         a.heads = heads_of(t.C);
         a.hn = new_tensor(c, t.C, t.H, t.W);
         a.qkv = new_tensor(c, 3 * t.C, t.H, t.W);
-        a.S = new_tensor(c, a.heads, T, T);
+        a.added_kv = cfg.added_kv != 0;
+        a.S = new_tensor(c, a.heads, T, a.added_kv ? c->ctx_Lp + T : T);
         a.o = new_tensor(c, t.C, t.H, t.W);
         a.n1 = new_norm(c, t.C);
         a.pn_n1 = name + ".norm"; a.pn_qkv = name + ".qkv"; a.pn_proj = name + ".proj_out";
-        if (cfg.context_dim > 0) {
+        if (cfg.context_dim > 0 && !a.added_kv) {
             a.has_x = true;
             a.xmid = new_tensor(c, t.C, t.H, t.W);
             a.xhn = new_tensor(c, t.C, t.H, t.W);
@@ -849,6 +857,11 @@ void declare_all(loco_ctx* c) {
                     declare_param(c, op.pn_qkv + ".bias", {3 * C});
                     declare_param(c, op.pn_proj + ".weight", {C, C, 1});
                     declare_param(c, op.pn_proj + ".bias", {C});
+                    if (op.added_kv) {   // deepfloyd_if AttentionBlock: norm_encoder (GroupNorm over the states), encoder_kv Conv1d
+                        declare_norm(c, op.name + ".norm_encoder", cfg.context_dim);
+                        declare_param(c, op.name + ".encoder_kv.weight", {2 * C, cfg.context_dim, 1});
+                        declare_param(c, op.name + ".encoder_kv.bias", {2 * C});
+                    }
                     if (op.has_x) {
                         const std::string x = op.name + ".xattn";
                         declare_norm(c, x + ".norm", C);
@@ -996,6 +1009,14 @@ int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::v
 int make_conv1(loco_ctx* c, const std::string& name, ConvP* out, int row_limit = -1) {
     return make_conv(c, {&c->params[name + ".weight"]}, {&c->params[name + ".bias"]}, out, row_limit);
 }
+// the same operator with weight and bias multiplied by `s` (the ResBlock output scale of cfg.res_scale lives in conv2 / the shortcut)
+int make_conv1_scaled(loco_ctx* c, const std::string& name, ConvP* out, float s) {
+    if (s == 1.f) return make_conv1(c, name, out);
+    HostParam w = c->params[name + ".weight"], b = c->params[name + ".bias"];
+    for (float& v : w.data) v *= s;
+    for (float& v : b.data) v *= s;
+    return make_conv(c, {&w}, {&b}, out);
+}
 int make_norm(loco_ctx* c, const std::string& name, NormP* n) {
     if (upload(c, &n->gamma, c->params[name + ".weight"].data)) return -1;
     if (upload(c, &n->beta, c->params[name + ".bias"].data)) return -1;
@@ -1036,8 +1057,8 @@ int finalize_params(loco_ctx* c) {
             case OP_CONV_IN: case OP_CONV: if (make_conv1(c, op.pn_conv, &op.conv)) return -1; break;
             case OP_RES: {
                 if (make_norm(c, op.pn_n1, &op.n1) || make_norm(c, op.pn_n2, &op.n2)) return -1;
-                if (make_conv1(c, op.pn_c1, &op.c1) || make_conv1(c, op.pn_c2, &op.c2)) return -1;
-                if (op.has_nin && make_conv1(c, op.pn_skip, &op.nin)) return -1;
+                if (make_conv1(c, op.pn_c1, &op.c1) || make_conv1_scaled(c, op.pn_c2, &op.c2, c->res_scale)) return -1;
+                if (op.has_nin && make_conv1_scaled(c, op.pn_skip, &op.nin, c->res_scale)) return -1;
                 if (!op.has_temb) break;
                 op.tproj_off = (long)tpb.size();
                 auto& w = c->params[op.pn_emb + ".weight"].data;
@@ -1055,6 +1076,26 @@ int finalize_params(loco_ctx* c) {
                                      {&c->params[op.name + ".q.bias"], &c->params[op.name + ".k.bias"],
                                       &c->params[op.name + ".v.bias"]}, &op.qkvc)) return -1;
                 if (make_conv1(c, op.pn_proj, &op.proj)) return -1;
+                if (op.added_kv) {
+                    // encoder_kv rows of head h are [k_h (CH) | v_h (CH)] (QKVAttention of deepfloyd_if: the states' projection is
+                    // split per head like qkv): un-interleave into the key and the value map, rows ordered (head, channel)
+                    const int C = c->tens[op.in].C, NH = op.heads, CH = C / NH, D = c->cfg.context_dim;
+                    const HostParam& w = c->params[op.name + ".encoder_kv.weight"];
+                    const HostParam& b = c->params[op.name + ".encoder_kv.bias"];
+                    std::vector<float> kw((size_t)C * D), vw((size_t)C * D), kb(C), vb(C);
+                    for (int h = 0; h < NH; ++h)
+                        for (int i = 0; i < CH; ++i) {
+                            const size_t rk = (size_t)h * 2 * CH + i, rv = rk + CH, r = (size_t)h * CH + i;
+                            std::copy(w.data.begin() + rk * D, w.data.begin() + (rk + 1) * D, kw.begin() + r * D);
+                            std::copy(w.data.begin() + rv * D, w.data.begin() + (rv + 1) * D, vw.begin() + r * D);
+                            kb[r] = b.data[rk]; vb[r] = b.data[rv];
+                        }
+                    if (upload(c, &op.xkw, kw) || upload(c, &op.xkb, kb) || upload(c, &op.xvw, vw) || upload(c, &op.xvb, vb) ||
+                        upload(c, &op.xng, c->params[op.name + ".norm_encoder.weight"].data) ||
+                        upload(c, &op.xnb, c->params[op.name + ".norm_encoder.bias"].data)) return -1;
+                    const size_t kv = (size_t)C * c->ctx_Lp;
+                    if (dalloc(c, &op.xK, kv) || dalloc(c, &op.xV, kv)) return -1;
+                }
                 if (op.has_x) {
                     const std::string x = op.name + ".xattn";
                     if (make_norm(c, x + ".norm", &op.nx) || make_conv1(c, x + ".q", &op.xqc) ||
@@ -1164,7 +1205,7 @@ inline void attn_gemm(const loco_ctx* c, const GemmArgs& g, hipStream_t st) {
 
 void conv_defaults(ConvArgs& a) {
     std::memset(&a, 0, sizeof(a));
-    a.stride = 1; a.pad = 1; a.nsplit = 1; a.mode = CM_NONE;
+    a.stride = 1; a.pad = 1; a.nsplit = 1; a.mode = CM_NONE; a.res_scale = 1.f;
 }
 
 // sc / sh / mr / tst pointers of a norm inside a stats arena
@@ -1203,7 +1244,7 @@ void stats_standalone(loco_ctx* c, const StatReq& rq, const float* x, long xbs, 
         NS sp = nstats(c, c->statsP, n);
         NS stt = nstats(c, rq.stats + (long)s0 * SB, n);
         launch_gn_tstats(x, xbs, rq.prim, 0, B, n.C, HW, G, sp.sc, sp.sh, sp.mr, 0, 0, rq.kind == ST_TAN ? 0 : 1, stt.tst,
-                         stt.tc, SB, c->red, st);
+                         stt.tc, SB, c->red, st, c->cfg.act);
     }
 }
 
@@ -1212,6 +1253,8 @@ void stats_standalone(loco_ctx* c, const StatReq& rq, const float* x, long xbs, 
 // reads as its residual.  Where the launch allows it is K-concatenated into `a`'s kernel (conv_lowp_kcat: one write-out, no
 // read-modify-write of the block output, one launch less); otherwise it runs first and `a` takes its result as residual.
 void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq* rq = nullptr, ConvArgs* second = nullptr) {
+    a.act = c->cfg.act;
+    if (a.mode == CM_GN_SILU && c->cfg.act == ACT_GELU) a.mode = CM_GN_GELU;     // the forward prologue of a GELU network
     if (second) {
         const size_t span = (size_t)c->cfg.max_batch * c->per_sample;
         ConvArgs t = a;
@@ -1565,6 +1608,94 @@ void sa_cotangent(const SA& s) {     // g_o in arenaT(o) -> g_q, g_k, g_v in are
     b.A = q; b.Bm = SG; b.sbk = T; b.sbn = 1; b.C = gk;
     attn_gemm(c, b, s.st);
 }
+
+// ------------------------------ attention over [text ; image] keys (cfg.added_kv) ------------------------------
+// The DeepFloyd-IF AttentionBlock (diffusers AttnAddedKVProcessor): P = softmax_j(scale q^T [K_text | k]) over Lp + T
+// columns (the Lp - L padding columns carry -1e30), o = [V_text | v] P^T.  K_text / V_text [C][Lp] are constants of the
+// prompt (loco_set_context), so tangents / cotangents reach them through q only.  Strided products on column ranges of
+// one score matrix S [NH][T][Lp + T] per sample; q / k / v of head h start HS floats apart inside `op.qkv`.
+struct AKV {
+    loco_ctx* c; const Op* op; int B, T, NH, CH, Lp, Tk; long HS, SS, KS; float scale; hipStream_t st;
+};
+AKV akv_of(loco_ctx* c, const Op& op, int B, hipStream_t st) {
+    AKV s; s.c = c; s.op = &op; s.B = B; s.st = st;
+    const Tens& t = c->tens[op.in];
+    s.T = t.H * t.W; s.NH = op.heads; s.CH = t.C / op.heads; s.Lp = c->ctx_Lp; s.Tk = s.Lp + s.T;
+    s.HS = 3L * s.CH * s.T; s.SS = (long)s.T * s.Tk; s.KS = (long)s.CH * s.Lp;
+    s.scale = 1.0f / std::sqrt((float)s.CH);
+    return s;
+}
+// S[b][h][i][col0 + j] (+)= alpha * sum_c X[b][h][c][i] K[.][h][c][j]     X: q-like [CH][T] per head (head stride xh)
+void akv_scores(const AKV& s, const float* X, long xb, long xh, const float* K, long kb, long kh, int kcols, float* S, long sb,
+                int col0, int N, float alpha, float beta, bool mask, bool exact) {
+    GemmArgs g; std::memset(&g, 0, sizeof(g));
+    g.A = X; g.sam = 1; g.sak = s.T; g.sab = xb; g.sah = xh;
+    g.Bm = K; g.sbk = kcols; g.sbn = 1; g.sbb = kb; g.sbh = kh;
+    g.C = S + col0; g.scm = s.Tk; g.scn = 1; g.scb = sb; g.sch = s.SS;
+    g.M = s.T; g.N = N; g.K = s.CH; g.batch = s.B; g.batch2 = s.NH; g.alpha = alpha; g.beta = beta;
+    g.colbias = mask ? s.c->ctx_colbias : nullptr;
+    if (exact) launch_gemm(g, s.st); else attn_gemm(s.c, g, s.st);
+}
+// O[b][h][c][i] (+)= sum_j V[.][h][c][j] S[b][h][i][col0 + j]
+void akv_values(const AKV& s, const float* V, long vb, long vh, int vcols, const float* S, long sb, int col0, int K, float* O,
+                long ob, long oh, float beta, bool exact) {
+    GemmArgs g; std::memset(&g, 0, sizeof(g));
+    g.A = V; g.sam = vcols; g.sak = 1; g.sab = vb; g.sah = vh;
+    g.Bm = S + col0; g.sbk = 1; g.sbn = s.Tk; g.sbb = sb; g.sbh = s.SS;
+    g.C = O; g.scm = s.T; g.scn = 1; g.scb = ob; g.sch = oh;
+    g.M = s.CH; g.N = s.T; g.K = K; g.batch = s.B; g.batch2 = s.NH; g.alpha = 1.f; g.beta = beta;
+    if (exact) launch_gemm(g, s.st); else attn_gemm(s.c, g, s.st);
+}
+// G[b][h][c][j] = sum_i X[.][h][c][i] S[b][h][i][col0 + j]            (g_v = g_o P, g_k = q g_S)
+void akv_keys(const AKV& s, const float* X, long xb, long xh, const float* S, long sb, int col0, float* G, long gb, long gh) {
+    GemmArgs g; std::memset(&g, 0, sizeof(g));
+    g.A = X; g.sam = s.T; g.sak = 1; g.sab = xb; g.sah = xh;
+    g.Bm = S + col0; g.sbk = s.Tk; g.sbn = 1; g.sbb = sb; g.sbh = s.SS;
+    g.C = G; g.scm = s.T; g.scn = 1; g.scb = gb; g.sch = gh;
+    g.M = s.CH; g.N = s.T; g.K = s.T; g.batch = s.B; g.batch2 = s.NH; g.alpha = 1.f; g.beta = 0.f;
+    attn_gemm(s.c, g, s.st);
+}
+void akv_forward(const AKV& s, float* ar, long bs) {           // q, k, v in ar(qkv) -> P in ar(S), o in ar(o)
+    loco_ctx* c = s.c; const Op& op = *s.op;
+    float* q = ar + c->tens[op.qkv].off; float* k = q + (long)s.CH * s.T; float* v = k + (long)s.CH * s.T;
+    float* S = ar + c->tens[op.S].off; float* o = ar + c->tens[op.o].off;
+    akv_scores(s, q, bs, s.HS, op.xK, 0, s.KS, s.Lp, S, bs, 0, s.Lp, s.scale, 0.f, true, true);
+    akv_scores(s, q, bs, s.HS, k, bs, s.HS, s.T, S, bs, s.Lp, s.T, s.scale, 0.f, false, false);
+    launch_softmax_rows(S, (long)s.NH * s.T, s.Tk, s.st, s.B, bs);
+    akv_values(s, v, bs, s.HS, s.T, S, bs, s.Lp, s.T, o, bs, (long)s.CH * s.T, 0.f, false);
+    akv_values(s, op.xV, 0, s.KS, s.Lp, S, bs, 0, s.Lp, o, bs, (long)s.CH * s.T, 1.f, true);
+}
+void akv_tangent(const AKV& s) {        // dq, dk, dv in arenaT(qkv) -> do in arenaT(o); primal in arenaP (B = 1)
+    loco_ctx* c = s.c; const Op& op = *s.op;
+    const long PS = c->per_sample, OS = (long)s.CH * s.T;
+    float* q = c->arenaP + c->tens[op.qkv].off; float* k = q + OS; float* v = k + OS;
+    float* dq = c->arenaT + c->tens[op.qkv].off; float* dk = dq + OS; float* dv = dk + OS;
+    float* SP = c->arenaP + c->tens[op.S].off; float* ST = c->arenaT + c->tens[op.S].off;
+    float* oT = c->arenaT + c->tens[op.o].off;
+    akv_scores(s, dq, PS, s.HS, op.xK, 0, s.KS, s.Lp, ST, PS, 0, s.Lp, 1.f, 0.f, false, true);       // dS_text = dq^T K_text
+    akv_scores(s, dq, PS, s.HS, k, 0, s.HS, s.T, ST, PS, s.Lp, s.T, 1.f, 0.f, false, false);         // dS_img = dq^T k
+    akv_scores(s, q, 0, s.HS, dk, PS, s.HS, s.T, ST, PS, s.Lp, s.T, 1.f, 1.f, false, false);         //        + q^T dk
+    launch_softmax_jac(ST, SP, (long)s.NH * s.T, s.Tk, (long)s.NH * s.T, s.scale, s.st, s.B, PS);
+    akv_values(s, dv, PS, s.HS, s.T, SP, 0, s.Lp, s.T, oT, PS, OS, 0.f, false);                      // do = dv P_img^T
+    akv_values(s, v, 0, s.HS, s.T, ST, PS, s.Lp, s.T, oT, PS, OS, 1.f, false);                       //    + v dP_img^T
+    akv_values(s, op.xV, 0, s.KS, s.Lp, ST, PS, 0, s.Lp, oT, PS, OS, 1.f, true);                     //    + V_text dP_text^T
+}
+void akv_cotangent(const AKV& s) {      // g_o in arenaT(o) -> g_q, g_k, g_v in arenaT(qkv)
+    loco_ctx* c = s.c; const Op& op = *s.op;
+    const long PS = c->per_sample, OS = (long)s.CH * s.T;
+    float* q = c->arenaP + c->tens[op.qkv].off; float* k = q + OS; float* v = k + OS;
+    float* gq = c->arenaT + c->tens[op.qkv].off; float* gk = gq + OS; float* gv = gk + OS;
+    float* SP = c->arenaP + c->tens[op.S].off; float* SG = c->arenaT + c->tens[op.S].off;
+    float* oG = c->arenaT + c->tens[op.o].off;
+    akv_keys(s, oG, PS, OS, SP, 0, s.Lp, gv, PS, s.HS);                                              // g_v = g_o P_img
+    akv_scores(s, oG, PS, OS, op.xV, 0, s.KS, s.Lp, SG, PS, 0, s.Lp, 1.f, 0.f, false, true);         // g_P_text = g_o^T V_text
+    akv_scores(s, oG, PS, OS, v, 0, s.HS, s.T, SG, PS, s.Lp, s.T, 1.f, 0.f, false, false);           // g_P_img = g_o^T v
+    launch_softmax_jac(SG, SP, (long)s.NH * s.T, s.Tk, (long)s.NH * s.T, s.scale, s.st, s.B, PS);
+    akv_values(s, k, 0, s.HS, s.T, SG, PS, s.Lp, s.T, gq, PS, s.HS, 0.f, false);                     // g_q = k g_S_img^T
+    akv_values(s, op.xK, 0, s.KS, s.Lp, SG, PS, 0, s.Lp, gq, PS, s.HS, 1.f, true);                   //     + K_text g_S_text^T
+    akv_keys(s, q, 0, s.HS, SG, PS, s.Lp, gk, PS, s.HS);                                             // g_k = q g_S_img
+}
+
 // y[Cout][T] (+ bias, + residual) = W x[Cin][T] as a 1x1 conv; dgrad: the transposed map
 void lin1x1(loco_ctx* c, const ConvP& w, bool dgrad, const float* in, long in_bs, int Cin, float* out, long out_bs, int Cout,
             int H, int W, int B, const float* res, long res_bs, bool with_bias, hipStream_t st, const StatReq* rq = nullptr) {
@@ -1587,7 +1718,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
     auto next_fwd = [&](int tid) { return req_fwd_of(c, tid, stats); };   // forward statistics for the consumer of `tid` (+ kept partials of a concatenation part)
     if (cfg.arch < 2) {
         launch_temb(t, cfg.ch, cfg.ch * 4, c->freq, c->td0w, c->td0b, c->td1w, c->td1b, c->tact, st, cfg.arch == 1,
-                    c->has_cond ? c->cond_add : nullptr, t_ptr);
+                    c->has_cond ? c->cond_add : nullptr, t_ptr, cfg.act);
         launch_temb_proj(c->tact, cfg.ch * 4, c->tp_w, c->tp_b, (int)c->tproj_total, c->tproj, st);
     }
     for (auto& op : c->ops) {
@@ -1628,7 +1759,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 if (op.updown == 1) {
                     // h = conv(avg_pool(silu(gn(x)))), x' = avg_pool(x)      (unet.py:198-200, 239-244)
                     launch_gn_apply(4, nullptr, 0, p.T(op.in), p.bs(), nullptr, 0, p.T(op.a1), p.bs(), 0, B, ti.C, HWi,
-                                    cfg.gn_groups, s1.sc, s1.sh, s1.mr, SB, SB, nullptr, 0, st);
+                                    cfg.gn_groups, s1.sc, s1.sh, s1.mr, SB, SB, nullptr, 0, st, cfg.act);
                     launch_pool2x2_sum(p.T(op.a1), p.bs(), p.T(op.ap), p.bs(), 0, B, ti.C, to.H, to.W, st, 0.25f);
                     launch_pool2x2_sum(p.T(op.in), p.bs(), p.T(op.xu), p.bs(), 0, B, ti.C, to.H, to.W, st, 0.25f);
                     a.in = p.T(op.ap); a.in_bs = p.bs(); a.Hin = to.H; a.Win = to.W;
@@ -1658,6 +1789,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 ConvArgs b; conv_defaults(b);
                 b.in = p.T(op.h1); b.in_bs = p.bs(); b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
                 setw(b, op.c2, false); b.bias = op.c2.bias; b.res = xin; b.res_bs = p.bs();
+                b.res_scale = op.has_nin ? 1.f : c->res_scale;        // (shortcut + h) * res_scale: c2 / nin carry it in their weights
                 b.mode = CM_GN_SILU; b.sc = s2.sc; b.sh = s2.sh; b.scsh_bs = SB;
                 b.out = p.T(op.out); b.out_bs = p.bs(); b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
                 const StatReq rq = next_fwd(op.out);
@@ -1678,6 +1810,10 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 // per head h: q = qkv[h*3*CH ...], k = +CH, v = +2CH channels (QKVAttentionLegacy, unet.py:346;
                 // with one head this is the [q|k|v] stacking of the fused DDPM projection)
                 float* q = p.T(op.qkv); float* k = q + (long)CH * T; float* v = k + (long)CH * T;
+                if (op.added_kv) {
+                    if (!c->has_ctx) { c->err = "this architecture attends over the prompt's states: call loco_set_context first"; return -1; }
+                    akv_forward(akv_of(c, op, B, st), arena, p.bs());
+                } else {
                 GemmArgs g; std::memset(&g, 0, sizeof(g));
                 g.A = q; g.sam = 1; g.sak = T; g.sab = p.bs(); g.sah = 3L * CH * T;
                 g.Bm = k; g.sbk = T; g.sbn = 1; g.sbb = p.bs(); g.sbh = 3L * CH * T;
@@ -1691,6 +1827,7 @@ int forward_pass(loco_ctx* c, const float* x, float t, int B, float* arena, floa
                 h.C = p.T(op.o); h.scm = T; h.scn = 1; h.scb = p.bs(); h.sch = (long)CH * T;
                 h.M = CH; h.N = T; h.K = T; h.batch = B; h.batch2 = NH; h.alpha = 1.f; h.beta = 0.f;
                 attn_gemm(c, h, st);
+                }
                 ConvArgs pr; conv_defaults(pr);
                 pr.in = p.T(op.o); pr.in_bs = p.bs(); pr.Cin = C; pr.Hin = to.H; pr.Win = to.W;
                 setw(pr, op.proj, false); pr.bias = op.proj.bias; pr.pad = 0;
@@ -1860,7 +1997,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                     NS sp = nstats(c, c->statsP, op.n1);
                     NS stt = nstats(c, c->statsT, op.n1);
                     launch_gn_apply(5, TT(op.in), PS, TP(op.in), 0, nullptr, 0, TT(op.a1), PS, 0, B, ti.C, HWi,
-                                    cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                                    cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st, cfg.act);
                     launch_pool2x2_sum(TT(op.a1), PS, TT(op.ap), PS, 0, B, ti.C, to.H, to.W, st, 0.25f);
                     launch_pool2x2_sum(TT(op.in), PS, TT(op.xu), PS, 0, B, ti.C, to.H, to.W, st, 0.25f);
                     a.in = TT(op.ap); a.in_bs = PS; a.Hin = to.H; a.Win = to.W;
@@ -1888,6 +2025,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 ConvArgs b; conv_defaults(b);
                 b.in = TT(op.h1); b.in_bs = PS; b.Cin = to.C; b.Hin = to.H; b.Win = to.W;
                 setw(b, op.c2, false); b.res = xin; b.res_bs = PS;
+                b.res_scale = op.has_nin ? 1.f : c->res_scale;
                 set_tan(c, b, op.n2, TP(op.h1));
                 b.out = TT(op.out); b.out_bs = PS; b.Cout = to.C; b.Hout = to.H; b.Wout = to.W; b.B = B;
                 const StatReq rq = next_tan(op.out);
@@ -1910,8 +2048,9 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 const long HS = 3L * CH * T, SS = (long)T * T;
                 float* q = TP(op.qkv); float* k = q + (long)CH * T; float* v = k + (long)CH * T;
                 float* dq = TT(op.qkv); float* dk = dq + (long)CH * T; float* dv = dk + (long)CH * T;
-                const bool flash = c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH);
-                if (flash) {        // do from dq, dk, dv and the primal P / o in one kernel, no [T x T] tangent (attn_flash.hip)
+                const bool flash = (c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH)) || op.added_kv;   // added_kv: its own products
+                if (op.added_kv) akv_tangent(akv_of(c, op, B, st));
+                else if (flash) {   // do from dq, dk, dv and the primal P / o in one kernel, no [T x T] tangent (attn_flash.hip)
                     AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
                     fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = 1.0f / std::sqrt((float)CH);
                     fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = TP(op.S); fa.o = TP(op.o);
@@ -2037,7 +2176,7 @@ void cot_stats(loco_ctx* c, const NormP& n, const float* d, long dbs, const floa
     NS sp = nstats(c, c->statsP, n);
     NS stt = nstats(c, c->statsT, n);
     launch_gn_tstats(d, dbs, x, 0, B, n.C, HW, c->cfg.gn_groups, sp.sc, sp.sh, sp.mr, 0, 0, kind, stt.tst,
-                     stt.tc, c->stats_per_sample, c->red, st);
+                     stt.tc, c->stats_per_sample, c->red, st, c->cfg.act);
 }
 
 // ge: cotangent of eps [B][n]; result A[B][n] = conv_in^T(...) + gx0
@@ -2070,7 +2209,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 NS sp = nstats(c, c->statsP, op.n1);
                 NS stt = nstats(c, c->statsT, op.n1);
                 launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 0, B, ti.C, ti.H * ti.W, G,
-                                sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                                sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st, cfg.act);
                 break;
             }
             case OP_UP: {
@@ -2161,15 +2300,15 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                     if (cot_in_epilogue) { /* done by the shortcut conv */ }
                     else if (op.has_nin)
                         launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, 1, B, ti.C, HWi, G,
-                                        sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
-                    else
+                                        sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st, cfg.act);
+                    else        // identity shortcut: g_in = res_scale * g_out + norm1^T g_a1
                         launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, gsk, PS, TG(op.in), PS, acc, B, ti.C, HWi, G,
-                                        sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
+                                        sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st, cfg.act, c->res_scale);
                 } else {
                     launch_gn_apply(2, TG(op.a1), PS, TP(op.in), 0, nullptr, 0, TG(op.in), PS, acc, B, ti.C, HWi, G,
-                                    sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st);
-                    if (op.updown == 1) launch_upsample2x(gsk, PS, TG(op.in), PS, 1, 0.25f, B, ti.C, to.H, to.W, st);
-                    else launch_pool2x2_sum(gsk, PS, TG(op.in), PS, 1, B, ti.C, ti.H, ti.W, st);
+                                    sp.sc, sp.sh, sp.mr, 0, 0, stt.tst, c->stats_per_sample, st, cfg.act);
+                    if (op.updown == 1) launch_upsample2x(gsk, PS, TG(op.in), PS, 1, 0.25f * c->res_scale, B, ti.C, to.H, to.W, st);
+                    else launch_pool2x2_sum(gsk, PS, TG(op.in), PS, 1, B, ti.C, ti.H, ti.W, st, c->res_scale);
                 }
                 break;
             }
@@ -2201,8 +2340,9 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 setw(pr, op.proj, true); pr.pad = 0;
                 pr.out = TG(op.o); pr.out_bs = PS; pr.Cout = C; pr.Hout = to.H; pr.Wout = to.W; pr.B = B;
                 run_conv(c, pr, 1, st);
-                const bool flash = c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH);
-                if (flash) {        // g_q, g_k, g_v from g_o and the primal q / k / v / P / o, no [T x T] cotangent (attn_flash.hip)
+                const bool flash = (c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH)) || op.added_kv;   // added_kv: its own products
+                if (op.added_kv) akv_cotangent(akv_of(c, op, B, st));
+                else if (flash) {   // g_q, g_k, g_v from g_o and the primal q / k / v / P / o, no [T x T] cotangent (attn_flash.hip)
                     AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
                     fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = 1.0f / std::sqrt((float)CH);
                     fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = TP(op.S); fa.o = TP(op.o);
@@ -2392,6 +2532,15 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         }
         if (cfg->ch % 32) { c->err = "ch must be a multiple of 32"; return -2; }
     }
+    if (cfg->act != ACT_SILU && cfg->act != ACT_GELU) { c->err = "act must be 0 (SiLU) or 1 (GELU)"; return -2; }
+    c->res_scale = cfg->res_scale == 0.f ? 1.f : cfg->res_scale;
+    if ((cfg->act != ACT_SILU || c->res_scale != 1.f || cfg->added_kv) && cfg->arch != 1) {
+        c->err = "act / res_scale / added_kv belong to the guided-diffusion family (arch 1)"; return -2;
+    }
+    if (cfg->added_kv && (cfg->context_dim <= 0 || cfg->context_len <= 0 || cfg->transformer_depth != 0 ||
+                          cfg->context_dim % cfg->gn_groups)) {
+        c->err = "added_kv needs context_dim (a multiple of gn_groups) and context_len > 0 and transformer_depth = 0"; return -2;
+    }
     if (build_program(c)) return -2;
     for (auto& op : c->ops)
         if (op.kind == OP_RES && op.updown && op.has_nin) { c->err = "resampling ResBlock with a channel change is not supported"; return -2; }
@@ -2445,7 +2594,7 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
         const char* e = getenv("LOCO_FUSE_STATS");
         c->fuse_stats = !(e && atoi(e) == 0);
         e = getenv("LOCO_FUSE_COT");
-        c->fuse_cot = !(e && atoi(e) == 0);
+        c->fuse_cot = !(e && atoi(e) == 0) && cfg->act == ACT_SILU;     // the epilogue term is written for SiLU
         e = getenv("LOCO_DEEP1");
         c->deep1 = !(e && atoi(e) == 0);
         e = getenv("LOCO_FUSE_XATTN");
@@ -2649,12 +2798,12 @@ int loco_pmp_primal(loco_ctx* c, const float* x, float t, float at, const uint8_
             const int HW = ti.H * ti.W, G = c->cfg.gn_groups;
             NS s1 = nstats(c, c->statsP, op.n1);
             launch_gn_cache(c->arenaP + ti.off, op.n1.C, HW, op.n1.C / G, s1.sc, s1.sh, s1.mr,
-                            c->sxcache + op.n1.sx_off, st);
+                            c->sxcache + op.n1.sx_off, st, c->cfg.act);
             if (op.kind == OP_RES) {
                 const Tens& th = c->tens[op.h1];
                 NS s2 = nstats(c, c->statsP, op.n2);
                 launch_gn_cache(c->arenaP + th.off, op.n2.C, th.H * th.W, op.n2.C / G, s2.sc, s2.sh, s2.mr,
-                                c->sxcache + op.n2.sx_off, st);
+                                c->sxcache + op.n2.sx_off, st, c->cfg.act);
             }
         }
     }
@@ -2888,16 +3037,22 @@ int loco_set_context(loco_ctx* c, const float* tokens, void* stream) {
         for (int l = 0; l < L; ++l) cb[l] = 0.f;
         if (upload(c, &c->ctx_colbias, cb)) return -1;
     }
+    if (c->cfg.added_kv && !c->ctx_norm && dalloc(c, &c->ctx_norm, (size_t)L * D)) return -1;
     for (auto& op : c->ops) {
-        if (!((op.kind == OP_ATTN && op.has_x) || op.kind == OP_XFMR)) continue;
+        if (!((op.kind == OP_ATTN && (op.has_x || op.added_kv)) || op.kind == OP_XFMR)) continue;
         const int C = c->tens[op.in].C;
+        const float* tok = tokens;
+        if (op.added_kv) {      // the block's own GroupNorm over the states [D][L] (norm_encoder), then encoder_kv
+            launch_ctx_groupnorm(tokens, L, D, c->cfg.gn_groups, c->cfg.gn_eps, op.xng, op.xnb, c->ctx_norm, st);
+            tok = c->ctx_norm;
+        }
         for (int w = 0; w < 2; ++w) {
             float* dst = w ? op.xV : op.xK;
             HIPCHK(c, hipMemsetAsync(dst, 0, (size_t)C * Lp * sizeof(float), st));
             // dst[c][l] = sum_d W[c][d] tokens[l][d] + b[c]
             GemmArgs g; std::memset(&g, 0, sizeof(g));
             g.A = w ? op.xvw : op.xkw; g.sam = D; g.sak = 1;
-            g.Bm = tokens; g.sbk = 1; g.sbn = D;
+            g.Bm = tok; g.sbk = 1; g.sbn = D;
             g.C = dst; g.scm = Lp; g.scn = 1;
             g.bias = w ? op.xvb : op.xkb;
             g.M = C; g.N = L; g.K = D; g.batch = 1; g.alpha = 1.f; g.beta = 0.f;

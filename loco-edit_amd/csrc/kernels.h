@@ -27,7 +27,22 @@ enum ConvMode : int {
     CM_GN = 2,        // a = sc*x + sh                               (forward, AttnBlock norm->q/k/v)
     CM_TAN_SILU = 3,  // a = silu'(y) * sc*(d - m1 - xh*m2)          (tangent of norm->swish)
     CM_COT_SILU = 4,  // a = rstd*(gamma*silu'(y)*d - m1 - xh*m2)    (cotangent of norm->swish, fused into next dgrad)
+    CM_GN_GELU = 5,   // a = gelu(sc*x + sh)                         (forward of the DeepFloyd-IF blocks: exact erf GELU)
 };
+// Activation of the norm -> activation -> conv chains of one network (ConvArgs::act and the `act` argument of the
+// elementwise launchers): every "silu" in the mode / kind descriptions below reads as this function.  The low-precision
+// conv kernels take it as a MODE (CM_GN_SILU / CM_GN_GELU forward; their tangent / cotangent modes read act'(y) from the
+// primal cache of launch_gn_cache), everything else as a wave-uniform runtime switch.
+enum ActKind : int { ACT_SILU = 0, ACT_GELU = 1 };
+__device__ __forceinline__ float act_fwd(float y, int act) {
+    if (act == ACT_GELU) return 0.5f * y * (1.0f + erff(y * 0.70710678118654752f));
+    return y * (1.0f / (1.0f + __expf(-y)));
+}
+__device__ __forceinline__ float act_der(float y, int act) {
+    if (act == ACT_GELU) return 0.5f * (1.0f + erff(y * 0.70710678118654752f)) + y * 0.39894228040143268f * __expf(-0.5f * y * y);
+    const float sg = 1.0f / (1.0f + __expf(-y));
+    return sg * (1.0f + y * (1.0f - sg));
+}
 
 // GroupNorm statistics of a conv's OUTPUT tensor for the norm that consumes it (engine.hip StatReq):
 //   ST_FWD: mean / rstd -> mr, sc, sh           ST_TAN: m1 = mean(d), m2 = mean(xhat d) -> tst, tc
@@ -86,6 +101,8 @@ struct ConvArgs {
     // pass over the tensor (ResBlock cotangent: g_in = nin^T g_out + norm1^T g_a1 in one write-out).  nullptr: none.
     const float* cot_d; long cot_d_bs; const float* cot_x;
     const float* cot_sc; const float* cot_sh; const float* cot_mr; const float* cot_tst; long cot_tst_bs; int cot_cpg;
+    int act;           // ActKind of the prologue modes (exact-fp32 kernel, split-K statistics epilogue)
+    float res_scale;   // out = conv + bias + res_scale * res  (DeepFloyd-IF: (x + h) / sqrt 2 with the conv's weights pre-scaled); conv_defaults: 1
 };
 
 // the conv kernel only; when a.nsplit > 1 the caller follows with launch_conv_splitk_reduce (run_conv does)
@@ -106,7 +123,7 @@ extern int g_bf16_tile_override;
 void launch_fill_random(float* p, long count, unsigned seed, float scale, hipStream_t st);
 // sx[c][hw] = { sc_c * silu'(sc_c*x + sh_c), (x - mean_g) * rstd_g }   (B = 1 primal cache)
 void launch_gn_cache(const float* x, int C, int HW, int cpg, const float* sc, const float* sh, const float* mr,
-                     float2* sx, hipStream_t st);
+                     float2* sx, hipStream_t st, int act = 0);
 // name of the kernel variant launch_conv would pick (for the per-kernel profile)
 const char* conv_variant_name(const ConvArgs& a, int taps, int prec);
 // workspace (floats) a conv launch with these args needs for split-K partials
@@ -207,7 +224,7 @@ void launch_conv_splitk_reduce_stats(const ConvArgs& a, int kind, int G, float e
 //   tst[b][g] = { mean_g(z), mean_g(xh * z) },  xh = (x - mean)*rstd of the primal (prim_bs may be 0)
 void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int B, int C, int HW, int G,
                       const float* sc, const float* sh, const float* mr, long pbs_c, long pbs_g,
-                      int kind, float* tst, float* tc, long tst_bs, double* scratch, hipStream_t st);
+                      int kind, float* tst, float* tc, long tst_bs, double* scratch, hipStream_t st, int act = 0);
 // elementwise GroupNorm applications (no conv behind them):
 //   kind 0: out = sc*x + sh                                    (attention norm forward)
 //   kind 1: out = sc*(d - m1 - xh*m2)                          (attention norm tangent)
@@ -218,7 +235,13 @@ void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int 
 void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x_bs,
                      const float* base, long base_bs, float* out, long out_bs, int accumulate,
                      int B, int C, int HW, int G, const float* sc, const float* sh, const float* mr,
-                     long pbs_c, long pbs_g, const float* tst, long tst_bs, hipStream_t st);
+                     long pbs_c, long pbs_g, const float* tst, long tst_bs, hipStream_t st, int act = 0,
+                     float base_scale = 1.0f);      // kinds 2, 3: base_scale * base
+
+// GroupNorm of encoder states given token-major: tok [L][D] -> out [L][D], statistics per group of D / G channels over all
+// L tokens (the `norm_encoder` of the DeepFloyd-IF attention blocks: GroupNorm on [D][L])
+void launch_ctx_groupnorm(const float* tok, int L, int D, int G, float eps, const float* gamma, const float* beta,
+                          float* out, hipStream_t st);
 
 // ---- attention helpers ------------------------------------------------------
 // rows: [R][T] contiguous; softmax over T in place (S -> P)
@@ -232,7 +255,8 @@ void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows
 void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
                  const float* w1, const float* b1, float* scratch, hipStream_t st, int cos_first = 0,
                  const float* add = nullptr,      // add[temb_ch]: conditioning embedding added to emb before the SiLU
-                 const float* t_ptr = nullptr);   // non-null: read the timestep from device memory (graph replay)
+                 const float* t_ptr = nullptr,    // non-null: read the timestep from device memory (graph replay)
+                 int act = 0);
 void launch_set_scalar(float* p, float v, hipStream_t st);
 void launch_clock_stamp(unsigned long long* out2, hipStream_t st);   // {s_memtime, s_memrealtime}
 void launch_temb_proj(const float* tact, int temb_ch, const float* w, const float* b, int cout,

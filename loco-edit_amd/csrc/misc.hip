@@ -33,11 +33,7 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
     return r;
 }
-__device__ __forceinline__ float sigm(float y) { return 1.0f / (1.0f + __expf(-y)); }
-__device__ __forceinline__ float dsilu(float y) {
-    float sg = sigm(y);
-    return sg * (1.0f + y * (1.0f - sg));
-}
+// activation and its derivative: act_fwd / act_der of kernels.h (ACT_SILU, ACT_GELU), a wave-uniform switch in these kernels
 
 // ---------------------------------------------------------------------------
 // GroupNorm statistics.  grid = (nsplit, G, B).  Each block reduces a 16B-aligned
@@ -143,7 +139,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void gn_tstats_partial(const float* d, long d_bs, const float* x, long x_bs,
                                                          int HW, int cpg, const float* sc, const float* sh,
                                                          const float* mr, long pbs_c, long pbs_g,
-                                                         double* scratch, float* tst, float* tc, long tbs) {
+                                                         double* scratch, float* tst, float* tc, long tbs, int act) {
     __shared__ double sm[4];
     const int s = blockIdx.x, nsplit = gridDim.x, g = blockIdx.y, b = blockIdx.z, G = gridDim.y;
     const long len = (long)cpg * HW;
@@ -168,7 +164,7 @@ __global__ __launch_bounds__(256) void gn_tstats_partial(const float* d, long d_
             float xh = (xx[j] - mean) * rstd;
             float z;
             if (KIND == 0) z = dd[j];
-            else if (KIND == 1) z = (scc / rstd) * dsilu(fmaf(scc, xx[j], shc)) * dd[j];
+            else if (KIND == 1) z = (scc / rstd) * act_der(fmaf(scc, xx[j], shc), act) * dd[j];
             else z = (scc / rstd) * dd[j];
             a1 += z;
             a2 += xh * z;
@@ -226,20 +222,20 @@ __global__ void gn_tstats_finalize(const double* scratch, int nsplit, long BG, i
 
 void launch_gn_tstats(const float* d, long d_bs, const float* x, long x_bs, int B, int C, int HW, int G,
                       const float* sc, const float* sh, const float* mr, long pbs_c, long pbs_g, int kind,
-                      float* tst, float* tc, long tst_bs, double* scratch, hipStream_t st) {
+                      float* tst, float* tc, long tst_bs, double* scratch, hipStream_t st, int act) {
     int cpg = C / G;
     long len = (long)cpg * HW;
     int ns = gn_nsplit(len, B * G);
     dim3 grid(ns, G, B);
     if (kind == 0)
         hipLaunchKernelGGL(gn_tstats_partial<0>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, HW, cpg, sc, sh, mr,
-                           pbs_c, pbs_g, scratch, tst, tc, tst_bs);
+                           pbs_c, pbs_g, scratch, tst, tc, tst_bs, act);
     else if (kind == 1)
         hipLaunchKernelGGL(gn_tstats_partial<1>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, HW, cpg, sc, sh, mr,
-                           pbs_c, pbs_g, scratch, tst, tc, tst_bs);
+                           pbs_c, pbs_g, scratch, tst, tc, tst_bs, act);
     else
         hipLaunchKernelGGL(gn_tstats_partial<2>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, HW, cpg, sc, sh, mr,
-                           pbs_c, pbs_g, scratch, tst, tc, tst_bs);
+                           pbs_c, pbs_g, scratch, tst, tc, tst_bs, act);
     if (ns == 1) return;
     long BG = (long)B * G;
     hipLaunchKernelGGL(gn_tstats_finalize, dim3((unsigned)((BG + 255) / 256)), dim3(256), 0, st, scratch, ns, BG,
@@ -394,7 +390,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_stats_kernel(ConvArgs a, i
         if (a.bias) add += a.bias[c];
         if (a.bias2) add += a.bias2[(long)b * a.bias2_bs + c];
         v += add;
-        if (a.res) v += *reinterpret_cast<const f32x4_t*>(a.res + (long)b * a.res_bs + e);
+        if (a.res) v += a.res_scale * *reinterpret_cast<const f32x4_t*>(a.res + (long)b * a.res_bs + e);
         float* o = a.out + (long)b * a.out_bs + e;
         if (a.accumulate) v += *reinterpret_cast<const f32x4_t*>(o);
         *reinterpret_cast<f32x4_t*>(o) = v;
@@ -410,7 +406,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_stats_kernel(ConvArgs a, i
             for (int j = 0; j < 4; ++j) {
                 const float xh = (xv[j] - mean_p) * rstd_p;
                 float z = v[j];
-                if (KIND == ST_COT) z *= (scc / rstd_p) * dsilu(fmaf(scc, xv[j], shc));
+                if (KIND == ST_COT) z *= (scc / rstd_p) * act_der(fmaf(scc, xv[j], shc), a.act);
                 a1 += z;
                 a2 += xh * z;
             }
@@ -520,7 +516,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* d, long d_bs
                                                        const float* base, long base_bs, float* out, long out_bs,
                                                        int accumulate, int C, int HW, int cpg, const float* sc,
                                                        const float* sh, const float* mr, long pbs_c, long pbs_g,
-                                                       const float* tst, long tbs) {
+                                                       const float* tst, long tbs, int act, float base_scale) {
     const int b = blockIdx.y;
     const long per = (long)C * HW;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per; i += (long)gridDim.x * 1024) {
@@ -535,7 +531,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* d, long d_bs
             for (int j = 0; j < 4; ++j) r[j] = fmaf(scc, xx[j], shc);
         } else if (KIND == 4) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { float y = fmaf(scc, xx[j], shc); r[j] = y * sigm(y); }
+            for (int j = 0; j < 4; ++j) r[j] = act_fwd(fmaf(scc, xx[j], shc), act);
         } else {
             float mean = mr[(long)b * pbs_g + 2 * g], rstd = mr[(long)b * pbs_g + 2 * g + 1];
             float m1 = tst[(long)b * tbs + g * 2], m2 = tst[(long)b * tbs + g * 2 + 1];
@@ -544,15 +540,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* d, long d_bs
             float bb[4] = {0.f, 0.f, 0.f, 0.f};
             if (KIND >= 2 && base) {
                 float4 bv = *reinterpret_cast<const float4*>(base + (long)b * base_bs + i);
-                bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+                bb[0] = base_scale * bv.x; bb[1] = base_scale * bv.y; bb[2] = base_scale * bv.z; bb[3] = base_scale * bv.w;
             }
             float gm = scc / rstd;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float xh = (xx[j] - mean) * rstd;
                 if (KIND == 1) r[j] = scc * (dd[j] - m1 - xh * m2);
-                else if (KIND == 5) r[j] = dsilu(fmaf(scc, xx[j], shc)) * scc * (dd[j] - m1 - xh * m2);
-                else if (KIND == 2) r[j] = bb[j] + rstd * (gm * dsilu(fmaf(scc, xx[j], shc)) * dd[j] - m1 - xh * m2);
+                else if (KIND == 5) r[j] = act_der(fmaf(scc, xx[j], shc), act) * scc * (dd[j] - m1 - xh * m2);
+                else if (KIND == 2) r[j] = bb[j] + rstd * (gm * act_der(fmaf(scc, xx[j], shc), act) * dd[j] - m1 - xh * m2);
                 else r[j] = bb[j] + rstd * (gm * dd[j] - m1 - xh * m2);
             }
         }
@@ -568,14 +564,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* d, long d_bs
 void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x_bs, const float* base,
                      long base_bs, float* out, long out_bs, int accumulate, int B, int C, int HW, int G,
                      const float* sc, const float* sh, const float* mr, long pbs_c, long pbs_g, const float* tst,
-                     long tst_bs, hipStream_t st) {
+                     long tst_bs, hipStream_t st, int act, float base_scale) {
     long per = (long)C * HW;
     int blocks = (int)((per / 4 + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     dim3 grid(blocks, B);
     int cpg = C / G;
 #define GA(K) hipLaunchKernelGGL(gn_apply_kernel<K>, grid, dim3(256), 0, st, d, d_bs, x, x_bs, base, base_bs, out, \
-                                 out_bs, accumulate, C, HW, cpg, sc, sh, mr, pbs_c, pbs_g, tst, tst_bs)
+                                 out_bs, accumulate, C, HW, cpg, sc, sh, mr, pbs_c, pbs_g, tst, tst_bs, act, base_scale)
     switch (kind) {
         case 0: GA(0); break;
         case 1: GA(1); break;
@@ -589,7 +585,7 @@ void launch_gn_apply(int kind, const float* d, long d_bs, const float* x, long x
 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_cache_kernel(const float* x, int C, int HW, int cpg, const float* sc,
-                                                       const float* sh, const float* mr, float2* sx) {
+                                                       const float* sh, const float* mr, float2* sx, int act) {
     const long per = (long)C * HW;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per; i += (long)gridDim.x * 1024) {
         int c = (int)(i / HW);
@@ -601,7 +597,7 @@ __global__ __launch_bounds__(256) void gn_cache_kernel(const float* x, int C, in
         float r[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            r[2 * j] = scc * dsilu(fmaf(scc, xx[j], shc));
+            r[2 * j] = scc * act_der(fmaf(scc, xx[j], shc), act);
             r[2 * j + 1] = (xx[j] - mean) * rstd;
         }
         o0 = make_float4(r[0], r[1], r[2], r[3]);
@@ -612,11 +608,39 @@ __global__ __launch_bounds__(256) void gn_cache_kernel(const float* x, int C, in
     }
 }
 void launch_gn_cache(const float* x, int C, int HW, int cpg, const float* sc, const float* sh, const float* mr,
-                     float2* sx, hipStream_t st) {
+                     float2* sx, hipStream_t st, int act) {
     long per = (long)C * HW;
     int blocks = (int)((per / 4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gn_cache_kernel, dim3(blocks), dim3(256), 0, st, x, C, HW, cpg, sc, sh, mr, sx);
+    hipLaunchKernelGGL(gn_cache_kernel, dim3(blocks), dim3(256), 0, st, x, C, HW, cpg, sc, sh, mr, sx, act);
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm of token-major encoder states (kernels.h launch_ctx_groupnorm): one workgroup per group, two passes in double
+__global__ __launch_bounds__(256) void ctx_groupnorm_kernel(const float* tok, int L, int D, int cpg, float eps,
+                                                            const float* gamma, const float* beta, float* out) {
+    __shared__ double sm[4];
+    const int g = blockIdx.x, n = L * cpg;
+    double s1 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s1 += (double)tok[(long)(i / cpg) * D + g * cpg + (i % cpg)];
+    const double mean = block_sum(s1, sm) / (double)n;
+    __syncthreads();
+    double s2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double d = (double)tok[(long)(i / cpg) * D + g * cpg + (i % cpg)] - mean;
+        s2 += d * d;
+    }
+    const double var = block_sum(s2, sm) / (double)n;
+    const float mf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = g * cpg + (i % cpg);
+        const long o = (long)(i / cpg) * D + c;
+        out[o] = (tok[o] - mf) * rstd * gamma[c] + beta[c];
+    }
+}
+void launch_ctx_groupnorm(const float* tok, int L, int D, int G, float eps, const float* gamma, const float* beta,
+                          float* out, hipStream_t st) {
+    hipLaunchKernelGGL(ctx_groupnorm_kernel, dim3(G), dim3(256), 0, st, tok, L, D, D / G, eps, gamma, beta, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -699,7 +723,7 @@ void launch_softmax_jac(float* dS, const float* P, long rows, int T, long p_rows
 // (reference diffusion.py:783-804, 154-157, and the nonlinearity(temb) of :899)
 __global__ void temb_kernel(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0,
                             const float* w1, const float* b1, float* out, int cos_first, const float* add,
-                            const float* t_ptr) {
+                            const float* t_ptr, int act) {
     extern __shared__ float sm[];
     if (t_ptr) t = *t_ptr;     // timestep from device memory: the launch is a node of a replayed HIP graph
     float* emb = sm;           // [ch]
@@ -716,21 +740,21 @@ __global__ void temb_kernel(float t, int ch, int temb_ch, const float* freq, con
     for (int o = threadIdx.x; o < temb_ch; o += blockDim.x) {
         float acc = b0[o];
         for (int i = 0; i < ch; ++i) acc = fmaf(w0[(long)o * ch + i], emb[i], acc);
-        h[o] = acc * sigm(acc);
+        h[o] = act_fwd(acc, act);
     }
     __syncthreads();
     for (int o = threadIdx.x; o < temb_ch; o += blockDim.x) {
         float acc = b1[o];
         for (int i = 0; i < temb_ch; ++i) acc = fmaf(w1[(long)o * temb_ch + i], h[i], acc);
         if (add) acc += add[o];          // conditioning embedding (class / pooled text), added to emb before the SiLU
-        out[o] = acc * sigm(acc);
+        out[o] = act_fwd(acc, act);
     }
 }
 void launch_temb(float t, int ch, int temb_ch, const float* freq, const float* w0, const float* b0, const float* w1,
                  const float* b1, float* scratch, hipStream_t st, int cos_first, const float* add,
-                 const float* t_ptr) {
+                 const float* t_ptr, int act) {
     hipLaunchKernelGGL(temb_kernel, dim3(1), dim3(512), (ch + temb_ch) * sizeof(float), st, t, ch, temb_ch, freq,
-                       w0, b0, w1, b1, scratch, cos_first, add, t_ptr);
+                       w0, b0, w1, b1, scratch, cos_first, add, t_ptr, act);
 }
 __global__ void set_scalar_kernel(float* p, float v) { *p = v; }
 // {shader-clock counter, 100 MHz wall counter} of the CU this one-lane launch lands on: two of these around a timed

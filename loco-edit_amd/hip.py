@@ -44,6 +44,7 @@ class LocoCfg(C.Structure):
         ("context_dim", C.c_int32), ("context_len", C.c_int32),
         ("scale_shift_norm", C.c_int32), ("resblock_updown", C.c_int32), ("num_heads", C.c_int32),
         ("transformer_depth", C.c_int32),
+        ("act", C.c_int32), ("res_scale", C.c_float), ("added_kv", C.c_int32),
     ]
 
 
@@ -157,6 +158,7 @@ class LocoEngine:
         c.context_dim, c.context_len = cfg.context_dim, cfg.context_len
         c.scale_shift_norm, c.resblock_updown = int(cfg.scale_shift_norm), int(cfg.resblock_updown)
         c.num_heads, c.transformer_depth = cfg.num_heads, cfg.transformer_depth
+        c.act, c.res_scale, c.added_kv = {"silu": 0, "gelu": 1}[cfg.act], float(cfg.res_scale), int(cfg.added_kv)
         self._ctx = C.c_void_p()
         rc = self.lib.loco_create(C.byref(c), C.byref(self._ctx))
         if rc != 0:
@@ -180,6 +182,8 @@ class LocoEngine:
     # ---- parameters (model.load_state_dict, reference utils.py:102-105)
     def load_state_dict(self, sd: Dict[str, "np.ndarray | torch.Tensor"]):
         for name, v in sd.items():
+            if self.cfg.encoder_dim > 0 and name.startswith(("encoder_proj.", "encoder_pooling.")):
+                continue        # the image-independent text conditioning of the IF U-Net lives on the host (tloco.IFTextConditioner)
             a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             a = np.ascontiguousarray(a, dtype=np.float32)
             shape = (C.c_int64 * a.ndim)(*a.shape)

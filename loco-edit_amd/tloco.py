@@ -49,6 +49,50 @@ def cond_params(cfg: UNetConfig, cond_dim: int, seed: int = 0) -> Dict[str, np.n
             "cond_proj.bias": (0.1 * rng.standard_normal(ted)).astype(np.float32)}
 
 
+class IFTextConditioner:
+    """The part of the IF U-Net that does not see the image: from the text encoder's states [1, L, E] (T5-XXL: 77 x 4096)
+    the context [L, D] its attention blocks read (`encoder_proj`; diffusers `encoder_hid_proj`) and the embedding [4 ch]
+    added to the time embedding (`encoder_pooling` = LayerNorm -> AttentionPooling -> Linear -> LayerNorm; diffusers
+    `add_embedding` = TextTimeEmbedding).  Once per prompt, a few small torch products on the device (host plumbing: the
+    engine takes the results through ``loco_set_context`` / ``loco_set_cond``).  Parameters: the ``encoder_proj.*`` /
+    ``encoder_pooling.*`` entries of the U-Net's state_dict (config.adm_param_shapes)."""
+    PREFIXES = ("encoder_proj.", "encoder_pooling.")
+
+    def __init__(self, params: Dict[str, "np.ndarray | torch.Tensor"], cfg: UNetConfig, device):
+        self.cfg = cfg
+        self.p = {k: torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v, dtype=torch.float32).to(device)
+                  for k, v in params.items() if k.startswith(self.PREFIXES)}
+        missing = [k for k in ("encoder_proj.weight", "encoder_pooling.1.q_proj.weight", "encoder_pooling.3.weight") if k not in self.p]
+        if missing:
+            raise KeyError(f"text conditioning parameters missing from the checkpoint: {missing}")
+
+    def __call__(self, states: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        import math
+        F = torch.nn.functional
+        p = self.p
+        x = states.to(p["encoder_proj.weight"].device, torch.float32)
+        if x.dim() == 2:
+            x = x[None]
+        E = x.shape[-1]
+        context = F.linear(x, p["encoder_proj.weight"], p["encoder_proj.bias"])[0]
+        x = F.layer_norm(x, (E,), p["encoder_pooling.0.weight"], p["encoder_pooling.0.bias"], 1e-5)
+        d = min(64, E // 2)                  # 64 channels per pooling head (att_pool_heads = 64 at E = 4096)
+        heads = E // d
+        token = x.mean(dim=1, keepdim=True) + p["encoder_pooling.1.positional_embedding"]
+        seq = torch.cat([token, x], dim=1)
+
+        def split(z):                        # [1, N, E] -> [heads, N, d]
+            return z.reshape(-1, heads, d).transpose(0, 1)
+        q = split(F.linear(token, p["encoder_pooling.1.q_proj.weight"], p["encoder_pooling.1.q_proj.bias"]))
+        k = split(F.linear(seq, p["encoder_pooling.1.k_proj.weight"], p["encoder_pooling.1.k_proj.bias"]))
+        v = split(F.linear(seq, p["encoder_pooling.1.v_proj.weight"], p["encoder_pooling.1.v_proj.bias"]))
+        w = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(d), dim=-1)          # [heads, 1, N]
+        pooled = (w @ v).transpose(0, 1).reshape(1, E)
+        pooled = F.linear(pooled, p["encoder_pooling.2.weight"], p["encoder_pooling.2.bias"])
+        aug = F.layer_norm(pooled, (pooled.shape[-1],), p["encoder_pooling.3.weight"], p["encoder_pooling.3.bias"], 1e-5)[0]
+        return context.contiguous(), aug.contiguous()
+
+
 class IFScheduler(object):
     """The scheduler the reference patches onto the IF pipeline (utils.py:159-213): squared-cosine alpha-bar
     (``betas_for_alpha_bar`` :425-441, float32), float timesteps ``linspace(0,1,N)*990``, alpha-bar looked up at
@@ -240,9 +284,12 @@ class EditDeepFloydIF(object):
         # text enters through cross-attention stages when the architecture has them (context_dim > 0: tokens
         # [context_len, context_dim] via loco_set_context), otherwise pooled through the time embedding (loco_set_cond)
         self.use_context = cfg.context_dim > 0
+        self.use_text_cond = cfg.encoder_dim > 0      # the IF U-Net: states -> (context, pooled embedding) on the host
         if pe is None:
             g = torch.Generator().manual_seed(int(getattr(args, "prompt_emb_seed", 31)))
             ntok, D = (cfg.context_len, cfg.context_dim) if self.use_context else (7, int(getattr(args, "cond_dim", 16)))
+            if self.use_text_cond:
+                D = cfg.encoder_dim
             pe = {k: torch.randn(1, ntok, D, generator=g) for k in ("for", "edit", "null")}
         self.for_prompt_emb, self.edit_prompt_emb, self.null_prompt_emb = pe["for"], pe["edit"], pe["null"]
         self.for_prompt, self.edit_prompt, self.null_prompt = args.for_prompt, args.edit_prompt, ""
@@ -265,7 +312,8 @@ class EditDeepFloydIF(object):
         if not self.use_context:
             self.cond_w = torch.as_tensor(np.asarray(params["cond_proj.weight"]), dtype=torch.float32)
             self.cond_b = torch.as_tensor(np.asarray(params["cond_proj.bias"]), dtype=torch.float32)
-        unet_params = {k: v for k, v in params.items() if not k.startswith("cond_proj.")}
+        self.text_cond = IFTextConditioner(params, cfg, self.device) if self.use_text_cond else None
+        unet_params = {k: v for k, v in params.items() if not k.startswith(("cond_proj.",) + IFTextConditioner.PREFIXES)}
         self.branches: Dict[str, LocoEngine] = {}
         prec = getattr(args, "precision", None) or os.environ.get("LOCO_PRECISION")
         for name in ("for", "edit", "null"):
@@ -308,7 +356,11 @@ class EditDeepFloydIF(object):
     def _bind(self, name: str, prompt_emb: torch.Tensor):
         key = (prompt_emb.data_ptr(), tuple(prompt_emb.shape), float(prompt_emb.sum()))
         if self._cond_of.get(name) != key:
-            if self.use_context:
+            if self.use_text_cond:
+                context, aug = self.text_cond(prompt_emb)
+                self.branches[name].set_context(context)
+                self.branches[name].set_cond(aug)
+            elif self.use_context:
                 self.branches[name].set_context(prompt_emb[0].to(self.device, torch.float32).contiguous())
             else:
                 self.branches[name].set_cond(self.cond_embedding(prompt_emb).to(self.device).contiguous())

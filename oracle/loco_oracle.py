@@ -206,9 +206,18 @@ def _adm_gn(p, name, x, cfg):  # GroupNorm32(32, C), eps 1e-5, computed in fp32 
     return F.group_norm(x.float(), cfg.gn_groups, p[name + ".weight"], p[name + ".bias"], cfg.gn_eps).type(x.dtype)
 
 
+def _act(cfg):
+    """SiLU (guided-diffusion, latent-diffusion) or the exact erf GELU of the DeepFloyd-IF U-Net (`act_fn = "gelu"`)."""
+    return F.gelu if getattr(cfg, "act", "silu") == "gelu" else F.silu
+
+
 def _adm_resblock(p, name, x, emb, cfg, up=False, down=False):
-    """ResBlock with use_scale_shift_norm=True -- unet.py:145-258."""
-    h = F.silu(_adm_gn(p, name + ".in_layers.0", x, cfg))
+    """ResBlock with use_scale_shift_norm=True -- unet.py:145-258.  DeepFloyd-IF variant (cfg.act / cfg.res_scale;
+    deepfloyd_if UNetModel = diffusers ResnetBlock2D with `time_embedding_norm="scale_shift"`, `skip_time_act`,
+    `output_scale_factor = sqrt 2`, un-vendored): GELU for SiLU, the embedding arrives activated once for all blocks
+    (the same act(emb) this block computes), output (skip + h) / sqrt 2."""
+    act = _act(cfg)
+    h = act(_adm_gn(p, name + ".in_layers.0", x, cfg))
     if up:      # Upsample(channels, False): nearest x2 on both branches -- :195-197, 239-244
         h = F.interpolate(h, scale_factor=2, mode="nearest")
         x = F.interpolate(x, scale_factor=2, mode="nearest")
@@ -216,16 +225,16 @@ def _adm_resblock(p, name, x, emb, cfg, up=False, down=False):
         h = F.avg_pool2d(h, 2, 2)
         x = F.avg_pool2d(x, 2, 2)
     h = F.conv2d(h, p[name + ".in_layers.2.weight"], p[name + ".in_layers.2.bias"], padding=1)
-    emb_out = F.linear(F.silu(emb), p[name + ".emb_layers.1.weight"], p[name + ".emb_layers.1.bias"])[:, :, None, None]
+    emb_out = F.linear(act(emb), p[name + ".emb_layers.1.weight"], p[name + ".emb_layers.1.bias"])[:, :, None, None]
     if getattr(cfg, "scale_shift_norm", True):
         scale, shift = torch.chunk(emb_out, 2, dim=1)
         h = _adm_gn(p, name + ".out_layers.0", h, cfg) * (1 + scale) + shift     # :250-254
     else:                                                                        # :255-257
         h = _adm_gn(p, name + ".out_layers.0", h + emb_out, cfg)
-    h = F.conv2d(F.silu(h), p[name + ".out_layers.3.weight"], p[name + ".out_layers.3.bias"], padding=1)
+    h = F.conv2d(act(h), p[name + ".out_layers.3.weight"], p[name + ".out_layers.3.bias"], padding=1)
     if (name + ".skip_connection.weight") in p:
         x = F.conv2d(x, p[name + ".skip_connection.weight"], p[name + ".skip_connection.bias"])
-    return x + h
+    return (x + h) * getattr(cfg, "res_scale", 1.0)
 
 
 def _adm_attn(p, name, x, cfg):
@@ -243,6 +252,60 @@ def _adm_attn(p, name, x, cfg):
     a = torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, hh * ww)
     h = F.conv1d(a, p[name + ".proj_out.weight"], p[name + ".proj_out.bias"])
     return (xr + h).reshape(b, c, hh, ww)
+
+
+def _if_attn(p, name, x, context, cfg):
+    """AttentionBlock of the DeepFloyd-IF U-Net (deepfloyd_if/model/unet.py AttentionBlock + QKVAttention, the GLIDE
+    text2im attention; diffusers `Attention(added_kv_proj_dim=..., cross_attention_norm="group_norm")` with
+    `AttnAddedKVProcessor`, un-vendored): the text states [B, L, D] pass the block's GroupNorm (over [D][L]) and a Conv1d to
+    2C channels, split per head into [k_h | v_h] and CONCATENATED IN FRONT of the image keys / values -- one softmax over
+    L + T columns; q, k, v of the image tokens as in QKVAttentionLegacy; out = x + proj_out(a)."""
+    b, c, hh, ww = x.shape
+    xr = x.reshape(b, c, -1)
+    qkv = F.conv1d(_adm_gn(p, name + ".norm", xr, cfg), p[name + ".qkv.weight"], p[name + ".qkv.bias"])
+    nh = c // cfg.num_head_channels
+    ch = c // nh
+    q, k, v = qkv.reshape(b * nh, ch * 3, hh * ww).split(ch, dim=1)
+    e = context.transpose(1, 2)                                                         # [B, D, L]
+    e = F.group_norm(e.float(), cfg.gn_groups, p[name + ".norm_encoder.weight"], p[name + ".norm_encoder.bias"], cfg.gn_eps)
+    e = F.conv1d(e, p[name + ".encoder_kv.weight"], p[name + ".encoder_kv.bias"])         # [B, 2C, L]
+    ek, ev = e.reshape(b * nh, ch * 2, -1).split(ch, dim=1)
+    k = torch.cat([ek, k], dim=-1)
+    v = torch.cat([ev, v], dim=-1)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale).float(), dim=-1)
+    a = torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, hh * ww)
+    h = F.conv1d(a, p[name + ".proj_out.weight"], p[name + ".proj_out.bias"])
+    return (xr + h).reshape(b, c, hh, ww)
+
+
+def if_text_conditioning(p, cfg, states):
+    """Host-side conditioning of the IF U-Net from the text encoder's states [B, L, E] (diffusers UNet2DConditionModel.forward
+    with `encoder_hid_dim_type="text_proj"`, `addition_embed_type="text"`; deepfloyd_if `encoder_proj` / `encoder_pooling`):
+    context = Linear(states) [B, L, D] for the attention blocks, aug = LayerNorm(Linear(AttentionPooling(LayerNorm(states))))
+    [B, 4 ch] added to the time embedding.  AttentionPooling: a class token mean(states) + positional_embedding queries
+    [token ; states] with `num_heads = E / 64` heads (IF: 64 heads of 64)."""
+    states = states.float()
+    ctx = F.linear(states, p["encoder_proj.weight"], p["encoder_proj.bias"])
+    E = states.shape[-1]
+    x = F.layer_norm(states, (E,), p["encoder_pooling.0.weight"], p["encoder_pooling.0.bias"], 1e-5)
+    b = x.shape[0]
+    dph = min(64, E // 2)
+    nh = E // dph
+    cls = x.mean(dim=1, keepdim=True) + p["encoder_pooling.1.positional_embedding"]
+    xs = torch.cat([cls, x], dim=1)                                                     # [B, L + 1, E]
+
+    def shape(z):    # [B, N, E] -> [B * heads, d, N]
+        return z.reshape(b, -1, nh, dph).transpose(1, 2).reshape(b * nh, -1, dph).transpose(1, 2)
+    q = shape(F.linear(cls, p["encoder_pooling.1.q_proj.weight"], p["encoder_pooling.1.q_proj.bias"]))
+    k = shape(F.linear(xs, p["encoder_pooling.1.k_proj.weight"], p["encoder_pooling.1.k_proj.bias"]))
+    v = shape(F.linear(xs, p["encoder_pooling.1.v_proj.weight"], p["encoder_pooling.1.v_proj.bias"]))
+    sc = 1 / math.sqrt(math.sqrt(dph))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * sc, k * sc).float(), dim=-1)
+    a = torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, 1).transpose(1, 2)[:, 0, :]     # [B, E]
+    a = F.linear(a, p["encoder_pooling.2.weight"], p["encoder_pooling.2.bias"])
+    aug = F.layer_norm(a, (a.shape[-1],), p["encoder_pooling.3.weight"], p["encoder_pooling.3.bias"], 1e-5)
+    return ctx, aug
 
 
 def _ldm_spatial_transformer(p, name, x, context, cfg):
@@ -315,6 +378,9 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Option
         if getattr(cfg, "transformer_depth", 0) > 0:
             ctx = context if context.dim() == 3 else context[None]
             return _ldm_spatial_transformer(p, name, h, ctx.expand(h.shape[0], -1, -1), cfg)
+        if getattr(cfg, "added_kv", False):
+            ctx = context if context.dim() == 3 else context[None]
+            return _if_attn(p, name, h, ctx.expand(h.shape[0], -1, -1), cfg)
         h = _adm_attn(p, name, h, cfg)
         if getattr(cfg, "context_dim", 0) > 0:
             ctx = context if context.dim() == 3 else context[None]
@@ -323,7 +389,7 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Option
     t = t.reshape(1) if t.dim() == 0 else t
     emb = timestep_embedding_adm(t.to(torch.float32), cfg.ch)
     emb = F.linear(emb, p["time_embed.0.weight"], p["time_embed.0.bias"])
-    emb = F.linear(F.silu(emb), p["time_embed.2.weight"], p["time_embed.2.bias"])
+    emb = F.linear(_act(cfg)(emb), p["time_embed.2.weight"], p["time_embed.2.bias"])
     if emb_add is not None:
         emb = emb + emb_add
     hs = []
@@ -366,7 +432,7 @@ def unet_forward_adm(p, cfg, x, t, trace: Optional[dict] = None, emb_add: Option
                                                                 p[f"output_blocks.{ob}.{j}.conv.bias"], padding=1))
                 res_px *= 2
             ob += 1
-    h = F.silu(_adm_gn(p, "out.0", h, cfg))
+    h = _act(cfg)(_adm_gn(p, "out.0", h, cfg))
     h = F.conv2d(h, p["out.2.weight"], p["out.2.bias"], padding=1)
     if cfg.learn_sigma and not full:
         h = torch.split(h, h.shape[1] // 2, dim=1)[0]      # et only (unet.py:680-684)

@@ -1,0 +1,137 @@
+"""GPU tests of the DeepFloyd-IF stage-I denoiser (config 5's architecture, `config.IF_I_M_UNET` and its small instances):
+exact GELU in the norm -> activation -> conv chains and the time embedding, ResBlock outputs (skip + h) / sqrt 2, attention
+over [text ; image] keys in one softmax (`added_kv`), the text conditioning computed on the host.  The engine against the
+torch restatement in oracle/loco_oracle.py (`_if_attn`, `if_text_conditioning`, `_adm_resblock` with cfg.act /
+cfg.res_scale): forward, J V (torch.func.jvp) and U^T J (autograd), in the three conv arithmetics.  The restatement itself
+is unpinned against diffusers / deepfloyd_if (neither is installed, no weights): bars as in test_gpu_parity.py.  The
+full-width network (IF_I_M_UNET) runs through the T-LOCO class in test_gpu_tloco.py::test_config5_full_width_operator_and_solver_at_size."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import loco_edit_amd  # noqa: E402,F401
+import loco_oracle as orc  # noqa: E402
+from loco_edit_amd.config import MID_IF, TINY_IF, synth_params  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {"f32": 2e-5, "bf16x3": 2e-4, "f16": 2e-2}
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _engine(cfg, params, states, max_batch):
+    from loco_edit_amd.hip import LocoEngine
+    from loco_edit_amd.tloco import IFTextConditioner
+    eng = LocoEngine(cfg, max_batch=max_batch, device=torch.device(DEV))
+    eng.load_state_dict(params)                       # skips the host-side encoder_proj / encoder_pooling entries
+    context, aug = IFTextConditioner(params, cfg, DEV)(states)
+    eng.set_context(context)
+    eng.set_cond(aug)
+    return eng, context, aug
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16"])
+def test_if_denoiser_forward_jvp_vjp_vs_restatement(prec):
+    cfg = TINY_IF
+    params = synth_params(cfg, 2)
+    p = orc.to_torch(params)
+    g = torch.Generator().manual_seed(11)
+    states = torch.randn(1, cfg.context_len, cfg.encoder_dim, generator=g)
+    eng, context, aug = _engine(cfg, params, states, 4)
+    ctx_ref, aug_ref = orc.if_text_conditioning(p, cfg, states)
+    assert rel(context, ctx_ref[0]) < 1e-5 and rel(aug, aug_ref[0]) < 1e-5          # host conditioning vs the restatement
+    eng.set_precision(prec)
+    x = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=g)
+    t = 417.0
+    f = lambda x_: orc.unet_forward_adm(p, cfg, x_, torch.tensor(t), emb_add=aug_ref, context=ctx_ref)
+    with torch.no_grad():
+        ref = f(x)
+    assert rel(eng.unet_forward(x.to(DEV), t), ref) < TOL[prec]
+    xb = torch.cat([x, 0.5 * x, x + 0.1], dim=0)                                     # a batch through one launch list
+    with torch.no_grad():
+        refb = orc.unet_forward_adm(p, cfg, xb, torch.full((3,), t), emb_add=aug_ref, context=ctx_ref)
+    assert rel(eng.unet_forward(xb.to(DEV), t), refb) < TOL[prec]
+    V = torch.randn(3, eng.n, generator=g)
+    JV = torch.stack([torch.func.jvp(f, (x,), (v.view_as(x),))[1].reshape(-1) for v in V])
+    eng.pmp_primal(x.to(DEV), t, 0.5, None, use_et=True)
+    U = eng.pmp_jvp(V.to(DEV))
+    assert rel(U, JV) < TOL[prec] * 5
+    Uc = torch.randn(3, eng.n_out, generator=g)
+    A = eng.pmp_vjp(Uc.to(DEV))
+    xx = x.clone().requires_grad_(True)
+    out = f(xx).reshape(-1)
+    Aref = torch.stack([torch.autograd.grad((out * u).sum(), xx, retain_graph=True)[0].reshape(-1) for u in Uc])
+    assert rel(A, Aref) < TOL[prec] * 5
+    lhs, rhs = (U.double().cpu() * Uc.double()).sum(), (V.double() * A.double().cpu()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < (1e-4 if prec != "f16" else 2e-2)
+    # the x0 combination and a mask, as the solver uses the operator
+    mask = torch.zeros(3, cfg.resolution, cfg.resolution, dtype=torch.bool); mask[:, 8:24, 4:20] = True
+    at = 0.37
+    eng.pmp_primal(x.to(DEV), t, at, mask.to(DEV))
+    m = mask.reshape(1, -1).float()
+    ref0 = m * (V / at ** 0.5 - (1 - at) ** 0.5 / at ** 0.5 * JV)
+    assert rel(eng.pmp_jvp(V.to(DEV)), ref0) < TOL[prec] * 5
+
+
+def test_if_denoiser_text_changes_the_output_and_needs_the_context():
+    """The prompt reaches the network through BOTH routes (attention keys / values and the pooled embedding); a context-free
+    engine refuses to run."""
+    from loco_edit_amd.hip import LocoEngine
+    cfg = TINY_IF
+    params = synth_params(cfg, 2)
+    g = torch.Generator().manual_seed(4)
+    s0 = torch.randn(1, cfg.context_len, cfg.encoder_dim, generator=g)
+    s1 = torch.randn(1, cfg.context_len, cfg.encoder_dim, generator=g)
+    x = torch.randn(1, 3, 32, 32, generator=g).to(DEV)
+    eng, c0, a0 = _engine(cfg, params, s0, 2)
+    e00 = eng.unet_forward(x, 100.0).clone()
+    from loco_edit_amd.tloco import IFTextConditioner
+    c1, a1 = IFTextConditioner(params, cfg, DEV)(s1)
+    eng.set_context(c1)
+    e10 = eng.unet_forward(x, 100.0).clone()
+    eng.set_cond(a1)
+    e11 = eng.unet_forward(x, 100.0).clone()
+    assert rel(e10, e00) > 1e-3 and rel(e11, e10) > 1e-3
+    bare = LocoEngine(cfg, max_batch=1, device=torch.device(DEV))
+    bare.load_state_dict(params)
+    with pytest.raises(RuntimeError):
+        bare.unet_forward(x, 100.0)
+
+
+def test_if_denoiser_mid_size_1024_token_level():
+    """Config 5's geometry at a third of the width (`MID_IF`: 64 x 64, four levels, three attention levels incl. 1024 image
+    tokens + 77 text states -> 1152 score columns, the streamed softmax rows): forward vs the restatement, J V / J^T U
+    adjointness and J V vs autodiff for one probe."""
+    cfg = MID_IF
+    params = synth_params(cfg, 1)
+    p = orc.to_torch(params)
+    g = torch.Generator().manual_seed(12)
+    states = torch.randn(1, cfg.context_len, cfg.encoder_dim, generator=g)
+    eng, _, _ = _engine(cfg, params, states, 3)
+    ctx_ref, aug_ref = orc.if_text_conditioning(p, cfg, states)
+    x = torch.randn(1, 3, 64, 64, generator=g)
+    t = 594.0
+    f = lambda x_: orc.unet_forward_adm(p, cfg, x_, torch.tensor(t), emb_add=aug_ref, context=ctx_ref)
+    with torch.no_grad():
+        ref = f(x)
+    for prec in ("bf16x3", "f32"):
+        eng.set_precision(prec)
+        assert rel(eng.unet_forward(x.to(DEV), t), ref) < TOL[prec]
+    eng.set_precision("bf16x3")
+    eng.pmp_primal(x.to(DEV), t, 0.5, None, use_et=True)
+    V = torch.randn(3, eng.n, generator=g)
+    U = torch.randn(3, eng.n, generator=g).to(DEV)
+    JV, JtU = eng.pmp_jvp(V.to(DEV)), eng.pmp_vjp(U)
+    jv_ref = torch.func.jvp(f, (x,), (V[0].view_as(x),))[1].reshape(1, -1)
+    assert rel(JV[0:1], jv_ref) < TOL["bf16x3"] * 5
+    lhs, rhs = (JV.double() * U.double()).sum(dim=1), (V.to(DEV).double() * JtU.double()).sum(dim=1)
+    assert ((lhs - rhs).abs() / (JV.norm(dim=1) * U.norm(dim=1)).double()).max().item() < 2e-4

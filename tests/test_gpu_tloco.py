@@ -261,10 +261,13 @@ def test_config5_64x64_vs_reference_fixture(prec, golden, tmp_path):
         assert c.min().item() > 0.999 and cosrow(u.T, sv["u"].T).min().item() > 0.999, mode
 
 
-@pytest.mark.parametrize("preset", ["IF64_STANDIN", "IF64_XATTN_STANDIN"])
+@pytest.mark.parametrize("preset", ["IF_I_M_UNET", "IF64_STANDIN", "IF64_XATTN_STANDIN"])
 def test_config5_full_width_operator_and_solver_at_size(preset, tmp_path):
     """Config 5 at its stated size AND width (64x64, 192 x (1,2,3,4), 3 ResBlocks per level, attention at 32 / 16 / 8 with
-    64-channel heads, learned variance; with and without the T5-shaped 77 x 4096 cross-attention stages): no CPU
+    64-channel heads, learned variance).  `IF_I_M_UNET` is the architecture the shipped script names (DeepFloyd/IF-I-M-v1.0:
+    GELU, (skip + h) / sqrt 2, attention over [text ; image] keys, the 77 x 4096 T5 states conditioned on the host; synthetic
+    weights); the two stand-ins are the guided-diffusion U-Net with the text through the time embedding only / through
+    T5-shaped 77 x 4096 cross-attention stages: no CPU
     reference finishes at this width, so the checks are the size-independent ones -- adjointness <J V, U> = <V, J^T U>,
     linearity, J V against a central finite difference of get_x0, and a 12-iteration top-5 solve whose rows are
     orthonormal, whose s descends and equals ||J v_i|| computed by an independent product."""
@@ -274,7 +277,8 @@ def test_config5_full_width_operator_and_solver_at_size(preset, tmp_path):
     os.environ.pop("WORLD_SIZE", None)
     gen = torch.Generator().manual_seed(31)
     if cfg.context_dim:
-        pe = {k: torch.randn(1, cfg.context_len, cfg.context_dim, generator=gen) for k in ("for", "edit", "null")}
+        width = cfg.encoder_dim if cfg.encoder_dim > 0 else cfg.context_dim     # the IF U-Net takes the text encoder's own states
+        pe = {k: torch.randn(1, cfg.context_len, width, generator=gen) for k in ("for", "edit", "null")}
     else:
         pe = {k: torch.randn(1, 7, 16, generator=gen) for k in ("for", "edit", "null")}
     args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=cfg, synthetic_weights=0, ckpt_path="",
