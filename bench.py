@@ -23,9 +23,10 @@ Workloads (--workload):
   tloco_sd   (BASELINE config 4): latent T-LOCO on the Stable-Diffusion-shaped stand-ins (4x64x64 latent denoiser +
              the SD autoencoder's decoder geometry, Jacobian of the decoded 3x512x512 image); explicit workload only
              (three 832 M-parameter denoiser contexts take a minute to set up)
-  tloco_if64 (BASELINE config 5): pixel-space T-LOCO at 64x64 on the IF-shaped stand-in conditional denoiser
-      (loco_edit_amd.tloco): top-5 null-space basis of the CFG-combined Jacobian ("null+(for-null)", guidance 7.5: two
-      denoiser branches per product), 5 probes per GPU sharded like the headline; value = 5 N directions / step time.
+  tloco_if_i_m (BASELINE config 5): pixel-space T-LOCO at 64x64 on the DeepFloyd IF-I-M stage-I architecture
+      (config.IF_I_M_UNET, loco_edit_amd.tloco): top-5 null-space basis of the CFG-combined Jacobian ("null+(for-null)",
+      guidance 7.5: two denoiser branches per product), 5 probes per GPU sharded like the headline; value = 5 N directions /
+      step time.  tloco_if64: the same on the round-2 stand-in (guided-diffusion U-Net, text through the time embedding).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--precision P]
                     [--no-cpu-baseline] [--no-e2e] [--no-extra]
@@ -63,7 +64,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64", "tloco_sd", "tloco_sd15"], default="celeba_top5")
+    ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64", "tloco_if_i_m", "tloco_sd", "tloco_sd15"], default="celeba_top5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end phase timing (inversion ... decode)")
@@ -358,12 +359,13 @@ def main():
             elapsed = float(tt.item())
         return elapsed, res
 
-    def make_tloco(prec):
-        """config 5: CFG-combined subspace solve on the IF-shaped stand-in (one engine context per prompt)."""
+    def make_tloco(prec, real=False):
+        """config 5: CFG-combined subspace solve (one engine context per prompt) on the IF-shaped stand-in or, `real`, on the
+        DeepFloyd IF-I-M architecture itself (config.IF_I_M_UNET, synthetic weights, seeded 77 x 4096 text states)."""
         from argparse import Namespace
-        from loco_edit_amd.config import IF64_STANDIN
+        from loco_edit_amd.config import IF64_STANDIN, IF_I_M_UNET
         from loco_edit_amd.tloco import EditDeepFloydIF
-        cfg = IF64_STANDIN
+        cfg = IF_I_M_UNET if real else IF64_STANDIN
         k = K_PER_GPU * world
         args = Namespace(device=device, dtype=torch.float32, seed=1, unet_config=cfg, synthetic_weights=0, ckpt_path="", max_batch=8,
                          precision=prec, dataset_name="Random", for_steps=100, use_yh_custom_scheduler=True, guidance_scale=7.5,
@@ -426,6 +428,8 @@ def main():
     def make_workload(name, prec):
         if name == "tloco_if64":
             return make_tloco(prec)
+        if name == "tloco_if_i_m":
+            return make_tloco(prec, real=True)
         if name == "tloco_sd":
             return make_tloco_sd(prec)
         if name == "tloco_sd15":
@@ -567,20 +571,22 @@ def main():
             extra["celeba_top5_two_streams"] = {"value": round(keep / (el / 2), 4), "unit": "edit-directions/s", "streams": n_st,
                                                 "ms_per_step": round(el / 2 * 1e3, 3), "dtype": DTYPE_NOTE[a.precision],
                                                 "parity": parity_vs_fixture(s2, vT2, "celeba256")}
-        # BASELINE config 5 next to the headline: T-LOCO null-space basis on the IF-shaped stand-in, 2 CFG branches
-        w3 = make_workload("tloco_if64", a.precision)
+        # BASELINE config 5 next to the headline: T-LOCO null-space basis on the DeepFloyd IF-I-M architecture, 2 CFG branches
+        w3 = make_workload("tloco_if_i_m", a.precision)
         el, (_, s5, vT5, _) = timed(w3["step"], 1, 1)
         if rank == 0:
             F3 = w3["eng"].unet_flops()
             kl = sharder.rows(w3["k"])[1] - sharder.rows(w3["k"])[0]
-            extra["tloco_if64"] = {
+            extra["tloco_if_i_m"] = {
                 "value": round(w3["k"] / el, 4), "unit": "edit-directions/s (top-5 null-space basis per GPU, CFG-combined Jacobian)",
                 "ms_per_step": round(el * 1e3, 3), "scaling": "weak", "n_gpus": world, "probes_per_gpu": kl, "n_iter": N_ITER,
                 "cfg_branches": 2, "unet_GFLOP": round(F3 / 1e9, 2),
                 "whole_step_TFLOPs_executed_per_gpu": round(2 * (1 + 2 * kl * N_ITER) * F3 / el / 1e12, 2),
                 "singular_values_head": [round(float(v), 4) for v in s5.tolist()[:5]],
-                "denoiser": "IF-shaped stand-in (64x64, ch 192 x (1,2,3,4), 3 res blocks, attention 32/16/8; text through the time "
-                            "embedding) -- the IF U-Net itself is un-vendored diffusers code"}
+                "denoiser": "the DeepFloyd IF-I-M stage-I architecture (64x64, 192 x (1,2,3,4), 3 ResBlocks per level, GELU, "
+                            "(skip + h)/sqrt 2, attention at 32/16/8 over [77 text ; image] keys, 315 M U-Net parameters + host-side "
+                            "text conditioning of the 77x4096 states; synthetic weights) -- parity of the network is unpinned (no "
+                            "diffusers / deepfloyd_if, no weights); r03 and before timed a guided-diffusion stand-in under 'tloco_if64'"}
         del w3
         # BASELINE config 4 next to the headline (single GPU only: four engine contexts): latent T-LOCO on the Stable
         # Diffusion v1 denoiser architecture itself, Jacobian of the decoded 512^2 image
@@ -639,9 +645,10 @@ def main():
                   "mask on the decoded image, t=0.7T, 12 power iterations, probes sharded 5 per GPU; per probe-pass "
                   f"{2 * eng.unet_flops() / 1e12:.2f} TFLOP of denoiser + {w['dec'].unet_flops() / 1e12:.2f} TFLOP of decoder")
             scaling = "weak"
-        elif a.workload == "tloco_if64":
+        elif a.workload in ("tloco_if64", "tloco_if_i_m"):
             metric = "edit-directions/sec (top-5 CFG-combined PMP-Jacobian null-space basis @64^2, T-LOCO)"
-            wl = ("T-LOCO pixel space 64x64, IF-shaped stand-in conditional denoiser, mode null+(for-null) guidance 7.5 (2 branches), "
+            wl = ("T-LOCO pixel space 64x64, " + ("DeepFloyd IF-I-M stage-I architecture (synthetic weights)" if a.workload == "tloco_if_i_m"
+                                                  else "IF-shaped stand-in conditional denoiser") + ", mode null+(for-null) guidance 7.5 (2 branches), "
                   "complement of an l_eye-sized mask, t=0.75T, 12 power iterations, probes sharded 5 per GPU")
             scaling = "weak"
         elif a.workload == "celeba_top5":

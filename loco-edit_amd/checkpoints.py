@@ -417,6 +417,172 @@ def ldm_to_hf_unet2d_condition(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> 
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# DeepFloyd IF stage I: the diffusers ``UNet2DConditionModel`` of the IF pipelines (`self.stage_1.unet`, reference
+# src/utils/utils.py:260-283, src/modules/edit.py:1212-1222) <-> the names of ``config.adm_param_shapes`` for the
+# ``added_kv`` presets (the module tree of the deepfloyd_if package: guided-diffusion names + ``encoder_kv`` /
+# ``norm_encoder`` in the attention blocks, ``encoder_proj`` / ``encoder_pooling`` for the text conditioning).  Written
+# from the published layouts -- ResnetDownsampleBlock2D / SimpleCrossAttn{Down,Up}Block2D / UNetMidBlock2DSimpleCrossAttn
+# with ``Attention(added_kv_proj_dim=...)``: ``group_norm``, ``to_q / to_k / to_v`` (Linear with bias), ``add_k_proj /
+# add_v_proj``, ``norm_cross`` (GroupNorm over the states), ``to_out.0``; resampling ResnetBlock2Ds under ``downsamplers.0``
+# / ``upsamplers.0``; ``add_embedding`` = TextTimeEmbedding, ``encoder_hid_proj`` -- **parity unpinned** (no diffusers, no
+# weights); tested: the map is a bijection onto the parameter list with the right shapes, and the per-head interleave of
+# q / k / v (qkv rows of head h = [q_h | k_h | v_h], encoder_kv rows = [k_h | v_h]) round-trips.
+_IF_POOL = {"norm1": "0", "pool": "1", "proj": "2", "norm2": "3"}
+
+
+def is_hf_if_unet(sd: Dict[str, torch.Tensor]) -> bool:
+    return "time_embedding.linear_1.weight" in sd and any(".add_k_proj." in k for k in sd)
+
+
+def _interleave_heads(parts, heads):
+    """[to_q | to_k | to_v] (each [C, ...], heads = contiguous blocks of C / heads rows) -> rows of head h = [q_h | k_h | v_h]."""
+    ch = parts[0].shape[0] // heads
+    return torch.cat([p_[h * ch:(h + 1) * ch] for h in range(heads) for p_ in parts], dim=0)
+
+
+def _split_heads(w, heads, n):
+    """Inverse of ``_interleave_heads``: n tensors of [C, ...] from [n C, ...] with per-head row blocks."""
+    ch = w.shape[0] // (heads * n)
+    return [torch.cat([w[(h * n + i) * ch:(h * n + i + 1) * ch] for h in range(heads)], dim=0) for i in range(n)]
+
+
+def hf_if_unet_to_native(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    nrb, nlev, has_attn = _ldm_block_index(cfg)
+    sd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    out: Dict[str, torch.Tensor] = {}
+    attn: Dict[str, Dict[str, torch.Tensor]] = {}
+
+    def res(dst, p, v):          # p: [..., "norm1", "weight"]
+        out[f"{dst}.{_LDM_RES[p[-2]]}.{p[-1]}"] = v
+
+    for k, v in sd.items():
+        p = k.split(".")
+        if p[0] == "time_embedding":
+            out[f"time_embed.{0 if p[1] == 'linear_1' else 2}.{p[-1]}"] = v
+        elif p[0] == "encoder_hid_proj":
+            out[f"encoder_proj.{p[-1]}"] = v
+        elif p[0] == "add_embedding":
+            out["encoder_pooling." + _IF_POOL[p[1]] + "." + ".".join(p[2:])] = v
+        elif p[0] == "conv_in":
+            out[f"input_blocks.0.0.{p[-1]}"] = v
+        elif p[0] == "conv_norm_out":
+            out[f"out.0.{p[-1]}"] = v
+        elif p[0] == "conv_out":
+            out[f"out.2.{p[-1]}"] = v
+        elif p[0] == "down_blocks":
+            lvl = int(p[1])
+            if p[2] == "resnets":
+                res(f"input_blocks.{(nrb + 1) * lvl + int(p[3]) + 1}.0", p, v)
+            elif p[2] == "downsamplers":
+                res(f"input_blocks.{(nrb + 1) * (lvl + 1)}.0", p, v)
+            elif p[2] == "attentions":
+                attn.setdefault(f"input_blocks.{(nrb + 1) * lvl + int(p[3]) + 1}.1", {})[".".join(p[4:])] = v
+            else:
+                raise KeyError(k)
+        elif p[0] == "mid_block":
+            if p[1] == "resnets":
+                res(f"middle_block.{0 if p[2] == '0' else 2}", p, v)
+            elif p[1] == "attentions":
+                attn.setdefault("middle_block.1", {})[".".join(p[3:])] = v
+            else:
+                raise KeyError(k)
+        elif p[0] == "up_blocks":
+            i = int(p[1])
+            lvl = nlev - 1 - i
+            if p[2] == "resnets":
+                res(f"output_blocks.{(nrb + 1) * i + int(p[3])}.0", p, v)
+            elif p[2] == "upsamplers":
+                res(f"output_blocks.{(nrb + 1) * i + nrb}.{2 if has_attn[lvl] else 1}", p, v)
+            elif p[2] == "attentions":
+                attn.setdefault(f"output_blocks.{(nrb + 1) * i + int(p[3])}.1", {})[".".join(p[4:])] = v
+            else:
+                raise KeyError(k)
+        else:
+            raise KeyError(f"not a key of the IF UNet2DConditionModel: {k}")
+    for name, a in attn.items():
+        C = a["to_q.weight"].shape[0]
+        heads = C // cfg.num_head_channels
+        for wb in ("weight", "bias"):
+            out[f"{name}.norm.{wb}"] = a[f"group_norm.{wb}"]
+            out[f"{name}.norm_encoder.{wb}"] = a[f"norm_cross.{wb}"]
+            qkv = _interleave_heads([a[f"to_q.{wb}"], a[f"to_k.{wb}"], a[f"to_v.{wb}"]], heads)
+            ekv = _interleave_heads([a[f"add_k_proj.{wb}"], a[f"add_v_proj.{wb}"]], heads)
+            po = a[f"to_out.0.{wb}"]
+            out[f"{name}.qkv.{wb}"] = qkv[..., None] if wb == "weight" else qkv
+            out[f"{name}.encoder_kv.{wb}"] = ekv[..., None] if wb == "weight" else ekv
+            out[f"{name}.proj_out.{wb}"] = po[..., None] if wb == "weight" else po
+    return out
+
+
+def native_to_hf_if_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """Inverse of ``hf_if_unet_to_native`` (round-trip tests; exporting a synthetic checkpoint in diffusers naming)."""
+    nrb, nlev, has_attn = _ldm_block_index(cfg)
+    inv_res = {v: k for k, v in _LDM_RES.items()}
+    inv_pool = {v: k for k, v in _IF_POOL.items()}
+    out: Dict[str, torch.Tensor] = {}
+
+    def res(dst, rest, v):       # rest: ["in_layers", "0", "weight"]
+        out[f"{dst}.{inv_res['.'.join(rest[:-1])]}.{rest[-1]}"] = v
+
+    def att(dst, rest, v):
+        v = torch.as_tensor(v)
+        what, wb = rest[0], rest[-1]
+        if what == "norm":
+            out[f"{dst}.group_norm.{wb}"] = v
+        elif what == "norm_encoder":
+            out[f"{dst}.norm_cross.{wb}"] = v
+        elif what == "proj_out":
+            out[f"{dst}.to_out.0.{wb}"] = v[..., 0] if wb == "weight" else v
+        else:
+            n = 3 if what == "qkv" else 2
+            w = v[..., 0] if wb == "weight" else v
+            heads = (w.shape[0] // n) // cfg.num_head_channels
+            names = ("to_q", "to_k", "to_v") if what == "qkv" else ("add_k_proj", "add_v_proj")
+            for nm, part in zip(names, _split_heads(w, heads, n)):
+                out[f"{dst}.{nm}.{wb}"] = part
+
+    for k, v in sd.items():
+        p = k.split(".")
+        if p[0] == "time_embed":
+            out[f"time_embedding.linear_{1 if p[1] == '0' else 2}.{p[-1]}"] = v
+        elif p[0] == "encoder_proj":
+            out[f"encoder_hid_proj.{p[-1]}"] = v
+        elif p[0] == "encoder_pooling":
+            out["add_embedding." + inv_pool[p[1]] + "." + ".".join(p[2:])] = v
+        elif p[0] == "out":
+            out[f"{'conv_norm_out' if p[1] == '0' else 'conv_out'}.{p[-1]}"] = v
+        elif p[0] == "input_blocks":
+            ib = int(p[1])
+            if ib == 0:
+                out[f"conv_in.{p[-1]}"] = v
+                continue
+            lvl, j = divmod(ib - 1, nrb + 1)
+            if j == nrb:
+                res(f"down_blocks.{lvl}.downsamplers.0", p[3:], v)
+            elif p[2] == "0":
+                res(f"down_blocks.{lvl}.resnets.{j}", p[3:], v)
+            else:
+                att(f"down_blocks.{lvl}.attentions.{j}", p[3:], v)
+        elif p[0] == "middle_block":
+            if p[1] == "1":
+                att("mid_block.attentions.0", p[2:], v)
+            else:
+                res(f"mid_block.resnets.{0 if p[1] == '0' else 1}", p[2:], v)
+        elif p[0] == "output_blocks":
+            i, j = divmod(int(p[1]), nrb + 1)
+            lvl = nlev - 1 - i
+            if p[2] == "0":
+                res(f"up_blocks.{i}.resnets.{j}", p[3:], v)
+            elif p[2] == "1" and has_attn[lvl]:
+                att(f"up_blocks.{i}.attentions.{j}", p[3:], v)
+            else:
+                res(f"up_blocks.{i}.upsamplers.0", p[3:], v)
+        else:
+            raise KeyError(k)
+    return out
+
+
 def normalize_unet_state_dict(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
     """Whatever ``--ckpt_path`` held -> the engine's parameter names and shapes for ``cfg``.
 
@@ -427,6 +593,8 @@ def normalize_unet_state_dict(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> D
     sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
     if is_compvis_sd(sd):
         sd = compvis_sd_to_ldm(sd)
+    elif is_hf_if_unet(sd):
+        sd = hf_if_unet_to_native(sd, cfg)
     elif is_hf_unet2d_condition(sd):
         sd = hf_unet2d_condition_to_ldm(sd, cfg)
     elif is_hf_unet2d(sd) and cfg.arch == "ddpm":

@@ -78,7 +78,7 @@ _UNET_PRESETS = {'celeba_ddpm': 'CELEBA_DDPM', 'ffhq_p2': 'FFHQ_P2', 'tiny_ddpm'
                  'tiny_adm': 'TINY_ADM', 'if64_standin': 'IF64_STANDIN', 'sd64_standin': 'SD64_STANDIN',
                  'sd64_xattn_standin': 'SD64_XATTN_STANDIN', 'tiny_latent': 'TINY_LATENT', 'tiny_latent_xattn': 'TINY_LATENT_XATTN',
                  'if64_xattn_standin': 'IF64_XATTN_STANDIN', 'tiny_adm_xattn': 'TINY_ADM_XATTN', 'sd15_unet': 'SD15_UNET', 'sd21_base_unet': 'SD21_BASE_UNET',
-                 'tiny_ldm': 'TINY_LDM'}
+                 'tiny_ldm': 'TINY_LDM', 'if_i_m_unet': 'IF_I_M_UNET', 'tiny_if': 'TINY_IF', 'mid_if': 'MID_IF'}
 _VAE_PRESETS = {'sd_vae_decoder': 'SD_VAE_DECODER', 'tiny_decoder': 'TINY_DECODER'}
 _TILDA_V = ["proj_null[for-null](edit-null)-direct", "(for-edit)-direct", "(edit-null)-direct",
             "null+(for-null)+(edit-null)", "null+(for-null)", "null+(edit-null)", "(for-edit)",
@@ -227,7 +227,9 @@ def _preset_t2i(args, family):
         args.c_in = args.unet_config.in_channels           # 4
     else:
         if getattr(args, 'unet_config', None) is None:
-            args.unet_config = config.IF64_STANDIN
+            # the stage-I U-Net of the id the shipped scripts name (scripts/main_T2I_DeepFloydIF_null_space_projection*.sh:4,
+            # DeepFloyd/IF-I-M-v1.0); `--unet_preset if64_standin` / `if64_xattn_standin` select the round-2 / 3 stand-ins
+            args.unet_config = config.IF_I_M_UNET
         args.c_in = 3
     args.image_size = args.unet_config.resolution          # 64: SD latents and the IF stage-I models alike
     args.memory_bound = 5

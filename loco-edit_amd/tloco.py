@@ -342,7 +342,11 @@ class EditDeepFloydIF(object):
         self.x_space_guidance_scale = args.x_space_guidance_scale
         self.x_space_guidance_num_step = args.x_space_guidance_num_step
         # path (edit.py:1205-1208)
-        self.result_folder = os.path.join(args.result_folder, f"for_prompt_{args.for_prompt}_cfg{args.guidance_scale}_seed{args.seed}_standin")
+        # the reference ends the name with the model size of "DeepFloyd/IF-I-<size>-v1.0" (edit.py:1204-1206); the stand-in
+        # denoisers (no IF architecture behind the name) say so instead
+        parts = str(getattr(args, "model_name", "")).split("-")
+        size = (parts[2] if len(parts) > 2 else "M") if self.use_text_cond else "standin"
+        self.result_folder = os.path.join(args.result_folder, f"for_prompt_{args.for_prompt}_cfg{args.guidance_scale}_seed{args.seed}_{size}")
         os.makedirs(self.result_folder, exist_ok=True)
         self.sharder = ProbeSharder("world")
         self.EXP_NAME = "exp"

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format c
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-e2e --no-extra > /dev/null 2> $O/pmc_write.err
 python3 $R/profiles/make_traffic.py $O/pmc_fetch $O/pmc_write $tag $O > $O/traffic_summary.txt 2>&1 || { echo "make_traffic failed"; cat $O/traffic_summary.txt; exit 1; }
 python3 $R/profiles/check_traffic.py $O/traffic.json $R/loco-edit_amd/libloco_hip.so || exit 1
-for wl in p2_k64 tloco_if64 tloco_sd15; do
+for wl in p2_k64 tloco_if_i_m tloco_sd15; do
   rocprofv3 --kernel-trace --stats -d $O/stats_$wl -o s --output-format csv -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra > $O/bench_${wl}_under_rocprof.json 2> $O/stats_$wl.err
 done
 # keep the merge small: the per-launch traces are large, the summaries are what is judged

@@ -135,3 +135,27 @@ def test_if_denoiser_mid_size_1024_token_level():
     assert rel(JV[0:1], jv_ref) < TOL["bf16x3"] * 5
     lhs, rhs = (JV.double() * U.double()).sum(dim=1), (V.to(DEV).double() * JtU.double()).sum(dim=1)
     assert ((lhs - rhs).abs() / (JV.norm(dim=1) * U.norm(dim=1)).double()).max().item() < 2e-4
+
+
+def test_cli_shipped_if_script_on_the_if_architecture(tmp_path, monkeypatch):
+    """`python -m loco_edit_amd.main` with the argument list of scripts/main_T2I_DeepFloydIF_null_space_projection.sh
+    (tests/golden/script_args.json) on a small instance of the IF architecture (`--unet_preset tiny_if`, synthetic weights,
+    seeded text states; SAM masks from mask.pt): the DeepFloyd branch of preset, the reference's result folder
+    (`..._seed<seed>_M`, edit.py:1204-1206), the projected direction saved under the reference's file name."""
+    import json
+    from loco_edit_amd.main import main
+    argv = json.load(open(os.path.join(ROOT, "tests", "golden", "script_args.json")))["main_T2I_DeepFloydIF_null_space_projection.sh"]
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("LOCO_PRECISION", "bf16x3")
+    rdir = tmp_path / "runs" / "DeepFloyd-IF-Random-with_prompt" / "results" / "for_prompt_A photo of a man_cfg7.5_seed2628577915_M"
+    os.makedirs(rdir / "mask")
+    masks = torch.zeros(13, 1, 32, 32, dtype=torch.bool)
+    masks[12, 0, 12:20, 8:18] = True
+    torch.save(masks, str(rdir / "mask" / "mask.pt"))
+    x0 = main(argv + ["--device", DEV, "--unet_preset", "tiny_if", "--synthetic_weights", "0"])
+    assert x0.dtype == torch.uint8 and tuple(x0.shape) == (3, 32, 32, 3)
+    pcs = [f for f in os.listdir(rdir / "basis") if f.endswith("-pc_000-vT.pt")]
+    assert len(pcs) == 1
+    v = torch.load(str(rdir / "basis" / pcs[0]))
+    assert tuple(v.shape) == (1, TINY_IF.n) and abs(float(v.norm()) - 1.0) < 1e-4
