@@ -22,6 +22,12 @@
 // heads run zero-padded to 64; two workgroups per CU) and, round 4, up to 96 channels (Stable Diffusion v1's 80-channel heads
 // at its 1024-token level: three 32-channel output tiles, one workgroup per CU); token counts that are multiples of 128.
 // Other shapes stay on the generic path.
+//
+// TXT (the DeepFloyd-IF attention, engine.hip "attention over [text ; image] keys"): the key axis is [Lt text states ; T
+// image tokens] under ONE softmax, P is [T][Lt + T] with the text columns first.  The text keys / values (a.kt / a.vt,
+// [CH][Lt] per head, zero beyond the real states) are constants of the prompt: they are streamed as Lt / 64 extra key blocks
+// ahead of the image blocks with zero key / value tangents (TAN) and take part in g_q (COTQ); g_k / g_v exist for the
+// image keys only, so COTK just reads its column of P at Lt + j.
 #include "kernels.h"
 #include <cstdlib>
 
@@ -70,6 +76,13 @@ __device__ __forceinline__ void load_tokens(TokRegs<NTOK, NOCT>& R, const float*
     }
 }
 template <int NTOK, int NOCT>
+__device__ __forceinline__ void zero_tokens(TokRegs<NTOK, NOCT>& R) {
+#pragma unroll
+    for (int it = 0; it < (NTOK * NOCT) / 256; ++it)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) R.v[it][k] = 0.f;
+}
+template <int NTOK, int NOCT>
 __device__ __forceinline__ void store_tokens(const TokRegs<NTOK, NOCT>& R, unsigned char* dst, int tid) {
 #pragma unroll
     for (int it = 0; it < (NTOK * NOCT) / 256; ++it) {
@@ -105,6 +118,11 @@ __device__ __forceinline__ void load_channels(ChRegs<NCP>& R, const float* X, in
             R.a[ps][0] = R.a[ps][1] = R.a[ps][2] = R.a[ps][3] = f32x4a{0.f, 0.f, 0.f, 0.f};
         }
     }
+}
+template <int NCP>
+__device__ __forceinline__ void zero_channels(ChRegs<NCP>& R) {
+#pragma unroll
+    for (int ps = 0; ps < NCP; ++ps) R.a[ps][0] = R.a[ps][1] = R.a[ps][2] = R.a[ps][3] = f32x4a{0.f, 0.f, 0.f, 0.f};
 }
 template <int NCP, int CHP>
 __device__ __forceinline__ void store_channels(const ChRegs<NCP>& R, unsigned char* dst, int tid) {
@@ -160,7 +178,7 @@ enum : int { M_TAN = 0, M_COTQ = 1, M_COTK = 2 };
 // step at compile time; a run-time skip splits the block's scheduling region and measured 3.4 % slower)
 // NCT: 32-channel output tiles of the padded head (2: heads up to 64 channels, two workgroups per CU; 3: up to 96 channels
 // -- Stable Diffusion v1's 80-channel heads at its 1024-token level -- one workgroup per CU: 120 KB of operand regions)
-template <int MODE, int NCK, int NCT>
+template <int MODE, int NCK, int NCT, bool TXT = false>
 __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     constexpr int NREC = 2 * NCT;                  // 16-channel records per token
     constexpr int NOCT = 4 * NCT;                  // octets per token
@@ -180,7 +198,11 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     const int nch = a.CH;                          // head width (<= CHP; narrower heads run zero-padded)
     const long HS = a.hs, HO = (long)nch * T;
     const float* q = a.q + h * HS;  const float* k = a.k + h * HS;  const float* v = a.v + h * HS;
-    const float* P = a.P + (long)h * T * T;
+    const int Lt = TXT ? a.Lt : 0;                 // text columns ahead of the image columns in every row of P
+    const int PS = Lt + T;                         // row stride of P
+    const float* P = a.P + (long)h * T * PS;
+    const float* kt = TXT ? a.kt + (long)h * nch * Lt : nullptr;
+    const float* vt = TXT ? a.vt + (long)h * nch * Lt : nullptr;
     const float* o = a.o + h * HO;
     const float* dq = MODE == M_TAN ? a.dq + (long)b * a.bs_d + h * HS : nullptr;
     const float* dk = MODE == M_TAN ? a.dk + (long)b * a.bs_d + h * HS : nullptr;
@@ -220,11 +242,26 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     TokRegs<NBLK, NOCT> ta, tb;
     ChRegs<NCP> ca, cb;
     float dreg = 0.f;
-    auto fetch = [&](int t0) {
+    // u: position on the streamed axis.  TAN / COTQ stream the keys, [text ; image] under TXT (u < Lt: a text block);
+    // COTK streams the queries (image tokens only)
+    const int U = (TXT && MODE != M_COTK) ? PS : T;
+    auto fetch = [&](int u) {
+        const bool text = TXT && MODE != M_COTK && u < Lt;
+        const int t0 = (TXT && MODE != M_COTK) ? u - Lt : u;
         if (MODE == M_TAN) {
+            if (text) {
+                load_tokens<NBLK, NOCT>(ta, kt, Lt, u, tid, nch); zero_tokens<NBLK, NOCT>(tb);
+                load_channels<NCP>(ca, vt, Lt, u, tid, nch); zero_channels<NCP>(cb);
+                return;
+            }
             load_tokens<NBLK, NOCT>(ta, k, T, t0, tid, nch); load_tokens<NBLK, NOCT>(tb, dk, T, t0, tid, nch);
             load_channels<NCP>(ca, v, T, t0, tid, nch); load_channels<NCP>(cb, dv, T, t0, tid, nch);
         } else if (MODE == M_COTQ) {
+            if (text) {
+                load_tokens<NBLK, NOCT>(ta, vt, Lt, u, tid, nch);
+                load_channels<NCP>(ca, kt, Lt, u, tid, nch);
+                return;
+            }
             load_tokens<NBLK, NOCT>(ta, v, T, t0, tid, nch);
             load_channels<NCP>(ca, k, T, t0, tid, nch);
         } else {
@@ -234,19 +271,19 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
         }
     };
     fetch(0);
-    for (int t0 = 0; t0 < T; t0 += NBLK) {
+    for (int t0 = 0; t0 < U; t0 += NBLK) {
         __syncthreads();                            // the previous block's fragment reads (and the prologue's) are done
         store_tokens<NBLK, NOCT>(ta, RA, tid);
         store_channels<NCP, CHP>(ca, RB, tid);
         if (MODE == M_TAN) { store_tokens<NBLK, NOCT>(tb, RA + T2, tid); store_channels<NCP, CHP>(cb, RB + T2, tid); }
         if (MODE == M_COTK) { store_channels<NCP, CHP>(cb, RB + T2, tid); if (tid < NBLK) DL[tid] = dreg; }
-        if (t0 + NBLK < T) fetch(t0 + NBLK);        // in flight under this block's MFMAs
+        if (t0 + NBLK < U) fetch(t0 + NBLK);        // in flight under this block's MFMAs
         // primal probabilities of the tile in the D-fragment layout (rows = streamed tokens, column = own token)
         f32x16 pt[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             if (MODE != M_COTK) {                   // own = query i (a row of P): 4 consecutive streamed keys per load
-                const float* pr = P + (long)mytok * T + t0 + 32 * mt + 4 * khalf;
+                const float* pr = P + (long)mytok * PS + t0 + 32 * mt + 4 * khalf;      // t0 is the column of P here (text first)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     const f32x4a x = *reinterpret_cast<const f32x4a*>(pr + 8 * qd);
@@ -256,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = t0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    pt[mt][r] = P[(long)i * T + mytok];
+                    pt[mt][r] = P[(long)i * PS + Lt + mytok];
                 }
             }
         }
@@ -330,19 +367,22 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
 
 }  // namespace
 
+bool attn_flash_text_supported(int T, int CH, int Lt) {
+    return CH >= 8 && CH <= 64 && T >= NOWN && (T % NOWN) == 0 && Lt > 0 && (Lt % NBLK) == 0;
+}
 bool attn_flash_supported(int T, int CH) {
     static int wide = -1;                 // LOCO_FLASH_WIDE=0: heads wider than 64 channels stay on the generic path (A/B switch)
     if (wide < 0) { const char* e = getenv("LOCO_FLASH_WIDE"); wide = e ? (atoi(e) != 0) : 1; }
     return CH >= 8 && CH <= (wide ? CHD : 64) && T >= NOWN && (T % NOWN) == 0;
 }
 
-template <int NCK, int NCT>
+template <int NCK, int NCT, bool TXT = false>
 static void attn_flash_launch_n(int mode, const AttnFlashArgs& a, hipStream_t st) {
     dim3 grid(a.T / NOWN, a.NH, a.B);
     const size_t ldsb = 2 * region_bytes(NCT);       // NCT 2: 80 KB, two workgroups per CU; NCT 3: 120 KB, one
-    auto k0 = &attn_flash_kernel<M_TAN, NCK, NCT>;
-    auto k1 = &attn_flash_kernel<M_COTQ, NCK, NCT>;
-    auto k2 = &attn_flash_kernel<M_COTK, NCK, NCT>;
+    auto k0 = &attn_flash_kernel<M_TAN, NCK, NCT, TXT>;
+    auto k1 = &attn_flash_kernel<M_COTQ, NCK, NCT, TXT>;
+    auto k2 = &attn_flash_kernel<M_COTK, NCK, NCT, TXT>;
     static DeviceOnce once;
     if (first_on_device(once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
@@ -354,6 +394,7 @@ static void attn_flash_launch_n(int mode, const AttnFlashArgs& a, hipStream_t st
     else hipLaunchKernelGGL(k2, grid, dim3(256), ldsb, st, a);
 }
 static void attn_flash_launch(int mode, const AttnFlashArgs& a, hipStream_t st) {
+    if (a.Lt > 0) { attn_flash_launch_n<4, 2, true>(mode, a, st); return; }      // attn_flash_text_supported: heads of <= 64 channels
     if (a.CH <= 48) attn_flash_launch_n<3, 2>(mode, a, st);
     else if (a.CH <= 64) attn_flash_launch_n<4, 2>(mode, a, st);
     else if (a.CH <= 80) attn_flash_launch_n<5, 3>(mode, a, st);

@@ -1672,6 +1672,14 @@ void akv_tangent(const AKV& s) {        // dq, dk, dv in arenaT(qkv) -> do in ar
     float* dq = c->arenaT + c->tens[op.qkv].off; float* dk = dq + OS; float* dv = dk + OS;
     float* SP = c->arenaP + c->tens[op.S].off; float* ST = c->arenaT + c->tens[op.S].off;
     float* oT = c->arenaT + c->tens[op.o].off;
+    if (c->flash_attn && c->prec >= 1 && attn_flash_text_supported(s.T, s.CH, s.Lp)) {      // no [T x (Lp + T)] tangent (attn_flash.hip TXT)
+        AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+        fa.T = s.T; fa.NH = s.NH; fa.B = s.B; fa.CH = s.CH; fa.scale = s.scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = s.HS;
+        fa.P = SP; fa.o = c->arenaP + c->tens[op.o].off; fa.Lt = s.Lp; fa.kt = op.xK; fa.vt = op.xV;
+        fa.dq = dq; fa.dk = dk; fa.dv = dv; fa.bs_d = PS; fa.out = oT; fa.bs_out = PS;
+        launch_attn_flash_tangent(fa, s.st);
+        return;
+    }
     akv_scores(s, dq, PS, s.HS, op.xK, 0, s.KS, s.Lp, ST, PS, 0, s.Lp, 1.f, 0.f, false, true);       // dS_text = dq^T K_text
     akv_scores(s, dq, PS, s.HS, k, 0, s.HS, s.T, ST, PS, s.Lp, s.T, 1.f, 0.f, false, false);         // dS_img = dq^T k
     akv_scores(s, q, 0, s.HS, dk, PS, s.HS, s.T, ST, PS, s.Lp, s.T, 1.f, 1.f, false, false);         //        + q^T dk
@@ -1687,6 +1695,14 @@ void akv_cotangent(const AKV& s) {      // g_o in arenaT(o) -> g_q, g_k, g_v in 
     float* gq = c->arenaT + c->tens[op.qkv].off; float* gk = gq + OS; float* gv = gk + OS;
     float* SP = c->arenaP + c->tens[op.S].off; float* SG = c->arenaT + c->tens[op.S].off;
     float* oG = c->arenaT + c->tens[op.o].off;
+    if (c->flash_attn && c->prec >= 1 && attn_flash_text_supported(s.T, s.CH, s.Lp)) {
+        AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+        fa.T = s.T; fa.NH = s.NH; fa.B = s.B; fa.CH = s.CH; fa.scale = s.scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = s.HS;
+        fa.P = SP; fa.o = c->arenaP + c->tens[op.o].off; fa.Lt = s.Lp; fa.kt = op.xK; fa.vt = op.xV;
+        fa.go = oG; fa.bs_go = PS; fa.gq = gq; fa.gk = gk; fa.gv = gv; fa.bs_g = PS; fa.delta = c->attn_delta;
+        launch_attn_flash_cotangent(fa, s.st);
+        return;
+    }
     akv_keys(s, oG, PS, OS, SP, 0, s.Lp, gv, PS, s.HS);                                              // g_v = g_o P_img
     akv_scores(s, oG, PS, OS, op.xV, 0, s.KS, s.Lp, SG, PS, 0, s.Lp, 1.f, 0.f, false, true);         // g_P_text = g_o^T V_text
     akv_scores(s, oG, PS, OS, v, 0, s.HS, s.T, SG, PS, s.Lp, s.T, 1.f, 0.f, false, false);           // g_P_img = g_o^T v

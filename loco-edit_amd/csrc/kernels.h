@@ -167,8 +167,12 @@ struct AttnFlashArgs {
     const float* go; long bs_go;              // cotangent input g_o per probe
     float *gq, *gk, *gv; long bs_g;           // cotangent results per probe
     float* delta;                             // scratch [B][NH][T]: delta_i = <g_o_i, o_i>
+    // keys / values = [text ; image] in one softmax (DeepFloyd-IF): Lt text columns (a multiple of 64, zero-padded) ahead of
+    // the T image columns in every row of P ([NH][T][Lt + T]); kt / vt [NH][CH][Lt] constants.  Lt = 0: plain self-attention
+    int Lt; const float *kt, *vt;
 };
 bool attn_flash_supported(int T, int CH);     // heads of <= 96 channels, token counts that are multiples of 128
+bool attn_flash_text_supported(int T, int CH, int Lt);   // the [text ; image] form: heads of <= 64 channels
 void launch_attn_flash_tangent(const AttnFlashArgs& a, hipStream_t st);
 void launch_attn_flash_cotangent(const AttnFlashArgs& a, hipStream_t st);
 

@@ -159,3 +159,32 @@ def test_cli_shipped_if_script_on_the_if_architecture(tmp_path, monkeypatch):
     assert len(pcs) == 1
     v = torch.load(str(rdir / "basis" / pcs[0]))
     assert tuple(v.shape) == (1, TINY_IF.n) and abs(float(v.norm()) - 1.0) < 1e-4
+
+
+def test_if_attention_flash_kernels_equal_the_strided_products(monkeypatch):
+    """The tangent / cotangent of the [text ; image] attention on the flash kernels (attn_flash.hip TXT: two text key blocks
+    ahead of the image blocks, no [T x (128 + T)] matrix per probe) against the strided products over one score matrix
+    (LOCO_FLASH_ATTN=0), same arithmetic class: 1024- and 256-token levels on the flash kernels, the 64-token level on the
+    products either way."""
+    from loco_edit_amd.hip import LocoEngine
+    from loco_edit_amd.tloco import IFTextConditioner
+    cfg = MID_IF
+    params = synth_params(cfg, 1)
+    g = torch.Generator().manual_seed(21)
+    states = torch.randn(1, cfg.context_len, cfg.encoder_dim, generator=g)
+    context, aug = IFTextConditioner(params, cfg, DEV)(states)
+    x = torch.randn(1, 3, 64, 64, generator=g).to(DEV)
+    V = torch.randn(4, cfg.n, generator=g).to(DEV)
+    U = torch.randn(4, cfg.n, generator=g).to(DEV)
+    res = {}
+    for flash in ("1", "0"):
+        monkeypatch.setenv("LOCO_FLASH_ATTN", flash)
+        eng = LocoEngine(cfg, max_batch=4, device=torch.device(DEV))
+        eng.load_state_dict(params)
+        eng.set_context(context); eng.set_cond(aug)
+        eng.set_precision("bf16x3")
+        eng.pmp_primal(x, 300.0, 0.5, None, use_et=True)
+        res[flash] = (eng.pmp_jvp(V).clone(), eng.pmp_vjp(U).clone())
+        del eng
+    assert rel(res["1"][0], res["0"][0]) < 1e-4 and rel(res["1"][1], res["0"][1]) < 1e-4
+    assert not torch.equal(res["1"][0], res["0"][0])          # two different code paths did run
