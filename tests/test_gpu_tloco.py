@@ -261,7 +261,7 @@ def test_config5_64x64_vs_reference_fixture(prec, golden, tmp_path):
         assert c.min().item() > 0.999 and cosrow(u.T, sv["u"].T).min().item() > 0.999, mode
 
 
-@pytest.mark.parametrize("preset", ["IF_I_M_UNET", "IF64_STANDIN", "IF64_XATTN_STANDIN"])
+@pytest.mark.parametrize("preset", ["IF_I_M_UNET", "IF64_STANDIN"])   # (IF64_XATTN_STANDIN ran here until the IF architecture itself did: 27 s; its stages stay covered at 32 x 32)
 def test_config5_full_width_operator_and_solver_at_size(preset, tmp_path):
     """Config 5 at its stated size AND width (64x64, 192 x (1,2,3,4), 3 ResBlocks per level, attention at 32 / 16 / 8 with
     64-channel heads, learned variance).  `IF_I_M_UNET` is the architecture the shipped script names (DeepFloyd/IF-I-M-v1.0:
