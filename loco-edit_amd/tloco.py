@@ -15,12 +15,15 @@ engine context ("branch") holding that prompt's primal activations; a probe batc
 pass per branch, the branches are combined by ``loco_lincomb`` / ``loco_masked_axpby``.  The reference pays the same
 2-3 U-Net evaluations per product as a batch of 2-3.
 
-NOT built (stated, not hidden): the IF denoiser itself is diffusers' ``UNet2DConditionModel`` with T5 cross-attention
-(un-vendored, hub weights) -- the conditional denoiser here is the guided-diffusion U-Net of the engine whose time
-embedding receives ``cond_proj(mean_tokens(prompt_emb))`` (``loco_set_cond``), so architecture parity is unpinned while
-the orchestration above is pinned against the reference's own methods (oracle/make_golden_tloco.py).  Prompt embeddings
-are inputs (``--prompt_emb_path``: a dict of [1, tokens, D] tensors) or seeded stand-ins; stages II/III, SAM and the
-``diffedit`` ablation are not on this path.
+The denoiser: ``config.IF_I_M_UNET`` (round 4), the stage-I architecture the shipped scripts name -- the engine's
+guided-diffusion family with GELU, (skip + h) / sqrt 2 and attention over [text ; image] keys; the image-independent text
+conditioning (``encoder_proj``, ``encoder_pooling``) runs on the host (``IFTextConditioner``) and reaches the engine through
+``loco_set_context`` / ``loco_set_cond``.  Written from the published module trees: neither diffusers nor deepfloyd_if is
+installed and there are no weights, so the architecture's parity is unpinned, while the orchestration above is pinned
+against the reference's own methods (oracle/make_golden_tloco.py).  The round-2 / 3 stand-ins stay selectable: the
+guided-diffusion U-Net whose time embedding receives ``cond_proj(mean_tokens(prompt_emb))``, and the same with text
+cross-attention stages.  Prompt embeddings are inputs (``--prompt_emb_path``: a dict of [1, tokens, D] tensors; the T5
+encoder is out of scope) or seeded; stages II/III, SAM and the ``diffedit`` ablation are not on this path.
 """
 from __future__ import annotations
 

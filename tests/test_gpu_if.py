@@ -188,3 +188,45 @@ def test_if_attention_flash_kernels_equal_the_strided_products(monkeypatch):
         del eng
     assert rel(res["1"][0], res["0"][0]) < 1e-4 and rel(res["1"][1], res["0"][1]) < 1e-4
     assert not torch.equal(res["1"][0], res["0"][0])          # two different code paths did run
+
+
+def test_if_i_m_denoiser_at_size_vs_restatement():
+    """`config.IF_I_M_UNET` at full width (315 M U-Net parameters, synthetic weights) with the weights arriving the way a
+    diffusers checkpoint stores them (UNet2DConditionModel names, separate to_q / to_k / to_v / add_k_proj / add_v_proj):
+    forward against the CPU restatement in both arithmetics, J V / J^T U adjointness and linearity of the raw network."""
+    from loco_edit_amd.checkpoints import native_to_hf_if_unet, normalize_unet_state_dict
+    from loco_edit_amd.config import IF_I_M_UNET
+    from loco_edit_amd.hip import LocoEngine
+    from loco_edit_amd.tloco import IFTextConditioner
+    cfg = IF_I_M_UNET
+    params = synth_params(cfg, 0)
+    p = orc.to_torch(params)
+    g = torch.Generator().manual_seed(8)
+    states = torch.randn(1, cfg.context_len, cfg.encoder_dim, generator=g)
+    x = torch.randn(1, 3, 64, 64, generator=g)
+    t = 742.0
+    ctx_ref, aug_ref = orc.if_text_conditioning(p, cfg, states)
+    with torch.no_grad():
+        ref = orc.unet_forward_adm(p, cfg, x, torch.tensor(t), emb_add=aug_ref, context=ctx_ref)
+    sd = normalize_unet_state_dict(native_to_hf_if_unet(p, cfg), cfg)
+    del p
+    eng = LocoEngine(cfg, max_batch=3, device=torch.device(DEV))
+    eng.load_state_dict(sd)
+    context, aug = IFTextConditioner(sd, cfg, DEV)(states)
+    del sd
+    assert rel(context, ctx_ref[0]) < 1e-5 and rel(aug, aug_ref[0]) < 1e-5
+    eng.set_context(context); eng.set_cond(aug)
+    for prec in ("bf16x3", "f32"):
+        eng.set_precision(prec)
+        e = rel(eng.unet_forward(x.to(DEV), t), ref)
+        print(f"IF-I-M U-Net forward at size, {prec} vs CPU restatement: rel err {e:.2e}")
+        assert e < TOL[prec]
+    eng.set_precision("bf16x3")
+    eng.pmp_primal(x.to(DEV), t, 0.5, None, use_et=True)
+    V = torch.randn(3, cfg.n, generator=g).to(DEV)
+    U = torch.randn(3, cfg.n, generator=g).to(DEV)
+    JV, JtU = eng.pmp_jvp(V), eng.pmp_vjp(U)
+    lhs, rhs = (JV.double() * U.double()).sum(dim=1), (V.double() * JtU.double()).sum(dim=1)
+    assert ((lhs - rhs).abs() / (JV.norm(dim=1) * U.norm(dim=1)).double()).max().item() < 2e-4
+    comb = eng.pmp_jvp((V[0:1] * 0.5 - V[1:2] * 2.0).contiguous())
+    assert rel(comb, JV[0:1] * 0.5 - JV[1:2] * 2.0) < 1e-3
