@@ -250,42 +250,9 @@ def test_cli_shipped_sd_script_on_the_standins(unet, tmp_path, monkeypatch):
     assert (rdir / "original.png").exists()
 
 
-def test_latent_solver_at_stable_diffusion_size(tmp_path):
-    """BASELINE config 4 at its size on the stand-ins: 4x64x64 latent, SD-width denoiser with text cross-attention over
-    77 x 768 prompt states (2 CFG branches), the SD
-    autoencoder's decoder geometry (64 -> 512, 4096-token mid attention), mask on the decoded 3x512x512 image.
-    No reference fixture at this size (parity of the architectures is unpinned): adjointness of the composed operator,
-    orthonormal descending basis, shapes."""
-    from loco_edit_amd.config import SD64_XATTN_STANDIN, SD_VAE_DECODER
-    from loco_edit_amd.tloco_sd import EditStableDiffusion
-    os.environ.pop("WORLD_SIZE", None)
-    args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=SD64_XATTN_STANDIN, vae_config=SD_VAE_DECODER,
-                     synthetic_weights=0, ckpt_path="", vae_ckpt_path="", max_batch=4, precision="bf16x3", dataset_name="Random",
-                     for_steps=100, use_yh_custom_scheduler=True, guidance_scale=7.5, guidance_scale_edit=4.0, prompt_emb=None,
-                     prompt_emb_seed=31, cond_dim=64, for_prompt="a", edit_prompt="b", edit_t=0.7, sampling_mode=False,
-                     tilda_v_score_type="null+(for-null)+(edit-null)", ablation_method="null-space-proj", mask_type="SAM",
-                     vT_path="", use_sega=False, x_space_guidance_edit_step=1.0, x_space_guidance_scale=8.0,
-                     x_space_guidance_num_step=1, result_folder=str(tmp_path))
-    ed = EditStableDiffusion(args)
-    g = torch.Generator().manual_seed(1)
-    z = torch.randn(1, 4, 64, 64, generator=g).to(DEV)
-    mask = torch.zeros(3, 512, 512, dtype=torch.bool); mask[:, 220:260, 140:220] = True
-    t = ed.scheduler.timesteps[ed.edit_t_idx]
-    F, E, N = ed.for_prompt_emb, ed.edit_prompt_emb, ed.null_prompt_emb
-    x0 = ed.get_x0(z, t, ed.edit_t_idx, F, E, N, mask=None, mode="null+(for-null)")
-    assert tuple(x0.shape) == (1, 3, 512, 512) and torch.isfinite(x0).all()
-    op = ed._operator(z, t, mask.to(DEV), "null+(for-null)")
-    V = torch.randn(2, 4 * 64 * 64, generator=g).to(DEV)
-    U = (torch.randn(2, 3 * 512 * 512, generator=g) * mask.reshape(1, -1)).to(DEV)
-    JV, JtU = op.jvp(V), op.vjp(U)
-    lhs, rhs = (JV.double() * U.double()).sum(dim=1), (V.double() * JtU.double()).sum(dim=1)
-    assert ((lhs - rhs).abs() / (JV.norm(dim=1) * U.norm(dim=1)).double()).max().item() < 2e-4      # split-bf16 passes
-    assert float(JV[:, ~mask.reshape(-1).to(DEV)].abs().max()) == 0.0 and op.dec.mask_count() == int(mask.sum())
-    u, s, vT = ed.local_encoder_decoder_pullback_zt(z, t, ed.edit_t_idx, F, E, N, pca_rank=3, min_iter=2, max_iter=2,
-                                                    mask=mask.to(DEV), mode="null+(for-null)", verbose=False)
-    assert u.shape == (int(mask.sum()), 3) and vT.shape == (3, 16384) and bool((s[:-1] >= s[1:]).all())
-    vd = vT.double()
-    assert (vd @ vd.T - torch.eye(3, device=DEV, dtype=torch.float64)).abs().max().item() < 2e-6
+# (test_latent_solver_at_stable_diffusion_size ran the same operator / solver checks on the round-2 stand-in denoiser at this
+# size until round 4: 70 s of the suite for what the test below checks on the Stable Diffusion architecture itself; the
+# stand-in's cross-attention stages stay covered at 16 x 16 in test_text_cross_attention_stages_vs_restatement.)
 
 
 def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
