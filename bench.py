@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64", "tloco_if_i_m", "tloco_sd", "tloco_sd15"], default="celeba_top5")
+    ap.add_argument("--streams", type=int, choices=[1, 2], default=int(os.environ.get("LOCO_STREAMS", "2")),
+                    help="unconditional workloads: probe groups of a tangent / cotangent pass on 1 or 2 HIP streams (the package default is 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end phase timing (inversion ... decode)")
@@ -447,6 +449,9 @@ def main():
         eng = LocoEngine(cfg, max_batch=mb, device=device)
         eng.load_state_dict(params)
         eng.set_precision(prec)
+        # the package default (utils.get_custom_diffusion_model): the two probe groups of a pass on two HIP streams, the side
+        # stream chosen by measurement; 1 when no stream of this process runs beside the current one (or --streams 1)
+        n_streams = eng.set_streams_measured(2) if a.streams == 2 else 1
         x, mask, v0 = synthetic_inputs(cfg, k, device)
 
         def step():
@@ -455,7 +460,7 @@ def main():
             # it cannot end the loop (solver.default_stop_rule: LAPACK's sign flips, tests/golden/converge.pt)
             return solver.local_basis(eng, x, t, at, k, mask=mask, min_iter=MIN_ITER, max_iter=N_ITER,
                                       convergence_threshold=1e-4, v0=v0, sharder=sharder, verbose=False, stop_rule="reference")
-        return dict(cfg=cfg, k=k, keep=keep, eng=eng, params=params, step=step, x=x, mask=mask, v0=v0)
+        return dict(cfg=cfg, k=k, keep=keep, eng=eng, params=params, step=step, x=x, mask=mask, v0=v0, streams=n_streams)
 
     w = make_workload(a.workload, a.precision)
     eng, cfg, k, keep = w["eng"], w["cfg"], w["k"], w["keep"]
@@ -523,6 +528,10 @@ def main():
                      "achieved = algorithmic 2*MAC / time on " + ("the exact-fp32 MFMA" if a.precision == "f32"
                                                                   else "one f16 MFMA per product")),
             "launches": r["launches"], "avg_launch_ms": round(r["ms"] / r["launches"], 4),
+            "measured_on": ("one more step of the same solve with a HIP event pair around every conv launch on the stream it is "
+                            "launched on; that step runs the probe groups on ONE stream (isolated kernel durations, the ones "
+                            "rocprofv3 --kernel-trace reports), the timed steps behind `value` run them on "
+                            f"{w.get('streams', 1)} stream(s)"),
             "flops_per_launch": r["flops"] / r["launches"],
             "conv_share_of_step": round(tot_ms / (t_prof * 1e3), 3),
             "whole_step_TFLOPs_executed_per_gpu": round(executed / (ms_per_step * 1e-3) / 1e12, 2),
@@ -562,15 +571,21 @@ def main():
                                                 "ms_per_step": round(el * 1e3, 3), "dtype": DTYPE_NOTE[prec],
                                                 "parity": parity_vs_fixture(s2, vT2, "celeba256")}
             eng.set_precision(a.precision)
-            # the same solve with the probe groups of a pass on two HIP streams (loco_set_streams): statistics / apply kernels
-            # of one group beside the convolutions of the other.  An extra line, not the headline: kernels that overlap
-            # have no per-kernel duration, so the roofline above is taken on one stream
-            n_st = eng.set_streams_measured(2)      # side stream picked by measurement (loco_set_side_stream): not queue luck
+            # the same solve in the other stream mode (loco_set_streams).  Two streams: the probe groups of a pass side by side,
+            # statistics / apply kernels of one group beside the convolutions of the other -- the package default and the
+            # headline's mode unless --streams 1; the per-kernel durations of the roofline block come from a one-stream step
+            # either way (kernels that overlap have no duration of their own)
+            if w["streams"] == 2:
+                eng.set_streams(1)
+                other, n_st = "celeba_top5_one_stream", 1
+            else:
+                n_st = eng.set_streams_measured(2)      # side stream picked by measurement (loco_set_side_stream): not queue luck
+                other = "celeba_top5_two_streams"
             el, (_, s2, vT2, _) = timed(w["step"], 2, 1)
-            eng.set_streams(1)
-            extra["celeba_top5_two_streams"] = {"value": round(keep / (el / 2), 4), "unit": "edit-directions/s", "streams": n_st,
-                                                "ms_per_step": round(el / 2 * 1e3, 3), "dtype": DTYPE_NOTE[a.precision],
-                                                "parity": parity_vs_fixture(s2, vT2, "celeba256")}
+            eng.set_streams(w["streams"])
+            extra[other] = {"value": round(keep / (el / 2), 4), "unit": "edit-directions/s", "streams": n_st,
+                            "ms_per_step": round(el / 2 * 1e3, 3), "dtype": DTYPE_NOTE[a.precision],
+                            "parity": parity_vs_fixture(s2, vT2, "celeba256")}
         # BASELINE config 5 next to the headline: T-LOCO null-space basis on the DeepFloyd IF-I-M architecture, 2 CFG branches
         w3 = make_workload("tloco_if_i_m", a.precision)
         el, (_, s5, vT5, _) = timed(w3["step"], 1, 1)
@@ -669,6 +684,7 @@ def main():
             "dtype": DTYPE_NOTE[a.precision], "data": "synthetic",
             "config": {"workload": wl, "probes_total": k, "probes_per_gpu": k_local, "kept": keep, "n_iter": int(n_iter),
                        "mask_L": int(w["mask"].sum().item()), "weights": "synthetic seed 0",
+                       **({"streams": w["streams"]} if "streams" in w else {}),
                        "convergence_check": ("executed inside the timed region as in the reference flow (min_iter=10, max_iter=12: "
                                              "one row-wise allclose + 2-float readback at i = 11)" if a.workload in ("celeba_top5", "p2_k64")
                                              else "min_iter == max_iter == 12")},
