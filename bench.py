@@ -65,8 +65,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64", "tloco_if_i_m", "tloco_sd", "tloco_sd15"], default="celeba_top5")
-    ap.add_argument("--streams", type=int, choices=[1, 2], default=int(os.environ.get("LOCO_STREAMS", "2")),
-                    help="unconditional workloads: probe groups of a tangent / cotangent pass on 1 or 2 HIP streams (the package default is 2)")
+    ap.add_argument("--streams", type=int, choices=[1, 2], default=1,
+                    help="unconditional workloads: probe groups of a tangent / cotangent pass on 1 (default, as the package) or 2 HIP "
+                         "streams.  Two streams raise the throughput (-3.5 ... -3.8 %% per headline solve) by overlapping launches of "
+                         "2 and 3 probes, each of which fills the chip worse than the 5-probe launch: the headline and its "
+                         "per-kernel roofline stay on one stream, the two-stream figure is the extra line celeba_top5_two_streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end phase timing (inversion ... decode)")
@@ -449,8 +452,8 @@ def main():
         eng = LocoEngine(cfg, max_batch=mb, device=device)
         eng.load_state_dict(params)
         eng.set_precision(prec)
-        # the package default (utils.get_custom_diffusion_model): the two probe groups of a pass on two HIP streams, the side
-        # stream chosen by measurement; 1 when no stream of this process runs beside the current one (or --streams 1)
+        # --streams 2 (LOCO_STREAMS=2 in the package): the two probe groups of a pass on two HIP streams, the side stream
+        # chosen by measurement; 1 when no stream of this process runs beside the current one
         n_streams = eng.set_streams_measured(2) if a.streams == 2 else 1
         x, mask, v0 = synthetic_inputs(cfg, k, device)
 
@@ -572,9 +575,10 @@ def main():
                                                 "parity": parity_vs_fixture(s2, vT2, "celeba256")}
             eng.set_precision(a.precision)
             # the same solve in the other stream mode (loco_set_streams).  Two streams: the probe groups of a pass side by side,
-            # statistics / apply kernels of one group beside the convolutions of the other -- the package default and the
-            # headline's mode unless --streams 1; the per-kernel durations of the roofline block come from a one-stream step
-            # either way (kernels that overlap have no duration of their own)
+            # statistics / apply kernels of one group beside the convolutions of the other.  An extra line, not the headline:
+            # the pass then consists of 2- and 3-probe launches (isolated, each is a worse kernel than the 5-probe launch:
+            # 82.9 us for 2.5 probes on average against 101.7 us for 5 under rocprofv3 on one box) whose overlap is what wins,
+            # so per-kernel durations and the roofline fraction are only meaningful on one stream
             if w["streams"] == 2:
                 eng.set_streams(1)
                 other, n_st = "celeba_top5_one_stream", 1

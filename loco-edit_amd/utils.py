@@ -54,11 +54,11 @@ def get_custom_diffusion_model(args) -> HipUNet:
     prec = getattr(args, "precision", None) or os.environ.get("LOCO_PRECISION")
     if prec:
         engine.set_precision(prec)
-    # the two probe groups of a tangent / cotangent pass side by side on two HIP streams: statistics / apply kernels of one
-    # group run beside the convolutions of the other (-3.3 ... -4 % per 256 x 256 solve on every box measured); the side
-    # stream is chosen by measurement and the mode falls back to one stream when none runs beside the current one.
-    # LOCO_STREAMS=1: one stream.  Results agree to rounding (the split-K / tail-probe choices follow the group size).
-    if os.environ.get("LOCO_STREAMS", "2") == "2" and torch.device(args.device).type == "cuda":
+    # LOCO_STREAMS=2: the two probe groups of a tangent / cotangent pass side by side on two HIP streams (statistics / apply
+    # kernels of one group beside the convolutions of the other: -3.5 ... -3.8 % per 256 x 256 solve on every box measured,
+    # results equal to rounding); the side stream is chosen by measurement, one stream when none runs beside the current one.
+    # Opt-in: the pass then runs as 2- and 3-probe launches, which only pay off through their overlap.
+    if os.environ.get("LOCO_STREAMS", "1") == "2" and torch.device(args.device).type == "cuda":
         engine.set_streams_measured(2)
     ckpt = getattr(args, "ckpt_path", "")
     if ckpt:
