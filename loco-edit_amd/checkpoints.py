@@ -448,6 +448,9 @@ def _split_heads(w, heads, n):
 
 
 def hf_if_unet_to_native(sd: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    if not (cfg.added_kv and cfg.num_head_channels > 0):
+        raise ValueError("a DeepFloyd-IF checkpoint needs an added-KV architecture (config.if_stage1_config), "
+                         f"not {cfg.arch!r} with added_kv={cfg.added_kv}")
     nrb, nlev, has_attn = _ldm_block_index(cfg)
     sd = {k: torch.as_tensor(v) for k, v in sd.items()}
     out: Dict[str, torch.Tensor] = {}

@@ -183,6 +183,20 @@ MID_IF64 = UNetConfig(resolution=64, ch=64, ch_mult=(1, 2, 3, 4), num_res_blocks
 IF_I_M_UNET = UNetConfig(resolution=64, ch=192, ch_mult=(1, 2, 3, 4), num_res_blocks=3, attn_resolutions=(32, 16, 8),
                          gn_eps=1e-5, arch="adm", num_head_channels=64, learn_sigma=True, context_dim=768, context_len=77,
                          act="gelu", res_scale=0.7071067811865476, added_kv=True, encoder_dim=4096)
+# the other published stage-I sizes share the tree: IF-I-L at 320 channels (0.9 B parameters), IF-I-XL at 704 (4.3 B; one
+# engine context keeps six layouts of every conv operator, so three XL contexts do not fit one GPU -- stated, not built for)
+IF_I_WIDTH = {"M": 192, "L": 320, "XL": 704}
+
+
+def if_stage1_config(size: str) -> UNetConfig:
+    """`DeepFloyd/IF-I-<size>-v1.0` -> the stage-I U-Net configuration (`IF_I_M_UNET` with that size's width; the text states
+    are projected to 4 * width channels)."""
+    if size not in IF_I_WIDTH:
+        raise ValueError(f"unknown DeepFloyd IF stage-I size {size!r} (known: {sorted(IF_I_WIDTH)})")
+    ch = IF_I_WIDTH[size]
+    return IF_I_M_UNET if size == "M" else UNetConfig(**{**IF_I_M_UNET.__dict__, "ch": ch, "context_dim": 4 * ch})
+
+
 # the same switches at sizes autodiff on the CPU finishes in seconds (two attention levels, a resampling ResBlock each way,
 # a channel-changing shortcut, 16-channel heads, 7 text states of width 24 -> 32)
 TINY_IF = UNetConfig(resolution=32, ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16, 8), gn_eps=1e-5,

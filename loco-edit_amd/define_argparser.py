@@ -229,7 +229,8 @@ def _preset_t2i(args, family):
         if getattr(args, 'unet_config', None) is None:
             # the stage-I U-Net of the id the shipped scripts name (scripts/main_T2I_DeepFloydIF_null_space_projection*.sh:4,
             # DeepFloyd/IF-I-M-v1.0); `--unet_preset if64_standin` / `if64_xattn_standin` select the round-2 / 3 stand-ins
-            args.unet_config = config.IF_I_M_UNET
+            parts = args.model_name.split("-")               # "DeepFloyd/IF-I-M-v1.0" -> size "M" (edit.py:1204)
+            args.unet_config = config.if_stage1_config(parts[2] if len(parts) > 2 and parts[2] in config.IF_I_WIDTH else "M")
         args.c_in = 3
     args.image_size = args.unet_config.resolution          # 64: SD latents and the IF stage-I models alike
     args.memory_bound = 5

@@ -26,8 +26,10 @@ def test_if_presets_routing_and_size(tmp_path, monkeypatch):
     total = sum(math.prod(s) for s in shapes.values())
     # IF-I-M is published as a 400 M-parameter model; the same tree at 704 channels gives IF-I-XL's 4.3 B
     assert (total - host, host, total) == (314_955_078, 56_650_752, 371_605_830)
-    xl = C.UNetConfig(**{**cfg.__dict__, "ch": 704, "context_dim": 2816})
-    assert 4.2e9 < sum(math.prod(s) for s in C.param_shapes(xl).values()) < 4.4e9
+    xl, lg = C.if_stage1_config("XL"), C.if_stage1_config("L")
+    assert (xl.ch, xl.context_dim, lg.ch) == (704, 2816, 320) and C.if_stage1_config("M") is cfg
+    assert 4.2e9 < sum(math.prod(s) for s in C.param_shapes(xl).values()) < 4.4e9       # published: 4.3 B
+    assert 0.85e9 < sum(math.prod(s) for s in C.param_shapes(lg).values()) < 1.0e9      # published: 0.9 B
     import json
     monkeypatch.chdir(tmp_path)
     argv = json.load(open(os.path.join(ROOT, "tests", "golden", "script_args.json")))["main_T2I_DeepFloydIF_null_space_projection.sh"]
@@ -35,6 +37,12 @@ def test_if_presets_routing_and_size(tmp_path, monkeypatch):
     assert a.is_DeepFloyd_IF_diffusion and a.unet_config is C.IF_I_M_UNET and a.model_name.split("-")[2] == "M"
     b = define_argparser.preset(define_argparser.parse_args(argv + ["--device", "cpu", "--unet_preset", "if64_standin"]))
     assert b.unet_config is C.IF64_STANDIN
+    i = argv.index("--model_name")
+    argv_l = argv[:i + 1] + ["DeepFloyd/IF-I-L-v1.0"] + argv[i + 2:]
+    assert define_argparser.preset(define_argparser.parse_args(argv_l + ["--device", "cpu"])).unet_config.ch == 320
+    import pytest
+    with pytest.raises(ValueError):
+        K.hf_if_unet_to_native({}, C.FFHQ_P2)
 
 
 def test_if_text_conditioner_equals_restatement():
