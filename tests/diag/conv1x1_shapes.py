@@ -15,4 +15,4 @@ for cin, cout, hw in ((256, 128, 256), (128, 256, 256), (256, 128, 128), (384, 2
         us = eng.bench_conv(cin, cout, hw, hw, B, 0, 1, -1, 8) * 1e3
         gf = 2.0 * cin * cout * hw * hw * B / 1e9
         mb = 4.0 * (cin + cout) * hw * hw * B / 1e6
-        print(f"1x1 {cin}->{cout} @{hw} B={B}: {us:7.1f} us  {gf / us:6.1f} TFLOP/s  {mb / us:6.2f} TB/s (in+out)", flush=True)
+        print(f"1x1 {cin}->{cout} @{hw} B={B}: {us:7.1f} us  {gf / us * 1e3:6.1f} TFLOP/s  {mb / us:6.2f} TB/s (in+out)", flush=True)
