@@ -247,7 +247,11 @@ int  loco_latent_sample(loco_ctx* ctx, const float* moments, const float* noise,
  * several conditions (edit.py:1324-1372).  src: host array of device pointers, coef: host array; out may alias a src. */
 /* Encoder states of the prompt for the cross-attention stages (context_dim > 0): tokens = device pointer to
  * [context_len][context_dim] fp32.  Projects them to the per-block keys / values once; the cached primal is
- * invalidated.  Replaces `encoder_hidden_states=prompt_emb` of self.unet(...) (edit.py:664-667, 1319-1322). */
+ * invalidated.  Replaces `encoder_hidden_states=prompt_emb` of self.unet(...) (edit.py:664-667, 1319-1322).
+ * With cfg.added_kv (the DeepFloyd-IF U-Net) the tokens are the states AFTER the model's `encoder_hid_proj` (the host computes
+ * that projection and the pooled `add_embedding` for loco_set_cond once per prompt): every attention block passes them
+ * through its own GroupNorm (`norm_cross`) and key / value projections (`add_k_proj`, `add_v_proj`) here, and attends over
+ * [these ; its image tokens] in one softmax. */
 int  loco_set_context(loco_ctx* ctx, const float* tokens, void* stream);
 
 int  loco_lincomb(loco_ctx* ctx, const float* const* src, const float* coef, int32_t n, float* out, int64_t count,
