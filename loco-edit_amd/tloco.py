@@ -269,9 +269,16 @@ class CFGJacobianOperator:
 class EditDeepFloydIF(object):
     def __init__(self, args):
         self.device, self.dtype = args.device, args.dtype
-        if self.dtype != torch.float32:
-            raise ValueError("tensors stay fp32 on this engine; choose the conv arithmetic with --precision "
-                             "(the reference's IF default is fp16 storage, edit.py:1653 casts to fp32 before the SVD)")
+        if self.dtype == torch.float16:
+            # `--dtype fp16` (the reference loads its IF / SD pipelines with torch_dtype=float16, utils.py:260-283, and casts to
+            # fp32 before the SVD, edit.py:1653): tensors stay fp32 on this engine, the request selects the f16 conv arithmetic
+            # (f16 MFMA operands, fp32 accumulate) unless --precision says otherwise
+            if not (getattr(args, "precision", None) or os.environ.get("LOCO_PRECISION")):
+                args.precision = "f16"
+            print(f"dtype fp16: fp32 tensors with conv arithmetic {getattr(args, 'precision', None) or os.environ.get('LOCO_PRECISION')}")
+            self.dtype = torch.float32
+        elif self.dtype != torch.float32:
+            raise ValueError("tensors are fp32 on this engine; choose the conv arithmetic with --precision")
         self.buffer_device, self.memory_bound = getattr(args, "buffer_device", "cpu"), getattr(args, "memory_bound", 5)
         self.seed = args.seed
         cfg: UNetConfig = args.unet_config

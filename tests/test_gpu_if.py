@@ -155,6 +155,14 @@ def test_cli_shipped_if_script_on_the_if_architecture(tmp_path, monkeypatch):
     torch.save(masks, str(rdir / "mask" / "mask.pt"))
     x0 = main(argv + ["--device", DEV, "--unet_preset", "tiny_if", "--synthetic_weights", "0"])
     assert x0.dtype == torch.uint8 and tuple(x0.shape) == (3, 32, 32, 3)
+    # `--dtype fp16` (how the reference loads its IF pipeline) selects the f16 conv arithmetic over fp32 tensors
+    monkeypatch.delenv("LOCO_PRECISION", raising=False)
+    from loco_edit_amd import define_argparser
+    from loco_edit_amd.tloco import EditDeepFloydIF
+    a16 = define_argparser.preset(define_argparser.parse_args(argv + ["--device", DEV, "--unet_preset", "tiny_if", "--synthetic_weights", "0",
+                                                                      "--dtype", "fp16"]))
+    ed = EditDeepFloydIF(a16)
+    assert ed.engine.get_precision() == "f16" and ed.dtype == torch.float32
     pcs = [f for f in os.listdir(rdir / "basis") if f.endswith("-pc_000-vT.pt")]
     assert len(pcs) == 1
     v = torch.load(str(rdir / "basis" / pcs[0]))
