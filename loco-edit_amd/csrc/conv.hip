@@ -362,6 +362,12 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
         if (!kn2[prec][mm][0]) snprintf(kn2[prec][mm], 40, "%s<2,4,2,2,%d>", prec == 1 ? "conv_kcat_bf16x3" : "conv_kcat_f16", mm);
         return kn2[prec][mm];
     }
+    if (prec == 1 && taps == 9 && a.dual) {
+        static char dn[5][40];
+        const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;
+        if (!dn[mm][0]) snprintf(dn[mm], 40, "conv_dual_bf16x3<%d>", mm);
+        return dn[mm];
+    }
     if (prec && conv_lowp_uses_spec(a, taps)) {
         static char sn[3][5][40];
         const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;

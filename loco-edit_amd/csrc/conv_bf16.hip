@@ -96,6 +96,61 @@ bool conv_lowp_can_fuse_stats(const ConvArgs& a) {
 }
 
 template <int PR, int MODE> void launch_kcat_b(const ConvArgs& a, hipStream_t st);   // conv_bf16_inst_*.hip
+template <int PR, int MODE> void launch_dual_b(const ConvArgs& a, hipStream_t st);   // conv_bf16_inst_h / _i.hip (conv_dual_kernel.h)
+
+// Dual-probe tile policy.  Opt-in (LOCO_CONV_DUAL=1): measured neutral on the headline (+1.2 %) and on config 3 (-0.2 %) in round 5
+// (profiles/r05_experiments.md: the tile halves the weight bytes per FLOP, but weight traffic is not what a launch waits for).
+// LOCO_DUAL_MIN_UNITS: fewest dual units (pixel tiles x cout tiles x probe pairs) a launch must have -- below ~3/4 of the CUs
+// the wider tile leaves too much of the chip idle (the 128 x 128 level of the headline: 64 tiles x 2 pairs).
+static int conv_dual_min_units() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("LOCO_CONV_DUAL");
+        if (!e || atoi(e) == 0) v = -1;
+        else { const char* m = getenv("LOCO_DUAL_MIN_UNITS"); v = m ? atoi(m) : 192; }
+    }
+    return v;
+}
+bool conv_dual_ok(const ConvArgs& a) {
+    const int minu = conv_dual_min_units();
+    if (minu < 0) return false;
+    if (a.taps != 9 || a.Cin2 > 0 || a.nsplit != 1 || a.stride != 1 || a.upsample || a.zins || a.pad != 1 || (a.Cin % BKC) != 0 ||
+        !a.in_padded || a.Wout < 32 || (a.Wout % 32) != 0 || (a.Hout % 8) != 0 || (a.Cout % 128) != 0 || a.B < 2 || a.cot_d)
+        return false;
+    if (!(a.mode == CM_NONE || a.mode == CM_GN_SILU || a.mode == CM_TAN_SILU || a.mode == CM_COT_SILU)) return false;
+    if (bf16_tile_of(a) != 5) return false;
+    const long units = (long)((a.Hout * a.Wout) / 256) * (a.Cout / 128) * (a.B / 2);
+    return units >= minu;
+}
+// `a` restricted to its samples nb .. B - 1
+static ConvArgs conv_shift_batch(const ConvArgs& a, int nb) {
+    ConvArgs t = a;
+    t.B = a.B - nb;
+    t.in += (long)nb * a.in_bs; t.out += (long)nb * a.out_bs;
+    if (t.prim) t.prim += (long)nb * a.prim_bs;
+    if (t.bias2) t.bias2 += (long)nb * a.bias2_bs;
+    if (t.res) t.res += (long)nb * a.res_bs;
+    if (t.sc) { t.sc += (long)nb * a.scsh_bs; t.sh += (long)nb * a.scsh_bs; }
+    if (t.mr) t.mr += (long)nb * a.mr_bs;
+    if (t.tst) t.tst += (long)nb * a.tst_bs;
+    if (t.tc) t.tc += (long)nb * a.tc_bs;
+    if (t.in2) t.in2 += (long)nb * a.in2_bs;
+    if (t.cot_d) { t.cot_d += (long)nb * a.cot_d_bs; t.cot_tst += (long)nb * a.cot_tst_bs; }
+    if (t.st_part) t.st_part += (long)nb * a.Cout * ((a.Hout * a.Wout) / conv_bf16_tile_pixels(a)) * 2;
+    return t;
+}
+int conv_lowp_plan(const ConvArgs& a, int taps, int prec, ConvArgs parts[2]) {
+    parts[0] = a;
+    parts[0].dual = 0;
+    ConvArgs q = a; q.taps = taps;
+    if (prec != 1 || taps != 9 || !conv_dual_ok(q)) return 1;
+    parts[0].B = a.B & ~1;
+    parts[0].dual = 1;
+    if (!(a.B & 1)) return 1;
+    parts[1] = conv_shift_batch(a, a.B - 1);
+    parts[1].dual = 0;
+    return 2;
+}
 
 template <int PR>
 static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
@@ -103,6 +158,17 @@ static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
         if (a.mode == CM_GN_SILU) launch_kcat_b<PR, CM_GN_SILU>(a, st);
         else launch_kcat_b<PR, CM_TAN_SILU>(a, st);
         return;
+    }
+    if constexpr (PR == PR_BF16X3) {
+        if (taps == 9 && a.dual) {           // conv_lowp_plan checked conv_dual_ok
+            switch (a.mode) {
+                case CM_NONE: launch_dual_b<PR, CM_NONE>(a, st); break;
+                case CM_GN_SILU: launch_dual_b<PR, CM_GN_SILU>(a, st); break;
+                case CM_TAN_SILU: launch_dual_b<PR, CM_TAN_SILU>(a, st); break;
+                default: launch_dual_b<PR, CM_COT_SILU>(a, st); break;
+            }
+            return;
+        }
     }
     if (taps == 9) {
         switch (a.mode) {

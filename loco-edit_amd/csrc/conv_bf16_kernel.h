@@ -343,6 +343,13 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     constexpr int DEEP_D = 4;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+#ifdef LOCO_DUAL_STAMP
+    // diagnostics build only (tests/diag/lowp_stamps.py): s_memtime at the phase boundaries of every workgroup, wave 0 lane 0
+#define LP_STAMP(i) do { if (threadIdx.x == 0 && PHASE == 0) reinterpret_cast<unsigned long long*>(a.partial)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LP_STAMP(i) do { } while (0)
+#endif
+    LP_STAMP(0);
     // double-buffered: weight stage s lives in W buffer s&1, the halo of chunk c in H buffer c&1
     constexpr int WBYTES = NTS * MT * RB;
     unsigned char* const Wsb = smem_b;               // 2 x [NTS][MT] records
@@ -586,6 +593,9 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     // 128-channel conv's halo bytes through the CU's vector-memory path).  `pf_live == false` (wave-uniform) collapses such
     // a load onto one address: every lane reads the same 16 bytes, one cache line per instruction.
     bool pf_live = true, dma_live = true;
+#ifdef LOCO_DUAL_STAMP
+    const bool wi_halo = (a.no_deep & 2) != 0, wi_dma = (a.no_deep & 4) != 0, wi_novalu = (a.no_deep & 8) != 0;
+#endif
     auto prefetch_hv = [&](HaloRegs& R, int chunk, int part) {
         // wave-uniform chunk base (SGPR pair) + 32-bit per-lane byte offset: global_load saddr form, no 64-bit VALU
         // (32-bit scalar offset arithmetic: one sample's tensor is far below 4 GB)
@@ -595,7 +605,11 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         const unsigned pl = (unsigned)in_plane * 4u;
 #pragma unroll
         for (int kk = 0; kk < KP; ++kk) {
+#ifdef LOCO_DUAL_STAMP
+            const unsigned po = (pf_live && !wi_halo) ? v_goff + (unsigned)(part * KP + kk) * pl : 64u;
+#else
             const unsigned po = pf_live ? v_goff + (unsigned)(part * KP + kk) * pl : 64u;     // 64 = the first element itself
+#endif
             // 4-byte aligned 16-byte loads (global memory tolerates dword alignment)
             R.dq[kk] = *reinterpret_cast<const f32x4_u*>(pk + po);
             if constexpr (NEEDP) {
@@ -618,6 +632,9 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         }
     };
     auto stage_hv = [&](const HaloRegs& R, int part) {
+#ifdef LOCO_DUAL_STAMP
+        if (wi_novalu) return;
+#endif
         const int oct = v_q4 >> 1, half = v_q4 & 1;
 #pragma unroll
         for (int pxi = 0; pxi < 4; ++pxi) {
@@ -635,8 +652,9 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                     v = fmaf(cq_a(R, kk), d, cq_b(R, kk));
                 } else if constexpr (NEEDP) {
                     const float Sv = R.sq[kk][pxi >> 1][(pxi & 1) * 2], xh = R.sq[kk][pxi >> 1][(pxi & 1) * 2 + 1];
-                    if constexpr (MODE == CM_TAN_SILU) v = Sv * (d - cq_a(R, kk) - xh * cq_b(R, kk));
-                    else v = Sv * d - cq_a(R, kk) - xh * cq_b(R, kk);
+                    // (explicit fused forms: the dual-probe tile of conv_dual_kernel.h computes the same bits)
+                    if constexpr (MODE == CM_TAN_SILU) v = Sv * fmaf(-xh, cq_b(R, kk), d - cq_a(R, kk));
+                    else v = fmaf(-xh, cq_b(R, kk), fmaf(Sv, d, -cq_a(R, kk)));
                 }
                 r[kk] = ((v_pm >> pxi) & 1u) ? v : 0.0f;
             }
@@ -727,7 +745,11 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         for (int i = 0; i < NWV; ++i) {
             const int e0 = (wave * 64 + i * NTHR);                 // first piece of this wave's 1 KiB slab
             if ((WTOT % NTHR) == 0 || e0 < WTOT)                   // wave-uniform
+#ifdef LOCO_DUAL_STAMP
+                __builtin_amdgcn_global_load_lds((glb_u8*)(wbase + ((dma_live && !wi_dma) ? wrel[i] : 0u)), (lds_u8*)(Wdst + e0 * 16), 16, 0, 0);
+#else
                 __builtin_amdgcn_global_load_lds((glb_u8*)(wbase + (dma_live ? wrel[i] : 0u)), (lds_u8*)(Wdst + e0 * 16), 16, 0, 0);
+#endif
         }
     };
     auto stage_regs = [&](const float (&hvs)[NITEM][8], int chunk, unsigned char* Hd) {
@@ -756,8 +778,8 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                             r = fmaf(ca, d, cb);
                         } else {
                             float Sv = pv[i][k].x, xh = pv[i][k].y;
-                            if constexpr (MODE == CM_TAN_SILU) r = Sv * (d - ca - xh * cb);
-                            else r = Sv * d - ca - xh * cb;
+                            if constexpr (MODE == CM_TAN_SILU) r = Sv * fmaf(-xh, cb, d - ca);
+                            else r = fmaf(-xh, cb, fmaf(Sv, d, -ca));
                         }
                     }
                 }
@@ -868,6 +890,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
             c_out = cclamp(cbeg + ci_ + row_ / NROW);
             r_out = row_ % NROW;
         };
+        LP_STAMP(1);
         if (nch > 0) {
             if constexpr (!(PHASE != 2 && EARLY_W)) {      // (otherwise issued at the top of the kernel)
                 int c1, r1;
@@ -894,6 +917,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
             Ws = Wsb; Hs = Hsb;
             load_frag(fr[0], 0, 0);                   // the only exposed operand read of the tile
         }
+        LP_STAMP(2);
         auto chunk_body = [&](auto ptag, const int ci) {
             constexpr int P = decltype(ptag)::value;
             const int chunk = cbeg + ci;
@@ -1134,7 +1158,10 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         __builtin_amdgcn_s_barrier();
         return;
     }
+    LP_STAMP(3);
     conv_lowp_epilogue<WM, WN, TM, TN>(a, acc, smem_b, co0, oy0, ox0, TW, tile_id, b, split);
+    LP_STAMP(4);
+#undef LP_STAMP
 }
 
 // ---------------------------------------------------------------------------

@@ -1344,22 +1344,31 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     };
     auto one = [&](ConvArgs& x, int s0) {
         const int how = stats_of(x, s0);
-        loco_ctx::ProfRec r, rr;
-        if (c->prof_on) {
-            r.name = conv_variant_name(x, taps, c->prec);
-            r.flops = 2.0 * (x.Cin * taps + x.Cin2) * x.Cout * (double)x.Hout * x.Wout * x.B;
-            if (x.zins) r.flops *= 0.25;     // algorithmic work of the stride-2 data gradient
-            r.cin = x.Cin; r.cout = x.Cout; r.h = x.Hout; r.b = x.B; r.ns = x.nsplit; r.mode = x.mode; r.taps = taps;
-            r.e0 = c->next_event(); r.e1 = c->next_event();
-            (void)hipEventRecord(r.e0, st);
-        }
-        if (c->prec == 1) launch_conv_bf16x3(x, taps, st);
-        else if (c->prec == 2) launch_conv_f16(x, taps, st);
-        else launch_conv(x, taps, st);
-        if (c->prof_on) { (void)hipEventRecord(r.e1, st); c->prof.push_back(r); }
-        if (x.nsplit > 1) {
+        // the launch as the low-precision dispatcher runs it: its even part on the dual-probe tile + an odd last probe on the
+        // 128 x 256 tile (conv_lowp_plan), each kernel with its own profile record
+        ConvArgs parts[2];
+        const int nparts = conv_lowp_plan(x, taps, c->prec, parts);
+        for (int pi = 0; pi < nparts; ++pi) {
+            ConvArgs& y = parts[pi];
+            loco_ctx::ProfRec r;
             if (c->prof_on) {
-                rr = r; rr.name = "conv_splitk_reduce"; rr.flops = 0.0;
+                r.name = conv_variant_name(y, taps, c->prec);
+                r.flops = 2.0 * (y.Cin * taps + y.Cin2) * y.Cout * (double)y.Hout * y.Wout * y.B;
+                if (y.zins) r.flops *= 0.25;     // algorithmic work of the stride-2 data gradient
+                r.cin = y.Cin; r.cout = y.Cout; r.h = y.Hout; r.b = y.B; r.ns = y.nsplit; r.mode = y.mode; r.taps = taps;
+                r.e0 = c->next_event(); r.e1 = c->next_event();
+                (void)hipEventRecord(r.e0, st);
+            }
+            if (c->prec == 1) launch_conv_bf16x3(y, taps, st);
+            else if (c->prec == 2) launch_conv_f16(y, taps, st);
+            else launch_conv(y, taps, st);
+            if (c->prof_on) { (void)hipEventRecord(r.e1, st); c->prof.push_back(r); }
+        }
+        if (x.nsplit > 1) {
+            loco_ctx::ProfRec rr;
+            if (c->prof_on) {
+                rr.name = "conv_splitk_reduce"; rr.flops = 0.0;
+                rr.cin = x.Cin; rr.cout = x.Cout; rr.h = x.Hout; rr.b = x.B; rr.ns = x.nsplit; rr.mode = x.mode; rr.taps = taps;
                 rr.e0 = c->next_event(); rr.e1 = c->next_event();
                 (void)hipEventRecord(rr.e0, st);
             }
@@ -3141,12 +3150,17 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     a.tc = c->statsT + 64; a.tc_bs = c->stats_per_sample;
     if (a.cpg < 1) a.cpg = 1;
     a.nsplit = 1; a.partial = c->partial;
+    if (const char* e = getenv("LOCO_DUAL_WHATIF")) a.no_deep = atoi(e);      // stamp build of the dual tile only (bits 2 / 4)
     int saved = g_bf16_tile_override;
     g_bf16_tile_override = tile;
+    ConvArgs parts[2];
+    const int nparts = conv_lowp_plan(a, taps, c->prec, parts);
     auto run = [&]() {
-        if (c->prec == 1) launch_conv_bf16x3(a, taps, st);
-        else if (c->prec == 2) launch_conv_f16(a, taps, st);
-        else launch_conv(a, taps, st);
+        for (int pi = 0; pi < nparts; ++pi) {
+            if (c->prec == 1) launch_conv_bf16x3(parts[pi], taps, st);
+            else if (c->prec == 2) launch_conv_f16(parts[pi], taps, st);
+            else launch_conv(parts[pi], taps, st);
+        }
         launch_conv_splitk_reduce(a, st);
     };
     run();

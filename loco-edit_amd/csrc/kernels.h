@@ -103,6 +103,7 @@ struct ConvArgs {
     const float* cot_sc; const float* cot_sh; const float* cot_mr; const float* cot_tst; long cot_tst_bs; int cot_cpg;
     int act;           // ActKind of the prologue modes (exact-fp32 kernel, split-K statistics epilogue)
     float res_scale;   // out = conv + bias + res_scale * res  (DeepFloyd-IF: (x + h) / sqrt 2 with the conv's weights pre-scaled); conv_defaults: 1
+    int dual;          // 1: run on the dual-probe tile of conv_dual_kernel.h (B even; set by conv_lowp_plan, never by the engine)
 };
 
 // the conv kernel only; when a.nsplit > 1 the caller follows with launch_conv_splitk_reduce (run_conv does)
@@ -110,6 +111,10 @@ void launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 void launch_conv_bf16x3(const ConvArgs& a, int taps, hipStream_t st);
 void launch_conv_f16(const ConvArgs& a, int taps, hipStream_t st);     // a.wb = the f16 weight records
 void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st);
+// Dual-probe tile (conv_dual_kernel.h): a low-precision launch is split into its even part on the dual tile (parts[0], `dual`
+// set) and -- for an odd batch -- the last probe on the 128 x 256 tile (parts[1]); returns the number of parts (1: `a` itself).
+bool conv_dual_ok(const ConvArgs& a);
+int conv_lowp_plan(const ConvArgs& a, int taps, int prec, ConvArgs parts[2]);
 // can a launch with these arguments feed a.st_part from its epilogue?  (whole cout tiles of the chosen variant, no split-K)
 bool conv_lowp_can_fuse_stats(const ConvArgs& a);
 int conv_bf16_tile_couts(const ConvArgs& a);

@@ -71,7 +71,10 @@ def run_pass(name, counters):
 
 res = {}
 missing = []
+ONLY = os.environ.get('PMC_BLOCKS', '')
 for blk, cands in CAND.items():
+    if ONLY and blk not in ONLY.split(','):
+        continue
     have = [c for c in cands if c in avail]
     missing += [c for c in cands if c not in avail]
     n = PER_PASS[blk]
