@@ -482,6 +482,32 @@ def dec_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     return shapes
 
 
+def _synth_tensor(cfg: UNetConfig, seed: int, name: str, shape) -> np.ndarray:
+    if cfg.encoder_dim >= 1024 and name.startswith("encoder_pooling.1.") and len(shape) == 2 and shape[0] == shape[1]:
+        # the three E x E maps of the attention pooling (3 x 16.8 M values at E = 4096): a cheap deterministic fill
+        rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+        row = rng.standard_normal(shape[1]).astype(np.float32) / np.sqrt(shape[1])
+        return np.ascontiguousarray(np.stack([np.roll(row, i) for i in range(shape[0])]).astype(np.float32))
+    rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+    z = rng.standard_normal(shape).astype(np.float32)
+    if name.endswith(".bias"):
+        if (".norm" in name or name.startswith("norm_out") or name.endswith("in_layers.0.bias")
+                or name.endswith("out_layers.0.bias") or name == "out.0.bias"):
+            val = 0.1 * z
+        else:
+            val = 0.05 * z
+    elif len(shape) == 1:  # norm gain
+        val = 1.0 + 0.1 * z
+    else:
+        fan_in = int(np.prod(shape[1:]))
+        val = z / np.sqrt(fan_in)
+    return np.ascontiguousarray(val.astype(np.float32))
+
+
+_SYNTH_CACHE: "OrderedDict[tuple, Dict[str, np.ndarray]]" = OrderedDict()
+_SYNTH_CACHE_MAX_BYTES = 8 << 30
+
+
 def synth_params(cfg: UNetConfig, seed: int = 0) -> Dict[str, np.ndarray]:
     """Deterministic synthetic checkpoint (no hub / cluster weights offline).
 
@@ -490,27 +516,31 @@ def synth_params(cfg: UNetConfig, seed: int = 0) -> Dict[str, np.ndarray]:
     keep activations O(1): conv/linear weights ~ N(0, 1/fan_in), norm gains
     1 + 0.1 N, biases 0.05 N.  No tensor is zero (a zero-initialised output
     conv would make d eps / d x vanish).
+
+    The tensors are independent streams, so they are drawn on a thread pool (numpy releases the GIL while it fills), and the
+    most recent results are kept per process (the at-size tests and the T-LOCO classes ask for the same 860 M-parameter set
+    several times: 37 s each on 8 cores, three quarters of the former at-size test time).  The returned dict is a fresh one
+    over shared arrays: treat the arrays as read-only.
     """
-    out: Dict[str, np.ndarray] = {}
-    for name, shape in param_shapes(cfg).items():
-        if cfg.encoder_dim >= 1024 and name.startswith("encoder_pooling.1.") and len(shape) == 2 and shape[0] == shape[1]:
-            # the three E x E maps of the attention pooling (3 x 16.8 M values at E = 4096): a cheap deterministic fill
-            rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
-            row = rng.standard_normal(shape[1]).astype(np.float32) / np.sqrt(shape[1])
-            out[name] = np.ascontiguousarray(np.stack([np.roll(row, i) for i in range(shape[0])]).astype(np.float32))
-            continue
-        rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
-        z = rng.standard_normal(shape).astype(np.float32)
-        if name.endswith(".bias"):
-            if (".norm" in name or name.startswith("norm_out") or name.endswith("in_layers.0.bias")
-                    or name.endswith("out_layers.0.bias") or name == "out.0.bias"):
-                val = 0.1 * z
-            else:
-                val = 0.05 * z
-        elif len(shape) == 1:  # norm gain
-            val = 1.0 + 0.1 * z
-        else:
-            fan_in = int(np.prod(shape[1:]))
-            val = z / np.sqrt(fan_in)
-        out[name] = np.ascontiguousarray(val.astype(np.float32))
-    return out
+    key = (cfg, int(seed))
+    hit = _SYNTH_CACHE.get(key)
+    if hit is not None:
+        _SYNTH_CACHE.move_to_end(key)
+        return dict(hit)
+    shapes = param_shapes(cfg)
+    names = sorted(shapes, key=lambda n: -int(np.prod(shapes[n])))
+    total = sum(int(np.prod(s)) for s in shapes.values())
+    if total > (1 << 22):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            vals = list(ex.map(lambda n: _synth_tensor(cfg, seed, n, shapes[n]), names))
+        drawn = dict(zip(names, vals))
+    else:
+        drawn = {n: _synth_tensor(cfg, seed, n, shapes[n]) for n in names}
+    out: Dict[str, np.ndarray] = {n: drawn[n] for n in shapes}      # the parameter list's own order
+    _SYNTH_CACHE[key] = out
+    size = lambda d: sum(v.nbytes for v in d.values())
+    while len(_SYNTH_CACHE) > 1 and sum(size(d) for d in _SYNTH_CACHE.values()) > _SYNTH_CACHE_MAX_BYTES:
+        _SYNTH_CACHE.popitem(last=False)
+    return dict(out)

@@ -357,22 +357,22 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
     if (prec && a.stride == 2 && t == 5) t = 0;
     if (t < 0 || t > 5) t = 0;
     if (prec && taps == 9 && a.Cin2 > 0) {
-        static char kn2[3][5][40];
-        const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;
+        static char kn2[3][6][40];
+        const int mm = (a.mode < 0 || a.mode > 5) ? 2 : a.mode;
         if (!kn2[prec][mm][0]) snprintf(kn2[prec][mm], 40, "%s<2,4,2,2,%d>", prec == 1 ? "conv_kcat_bf16x3" : "conv_kcat_f16", mm);
         return kn2[prec][mm];
+    }
+    if (prec == 1 && taps == 1 && a.gemm) {
+        static char gn[2][40];
+        char* n = gn[a.gemm_tm == 4];
+        if (!n[0]) snprintf(n, 40, "conv_gemm_bf16x3<%d>", a.gemm_tm);
+        return n;
     }
     if (prec == 1 && taps == 9 && a.dual) {
         static char dn[5][40];
         const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;
         if (!dn[mm][0]) snprintf(dn[mm], 40, "conv_dual_bf16x3<%d>", mm);
         return dn[mm];
-    }
-    if (prec && conv_lowp_uses_spec(a, taps)) {
-        static char sn[3][5][40];
-        const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;
-        if (!sn[prec][mm][0]) snprintf(sn[prec][mm], 40, "%s<%d>", prec == 1 ? "conv_spec_bf16x3" : "conv_spec_f16", mm);
-        return sn[prec][mm];
     }
     int ti = taps == 9 ? 0 : 1;
     int m = a.mode;

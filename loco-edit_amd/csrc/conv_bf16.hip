@@ -59,35 +59,22 @@ int bf16_tile_of(const ConvArgs& a) {
     return tile;
 }
 int conv_bf16_tile_pixels(const ConvArgs& a) {
+    if (a.gemm) return 256;
     static const int NTs[7] = {128, 64, 128, 64, 256, 256, 128};
     return NTs[bf16_tile_of(a)];
 }
 
 int conv_bf16_tile_couts(const ConvArgs& a) {
+    if (a.gemm) return 64 * a.gemm_tm;
     static const int MTs[7] = {128, 128, 32, 64, 128, 128, 128};
     return MTs[bf16_tile_of(a)];
-}
-// Role-split 3x3 kernel (conv_spec_kernel.h): 128 x 256 tiles of stride-1 convs whose input lives in a padded engine
-// arena (16-byte halo loads) with whole 16-channel chunks.  LOCO_CONV_SPEC=0 is the A/B switch back to the lock-step kernel.
-static int conv_spec_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LOCO_CONV_SPEC"); v = e ? (atoi(e) != 0) : 0; }
-    return v;
-}
-int conv_spec_dma_by_compute() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LOCO_SPEC_DMA"); v = e ? (atoi(e) != 0) : 1; }
-    return v;
-}
-bool conv_lowp_uses_spec(const ConvArgs& a, int taps) {
-    return conv_spec_enabled() && taps == 9 && bf16_tile_of(a) == 5 && a.stride == 1 && !a.upsample && !a.zins &&
-           (a.Cin % BKC) == 0 && a.in_padded && a.pad == 1;
 }
 bool conv_lowp_can_kcat(const ConvArgs& a) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("LOCO_KCAT"); on = e ? (atoi(e) != 0) : 1; }
     return on && a.Cin2 > 0 && a.nsplit == 1 && bf16_tile_of(a) == 5 && a.stride == 1 && !a.upsample && !a.zins && a.pad == 1 &&
-           (a.Cin % BKC) == 0 && (a.Cin2 % BKC) == 0 && a.in_padded && (a.mode == CM_GN_SILU || a.mode == CM_TAN_SILU);
+           (a.Cin % BKC) == 0 && (a.Cin2 % BKC) == 0 && a.in_padded &&
+           (a.mode == CM_GN_SILU || a.mode == CM_GN_GELU || a.mode == CM_TAN_SILU);
 }
 // the epilogue statistics exist on the LDS-staged path of whole cout tiles (conv_bf16_kernel.h) and need the finished
 // sums, i.e. no split-K
@@ -152,10 +139,59 @@ int conv_lowp_plan(const ConvArgs& a, int taps, int prec, ConvArgs parts[2]) {
     return 2;
 }
 
+void launch_conv_gemm(const ConvArgs& a, hipStream_t st);      // conv_bf16_inst_j.hip (conv_gemm_kernel.h)
+
+bool conv_gemm_plan(ConvArgs& a) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("LOCO_CONV_GEMM"); on = e ? (atoi(e) != 0) : 1; }
+    a.gemm = 0;
+    const long HW = (long)a.Hout * a.Wout;
+    if (!on || a.stride != 1 || a.upsample || a.zins || (a.Cin % BKC) != 0 || a.Cin < 320 || (HW % 256) != 0 || (a.Wout % 16) != 0 ||
+        a.Cout < 128 || !a.partial || a.Cin2 > 0 || !(a.mode == CM_NONE || a.mode == CM_GN))
+        return false;
+    // Where it pays (tests/diag/gemm_check.py, 5 probes, us per launch old -> new incl. the split pass): the split pass costs 8 bytes
+    // per input element, so the map must have many cout tiles to spread it over (320 -> 2560 @64^2 190 -> 150, 640 -> 5120 @32^2
+    // 180 -> 121, 1280 -> 10240 @16^2 164 -> 104) or be one of the K-heavy, pixel-poor maps the per-pixel kernel runs at 64 - 118
+    // TFLOP/s behind split-K (2560 -> 640 @32^2 144 -> 125, 5120 -> 1280 @16^2 272 -> 82).  It does not pay for the q/k/v maps
+    // (3 C couts: 84 -> 105), the C -> C maps and the wide-input, narrow-output maps at 64^2 (2560 -> 320: 160 -> 218).
+    static int all_shapes = -1;      // LOCO_GEMM_ALL=1: every eligible shape (A/B)
+    if (all_shapes < 0) { const char* e = getenv("LOCO_GEMM_ALL"); all_shapes = e ? atoi(e) : 0; }
+    if (!all_shapes && !(a.Cout >= 640 && (a.Cout >= 4 * a.Cin || a.Cin >= 2560))) return false;
+    // cout tile: 256 where the padding to whole tiles costs < 10 %, else 128
+    const int pad256 = (a.Cout + 255) / 256 * 256;
+    static int force_tm = -1, no_split = -1;      // bring-up knobs: LOCO_GEMM_TM=2|4, LOCO_GEMM_NOSPLIT=1
+    if (force_tm < 0) { const char* e = getenv("LOCO_GEMM_TM"); force_tm = e ? atoi(e) : 0; }
+    if (no_split < 0) { const char* e = getenv("LOCO_GEMM_NOSPLIT"); no_split = e ? atoi(e) : 0; }
+    int tm = force_tm ? force_tm : ((pad256 * 10 <= a.Cout * 11) ? 4 : 2);
+    // a caller that put the norm-cotangent term into this launch's epilogue (ConvArgs::cot_d) did so for ONE unsplit launch of
+    // whole 128-cout tiles: keep exactly that
+    const bool pinned = a.cot_d != nullptr;
+    if (pinned) { if ((a.Cout % 128) != 0) return false; if ((a.Cout % (64 * tm)) != 0) tm = 2; }
+    const int mt = 64 * tm;
+    const long tiles = (HW / 256) * ((a.Cout + mt - 1) / mt) * a.B;
+    const size_t rec_floats = (size_t)a.B * a.Cin * HW;
+    int ns = 1;
+    if (tiles < 192 && pinned) return false;
+    if (tiles < 192 && !no_split) {
+        const int nchunks = a.Cin / BKC;
+        ns = (int)((256 + tiles - 1) / tiles);
+        if (ns > 8) ns = 8;
+        while (ns > 1 && nchunks / ns < 8) --ns;
+        while (ns > 1 && (size_t)ns * a.B * a.Cout * HW + rec_floats > a.partial_floats) --ns;
+    }
+    if ((ns > 1 ? (size_t)ns * a.B * a.Cout * HW : 0) + rec_floats > a.partial_floats) return false;
+    a.gemm = 1; a.gemm_tm = tm; a.nsplit = ns;
+    return true;
+}
+
 template <int PR>
 static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
+    if constexpr (PR == PR_BF16X3) {
+        if (taps == 1 && a.gemm) { launch_conv_gemm(a, st); return; }
+    }
     if (taps == 9 && a.Cin2 > 0) {       // the caller checked conv_lowp_can_kcat
         if (a.mode == CM_GN_SILU) launch_kcat_b<PR, CM_GN_SILU>(a, st);
+        else if (a.mode == CM_GN_GELU) launch_kcat_b<PR, CM_GN_GELU>(a, st);      // forward pass of a GELU network (DeepFloyd IF)
         else launch_kcat_b<PR, CM_TAN_SILU>(a, st);
         return;
     }

@@ -4,4 +4,5 @@
 namespace loco {
 template void launch_kcat_b<PR_BF16X3, CM_GN_SILU>(const ConvArgs&, hipStream_t);
 template void launch_kcat_b<PR_BF16X3, CM_TAN_SILU>(const ConvArgs&, hipStream_t);
+template void launch_kcat_b<PR_BF16X3, CM_GN_GELU>(const ConvArgs&, hipStream_t);
 }  // namespace loco

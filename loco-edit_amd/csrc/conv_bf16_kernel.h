@@ -112,8 +112,7 @@ constexpr int max_halo(int NT, int taps, bool s2) {
     return s2 ? 5 * 65 : 4 * 34;
 }
 
-// Epilogue of the low-precision conv kernels (shared by the lock-step kernel below and the role-split kernel of
-// conv_spec_kernel.h): the WM x WN compute waves (threads 0 .. WM*WN*64-1) write their accumulator tiles.
+// Epilogue of the low-precision conv kernel: the WM x WN waves (threads 0 .. WM*WN*64-1) write their accumulator tiles.
 // D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem_b, const int co0,
@@ -1253,20 +1252,11 @@ void launch_kcat_b(const ConvArgs& a, hipStream_t st) {
 
 int bf16_tile_of(const ConvArgs& a);     // conv_bf16.hip
 
-}  // namespace loco
-#include "conv_spec_kernel.h"
-namespace loco {
-
 template <int PR, int TAPS, int MODE>
 void launch_tile_b(const ConvArgs& a, hipStream_t st) {
     const int tile = bf16_tile_of(a);
     switch (tile) {
         case 5:                                                           // 128 x 256, 8 compute waves (64 x 64 each)
-            if constexpr (TAPS == 9 && MODE != CM_GN_GELU) {
-                // stride-1 convs on padded arena tensors: the role-split kernel (conv_spec_kernel.h; LOCO_CONV_SPEC=0 keeps
-                // every launch on the lock-step kernel below)
-                if (conv_lowp_uses_spec(a, TAPS)) { launch_conv_spec<PR, MODE>(a, st); break; }
-            }
             launch_one_b<PR, TAPS, 2, 4, 2, 2, MODE>(a, st);
             break;
         case 6:                                                           // 128 x 128, 4 waves, compact LDS: two workgroups per CU (LOCO_CONV_2WG=1)

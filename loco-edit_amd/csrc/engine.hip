@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -148,6 +150,7 @@ struct loco_ctx {
     long attn_dmax = 0;            // heads * tokens of the largest attention = the per-sample pitch of attn_delta
     float* partial = nullptr;      // split-K workspace
     size_t partial_floats = 0;
+    const float* bench_out = nullptr; int64_t bench_out_count = 0;      // diag: output tensor of the last loco_bench_conv
     float *tact = nullptr, *tproj = nullptr, *freq = nullptr;
     float *tp_w = nullptr, *tp_b = nullptr;          // concatenated temb_proj
     float *td0w = nullptr, *td0b = nullptr, *td1w = nullptr, *td1b = nullptr;
@@ -920,13 +923,28 @@ static inline uint16_t f2bf(float f) {
 static inline float bf2f(uint16_t h) {
     uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f;
 }
+// Host-side layout building is split over threads (independent output rows): an 860 M-parameter denoiser has six layouts of
+// every operator to build, single-threaded 22 s per engine context (three contexts per T-LOCO object).
+template <typename F>
+static void parallel_for(int n, size_t work, F fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if ((int)nt > n) nt = (unsigned)n;
+    if (nt <= 1 || work < ((size_t)1 << 18)) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&]() { int i; while ((i = next.fetch_add(1)) < n) fn(i); });
+    for (auto& t : th) t.join();
+}
+
 // split-bf16 records: W(o, i, t) for o < nout, i < nin -> [ceil(nin/16)][taps][noutP][32 x u16], 64-byte record
 // per (chunk, tap, o): logical 16-byte pieces {hi k0-7, hi k8-15, lo k0-7, lo k8-15} stored at piece ^ ((o>>2)&3)
 template <typename F>
 static std::vector<float> build_records(int nin, int nout, int taps, F get) {
     int nch = (nin + 15) / 16, noutP = (nout + 31) & ~31;
     std::vector<uint16_t> rec((size_t)nch * taps * noutP * 32, 0);
-    for (int ck = 0; ck < nch; ++ck)
+    parallel_for(nch, (size_t)nin * nout * taps, [&](int ck) {
         for (int t = 0; t < taps; ++t)
             for (int o = 0; o < nout; ++o) {
                 uint16_t* r = rec.data() + (((size_t)ck * taps + t) * noutP + o) * 32;
@@ -941,6 +959,7 @@ static std::vector<float> build_records(int nin, int nout, int taps, F get) {
                     r[ql * 8 + (k & 7)] = l;
                 }
             }
+    });
     std::vector<float> out(rec.size() / 2);
     std::memcpy(out.data(), rec.data(), rec.size() * 2);
     return out;
@@ -952,7 +971,7 @@ template <typename F>
 static std::vector<float> build_records_f16(int nin, int nout, int taps, F get) {
     int nch = (nin + 15) / 16, noutP = (nout + 31) & ~31;
     std::vector<_Float16> rec((size_t)nch * taps * noutP * 16, (_Float16)0.f);
-    for (int ck = 0; ck < nch; ++ck)
+    parallel_for(nch, (size_t)nin * nout * taps, [&](int ck) {
         for (int t = 0; t < taps; ++t)
             for (int o = 0; o < nout; ++o) {
                 _Float16* r = rec.data() + (((size_t)ck * taps + t) * noutP + o) * 16;
@@ -963,6 +982,7 @@ static std::vector<float> build_records_f16(int nin, int nout, int taps, F get) 
                     r[((k >> 3) ^ sw) * 8 + (k & 7)] = (_Float16)v;     // round to nearest even
                 }
             }
+    });
     std::vector<float> out(rec.size() / 2);
     std::memcpy(out.data(), rec.data(), rec.size() * 2);
     return out;
@@ -983,13 +1003,16 @@ int make_conv(loco_ctx* c, const std::vector<const HostParam*>& ws, const std::v
         const HostParam* w = ws[wi];
         int co_n = (int)w->shape[0];
         if (co_n > cout - co0) co_n = cout - co0;
-        for (int co = 0; co < co_n; ++co)
+        parallel_for(co_n, (size_t)co_n * cin * taps, [&](int co) {      // dgrad layout: one row block per cout
             for (int ci = 0; ci < cin; ++ci)
-                for (int t = 0; t < taps; ++t) {
-                    float v = w->data[((size_t)co * cin + ci) * taps + t];
-                    wf[((size_t)ci * taps + t) * coutP + co0 + co] = v;
-                    wd[((size_t)(co0 + co) * taps + (taps - 1 - t)) * cinP + ci] = v;
-                }
+                for (int t = 0; t < taps; ++t)
+                    wd[((size_t)(co0 + co) * taps + (taps - 1 - t)) * cinP + ci] = w->data[((size_t)co * cin + ci) * taps + t];
+        });
+        parallel_for(cin, (size_t)co_n * cin * taps, [&](int ci) {       // forward layout: one row block per cin
+            for (int t = 0; t < taps; ++t)
+                for (int co = 0; co < co_n; ++co)
+                    wf[((size_t)ci * taps + t) * coutP + co0 + co] = w->data[((size_t)co * cin + ci) * taps + t];
+        });
         for (int co = 0; co < co_n; ++co) bias[co0 + co] = bs[wi]->data[co];
         co0 += co_n;
     }
@@ -1284,6 +1307,10 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
     if (a.nsplit < 1) a.nsplit = 1;
     a.partial = c->partial;
+    a.partial_floats = c->partial_floats;
+    a.gemm = 0;
+    // compute-shaped 1x1 operators (the transformer's linear layers): the DMA-fed GEMM with its own split-K choice
+    if (c->prec == 1 && taps == 1) conv_gemm_plan(a);
     {
         const size_t span = (size_t)c->cfg.max_batch * c->per_sample;
         a.in_padded = (a.in >= c->arenaP && a.in < c->arenaP + span) || (a.in >= c->arenaT && a.in < c->arenaT + span);
@@ -1293,7 +1320,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     // with split-K so the tail round is as wide as the chip: 1 + 1/s rounds + a one-sample reduce instead of 2
     // (measured 331.0 vs 334.1 ms per step).
     int tail_probes = 0, tail_split = 1;
-    if (c->prec >= 1 && a.nsplit == 1 && a.B >= 2) {
+    if (c->prec >= 1 && a.nsplit == 1 && a.B >= 2 && !a.gemm) {
         const long per_probe = (long)((a.Hout * a.Wout) / conv_bf16_tile_pixels(a)) * ((a.Cout + 127) / 128);
         const long total = per_probe * a.B, r = total % 256;
         const int nchunks = (a.Cin + 15) / 16;
@@ -2945,6 +2972,13 @@ int loco_convergence_rows(loco_ctx* c, const float* Vprev, const float* V, int32
                           float* out2, void* stream) {
     if (!c) return -2;
     if (k < 1 || k > 64 || n < 1) { c->err = "convergence_rows: need 1 <= k <= 64"; return -2; }
+    // the kernel leaves k * min(64, ceil(n / 256)) * 4 doubles in gscratch, which is sized for rows of the context's own width
+    if (n > c->n_in) { c->err = "convergence_rows: rows longer than the context's input"; return -2; }
+    {
+        const size_t nseg = (size_t)((n + 255) / 256) < 64 ? (size_t)((n + 255) / 256) : 64;
+        const size_t cap = (((size_t)c->n_in + 255) / 256) * 64 * 64 + 4096;       // doubles in gscratch (finalize_params)
+        if ((size_t)k * nseg * 4 > cap) { c->err = "convergence_rows: k rows of this length exceed the reduction workspace"; return -2; }
+    }
     launch_convergence_rows(Vprev, V, k, n, atol, 1e-5f, out2, c->gscratch, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -3118,6 +3152,33 @@ int loco_lincomb(loco_ctx* c, const float* const* src, const float* coef, int32_
 
 // Tuning hook: time one convolution shape on scratch data (random inputs), avg ms over `iters` launches.
 #ifdef LOCO_DIAG     /* include/loco_hip_diag.h: tuning / bring-up hooks, only in the diag build */
+}  // extern "C"
+// well-formed split-bf16 weight records of random values (64 bytes: [hi k0-7|hi k8-15|lo k0-7|lo k8-15], pieces XOR-swizzled by
+// (record index inside its tap block >> 2) & 3), so that diagnostic launches produce comparable numbers, not Inf / NaN
+__global__ void diag_fill_records(unsigned char* rec, long nrec, int wpitch, unsigned seed, float scale) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    const int idx = (int)(r % wpitch);
+    unsigned short hi[16], lo[16];
+    for (int k = 0; k < 16; ++k) {
+        unsigned h = (unsigned)(r * 16 + k) * 2654435761u + seed * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        const float v = scale * ((float)(h & 0xffffff) * (1.0f / 8388608.0f) - 1.0f);
+        const __bf16 hb = (__bf16)v;
+        const __bf16 lb = (__bf16)(v - (float)hb);
+        hi[k] = __builtin_bit_cast(unsigned short, hb);
+        lo[k] = __builtin_bit_cast(unsigned short, lb);
+    }
+    const int sw = (idx >> 2) & 3;
+    unsigned short* base = reinterpret_cast<unsigned short*>(rec + r * 64);
+    for (int k = 0; k < 8; ++k) {
+        base[((0 ^ sw) << 3) + k] = hi[k];
+        base[((1 ^ sw) << 3) + k] = hi[8 + k];
+        base[((2 ^ sw) << 3) + k] = lo[k];
+        base[((3 ^ sw) << 3) + k] = lo[8 + k];
+    }
+}
+extern "C" {
 int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t B, int32_t mode,
                     int32_t taps, int32_t tile, int32_t iters, float* ms_avg, void* stream) {
     if (!c) return -2;
@@ -3139,6 +3200,11 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     if (wfl * 2 > c->partial_floats) { c->err = "bench_conv: weights exceed workspace"; return -2; }
     float* wf = c->partial + c->partial_floats - wfl * 2;
     launch_fill_random(wf, (long)wfl * 2, 6u, 0.05f, st);
+    if (c->prec == 1) {      // split-bf16 records: well-formed ones
+        const long nrec = (long)((cin + 15) / 16) * taps * ((cout + 31) & ~31);
+        hipLaunchKernelGGL(diag_fill_records, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<unsigned char*>(wf), nrec, (cout + 31) & ~31, 7u, 0.05f);
+    }
     ConvArgs a; conv_defaults(a);
     a.in = in; a.in_bs = in_e; a.Cin = cin; a.Hin = H; a.Win = W;
     a.prim = c->arenaP; a.prim_bs = 0; a.sx = c->sxcache;
@@ -3150,6 +3216,8 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     a.tc = c->statsT + 64; a.tc_bs = c->stats_per_sample;
     if (a.cpg < 1) a.cpg = 1;
     a.nsplit = 1; a.partial = c->partial;
+    a.partial_floats = c->partial_floats - wfl * 2;                            // (the synthetic weights sit at the end of the workspace)
+    if (c->prec == 1 && taps == 1) conv_gemm_plan(a);
     if (const char* e = getenv("LOCO_DUAL_WHATIF")) a.no_deep = atoi(e);      // stamp build of the dual tile only (bits 2 / 4)
     int saved = g_bf16_tile_override;
     g_bf16_tile_override = tile;
@@ -3169,6 +3237,7 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     g_bf16_tile_override = saved;
+    c->bench_out = out; c->bench_out_count = (int64_t)out_e * B;
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *ms_avg = ms / iters;
@@ -3229,6 +3298,12 @@ int loco_profile_report(loco_ctx* c, char* buf, int64_t cap) {
 int64_t loco_debug_tensor(loco_ctx* c, const char* name, float* dst, int64_t cap, void* stream) {
     if (!c) return -2;
     std::string nm(name);
+    if (nm == "bench_out") {     // the output tensor of the last loco_bench_conv ([B][Cout][H][W])
+        if (!c->bench_out) { c->err = "no loco_bench_conv yet"; return -3; }
+        int64_t cnt = cap < c->bench_out_count ? cap : c->bench_out_count;
+        HIPCHK(c, hipMemcpyAsync(dst, c->bench_out, (size_t)cnt * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return cnt;
+    }
     if (nm == "workspace") {     // head of the split-K workspace (diagnostic kernels leave their cycle stamps there)
         int64_t cnt = cap < (int64_t)c->partial_floats ? cap : (int64_t)c->partial_floats;
         HIPCHK(c, hipMemcpyAsync(dst, c->partial, (size_t)cnt * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -104,6 +104,10 @@ struct ConvArgs {
     int act;           // ActKind of the prologue modes (exact-fp32 kernel, split-K statistics epilogue)
     float res_scale;   // out = conv + bias + res_scale * res  (DeepFloyd-IF: (x + h) / sqrt 2 with the conv's weights pre-scaled); conv_defaults: 1
     int dual;          // 1: run on the dual-probe tile of conv_dual_kernel.h (B even; set by conv_lowp_plan, never by the engine)
+    // 1x1 operator as a DMA-fed GEMM (conv_gemm_kernel.h; set by conv_gemm_plan): gemm_tm = 2 / 4 (128 / 256 couts per
+    // workgroup); the activations' split records are written to the END of the workspace `partial` (partial_floats floats)
+    int gemm, gemm_tm;
+    size_t partial_floats;
 };
 
 // the conv kernel only; when a.nsplit > 1 the caller follows with launch_conv_splitk_reduce (run_conv does)
@@ -115,11 +119,13 @@ void launch_conv_splitk_reduce(const ConvArgs& a, hipStream_t st);
 // set) and -- for an odd batch -- the last probe on the 128 x 256 tile (parts[1]); returns the number of parts (1: `a` itself).
 bool conv_dual_ok(const ConvArgs& a);
 int conv_lowp_plan(const ConvArgs& a, int taps, int prec, ConvArgs parts[2]);
+// Compute-shaped 1x1 operators on the DMA-fed GEMM kernel: decides eligibility, the cout tile and the split-K factor (overwrites
+// a.nsplit) and sets a.gemm / a.gemm_tm; false: the launch stays on the per-pixel kernel with the split-K factor it had.
+// LOCO_CONV_GEMM=0 switches it off (A/B).
+bool conv_gemm_plan(ConvArgs& a);
 // can a launch with these arguments feed a.st_part from its epilogue?  (whole cout tiles of the chosen variant, no split-K)
 bool conv_lowp_can_fuse_stats(const ConvArgs& a);
 int conv_bf16_tile_couts(const ConvArgs& a);
-// does the low-precision launch with these arguments run on the role-split kernel (conv_spec_kernel.h)?
-bool conv_lowp_uses_spec(const ConvArgs& a, int taps);
 // can the low-precision launch `a` (3x3, its split-K factor already chosen) carry the 1x1 operator a.in2 / a.Cin2 / a.wb2 in the
 // same kernel?  (128 x 256 tiles, stride 1, whole 16-channel chunks of both inputs, no split-K)
 bool conv_lowp_can_kcat(const ConvArgs& a);

@@ -230,7 +230,13 @@ def _preset_t2i(args, family):
             # the stage-I U-Net of the id the shipped scripts name (scripts/main_T2I_DeepFloydIF_null_space_projection*.sh:4,
             # DeepFloyd/IF-I-M-v1.0); `--unet_preset if64_standin` / `if64_xattn_standin` select the round-2 / 3 stand-ins
             parts = args.model_name.split("-")               # "DeepFloyd/IF-I-M-v1.0" -> size "M" (edit.py:1204)
-            args.unet_config = config.if_stage1_config(parts[2] if len(parts) > 2 and parts[2] in config.IF_I_WIDTH else "M")
+            size = parts[2] if len(parts) > 2 and parts[2] in config.IF_I_WIDTH else "M"
+            if size == "XL":
+                # 4.3 B parameters x six layouts per conv operator x one engine context per CFG branch: the three contexts
+                # of the T-LOCO flow do not fit one GPU (config.py); refuse here instead of failing in hipMalloc at load time
+                raise SystemExit("DeepFloyd/IF-I-XL-v1.0: three engine contexts of the 4.3 B-parameter stage-I U-Net exceed one "
+                                 "GPU's memory in this build; use IF-I-M (the shipped scripts' model) or IF-I-L")
+            args.unet_config = config.if_stage1_config(size)
         args.c_in = 3
     args.image_size = args.unet_config.resolution          # 64: SD latents and the IF stage-I models alike
     args.memory_bound = 5

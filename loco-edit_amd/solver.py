@@ -31,7 +31,8 @@ def default_stop_rule() -> str:
     sign LAPACK picks is stable and the loop stops when the vector has converged; with k >= 2 probes the left factor of
     the nearly diagonal k x k problem comes back as a reflection (first row ~ -e_0, others vary), so at least one row of
     ``v`` is the NEGATIVE of its predecessor in every iteration, the test never holds, and the reference runs ``max_iter``
-    iterations (40 of 40 random near-diagonal problems for every k in 2..64).
+    iterations (38 - 40 of 40 random near-diagonal problems for every k in 2..64 on the LAPACK build of this image; the
+    test asserts >= 38 -- on a LAPACK that does not flip, the reference would stop early and this rule would not).
 
     ``reference``: what the reference does -- a single probe stops on the test (rows compared up to sign, which for one
     probe is the reference's own comparison); k >= 2 runs ``max_iter`` iterations, the test is still evaluated where the
@@ -100,6 +101,9 @@ def subspace_iteration(op, algebra, V0: torch.Tensor, min_iter: int = 10, max_it
     sharder = sharder or ProbeSharder(None)
     k = V0.shape[0]
     may_stop = (stop_rule or default_stop_rule()) == "aligned" or k == 1
+    if verbose and not may_stop and max_iter > min_iter + 1:
+        print(f'power method : {k} probes run all {max_iter} iterations under LOCO_STOP_RULE=reference (the reference\'s allclose '
+              f'never holds for k >= 2); LOCO_STOP_RULE=aligned stops on the intended test')
     V = V0
     n_done = 0
     U = None

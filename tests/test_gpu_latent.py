@@ -265,6 +265,11 @@ def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
     from loco_edit_amd.config import SD15_UNET, SD_VAE_DECODER
     from loco_edit_amd.tloco_sd import EditStableDiffusion
     os.environ.pop("WORLD_SIZE", None)
+    import time
+    T0 = [time.perf_counter()]
+
+    def lap(what):      # where the test's wall time goes (printed with -s)
+        t = time.perf_counter(); print(f"  [config4 timing] {what}: {t - T0[0]:.1f} s", flush=True); T0[0] = t
 
     def build(prec):
         args = Namespace(device=torch.device(DEV), dtype=torch.float32, seed=1, unet_config=SD15_UNET, vae_config=SD_VAE_DECODER,
@@ -276,6 +281,7 @@ def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
                          x_space_guidance_num_step=1, result_folder=str(tmp_path))
         return EditStableDiffusion(args)
     ed = build("bf16x3")
+    lap("EditStableDiffusion bf16x3 built")
     assert ed.cfg is SD15_UNET and ed.use_context and tuple(ed.for_prompt_emb.shape) == (1, 77, 768)
     g = torch.Generator().manual_seed(1)
     z = torch.randn(1, 4, 64, 64, generator=g).to(DEV)
@@ -283,10 +289,11 @@ def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
     t = ed.scheduler.timesteps[ed.edit_t_idx]
     F, E, N = ed.for_prompt_emb, ed.edit_prompt_emb, ed.null_prompt_emb
     # ---- the denoiser against the restatement, full width (one evaluation on the host: ~0.8 TFLOP)
-    p = orc.to_torch(synth_params(SD15_UNET, 0))
+    p = {k: torch.from_numpy(v) for k, v in synth_params(SD15_UNET, 0).items()}      # (no copy: 3.4 GB, read-only use)
     with torch.no_grad():
         ref = orc.unet_forward_adm(p, SD15_UNET, z.cpu(), torch.tensor(float(t)), context=F[0])
     del p
+    lap("CPU restatement forward")
     ed._bind_all(F, E, N)
     e = rel(ed.branches["for"].unet_forward(z, float(t)), ref)
     print(f"SD15 U-Net forward at size, bf16x3 vs CPU restatement: rel err {e:.2e}")
@@ -303,6 +310,7 @@ def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
     assert float(JV[:, ~mask.reshape(-1).to(DEV)].abs().max()) == 0.0 and op.dec.mask_count() == int(mask.sum())
     comb = op.jvp((V[0:1] * 0.5 - V[1:2] * 2.0).contiguous())
     assert rel(comb, JV[0:1] * 0.5 - JV[1:2] * 2.0) < 1e-3
+    lap("forward + operator checks")
     # ---- the workload bench.py times as `tloco_sd15`: top-5 basis, 12 power iterations (the reference's minimum);
     # s_i against an independent product ||J v_i|| (the check config 5 carries), orthonormal descending rows
     v0 = torch.randn(4 * 64 * 64, 5, generator=g).to(DEV)
@@ -317,8 +325,10 @@ def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
     assert torch.allclose(nrm.cpu(), s.cpu(), rtol=2e-2)
     del ed, op
     torch.cuda.empty_cache()
+    lap("12-iteration solve")
     # ---- finite difference of the decoded x0_hat along a probe, exact-fp32 engine
     ed = build("f32")
+    lap("EditStableDiffusion f32 built")
     opf = ed._operator(z, t, None, "null+(for-null)")
     v = V[0:1] / V[0:1].norm()
     jv = opf.jvp(v.contiguous())
@@ -329,6 +339,7 @@ def test_config4_on_the_stable_diffusion_v1_architecture_at_size(tmp_path):
         best = min(best, rel(((xp - xm) / (2 * h)).reshape(1, -1), jv))
     print(f"SD15 composed operator, finite difference vs J v (f32 engine): {best:.2e}")
     assert best < 2.5e-2
+    lap("finite differences (f32 engine)")
 
 
 def test_stable_diffusion_2_1_base_denoiser_at_size():

@@ -714,7 +714,7 @@ def test_bench_two_ranks_share_one_gpu():
     env.pop("WORLD_SIZE", None)
     # the driver's own command form: no external launcher, bench.py starts its ranks itself
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-           "--no-cpu-baseline", "--no-extra"]
+           "--no-cpu-baseline", "--no-extra", "--no-e2e"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -723,6 +723,22 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["probes_total"] == 10 and d["config"]["probes_per_gpu"] == 5 and d["value"] > 0
     assert d["roofline"] is not None and d["cpu_baseline"] is None
     assert d["parity"] is not None and d["parity"]["cos_min"] > 0.99     # the k=5 fixture solve, replicated per rank
+
+
+@pytest.mark.gpu
+def test_dual_probe_conv_tile_is_bit_identical_to_the_128x256_tile():
+    """The opt-in dual-probe 3x3 tile (csrc/conv_dual_kernel.h, LOCO_CONV_DUAL=1: two probes' pixel tiles share each weight
+    stage) against the default kernel on a forward batch, J V and U^T J of 3 samples / probes at 256 x 256 (one pair on the
+    dual tile + the odd probe on the 128 x 256 tile): same products in the same order, so the outputs are the same bits.  The
+    switch is read once per process: one child process per setting (tests/diag/dual_check.py)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "dual_check.py"), "3"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "LOCO_CONV_DUAL 0 vs 1: PASS (bit-identical)" in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.gpu
