@@ -49,6 +49,13 @@ sys.path.insert(0, ROOT)
 K_PER_GPU = 5
 N_ITER = 12
 MIN_ITER = 10     # edit.py:2292-2310: the stop test runs from i = 11 on
+# Smoke-test knobs for the two-ranks-on-one-GPU test (two processes on one device take ~4 s per power iteration): fewer
+# iterations, and a probe total that does not divide over the ranks.  A line produced under them says so ("smoke") and carries
+# no parity block (the reference fixture is the 12-iteration solve).
+SMOKE_ITERS = int(os.environ.get("LOCO_BENCH_SMOKE_ITERS", "0"))
+K_TOTAL = int(os.environ.get("LOCO_BENCH_K_TOTAL", "0"))
+if SMOKE_ITERS > 0:
+    N_ITER, MIN_ITER = SMOKE_ITERS, max(0, SMOKE_ITERS - 2)
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (Chip-level parameters)
 PEAK_F32_MFMA_TF = 157.3      # v_mfma_f32_32x32x2_f32 (exact fp32)
 PEAK_BF16_MFMA_TF = 2500.0    # v_mfma_f32_32x32x16_bf16 / _f16; the split-bf16 path issues 3 MFMA flops per algorithmic flop
@@ -291,8 +298,18 @@ def e2e_phases(eng, cfg, sched_cls, solver, device):
     return out
 
 
+_T0 = time.perf_counter()
+
+
+def _mark(label):
+    """LOCO_BENCH_TRACE=1: wall-clock marks on stderr (where a bench process spends its time outside the timed region)."""
+    if os.environ.get("LOCO_BENCH_TRACE"):
+        print(f"[bench trace pid {os.getpid()} rank {os.environ.get('RANK', '-')}] {time.perf_counter() - _T0:7.2f} s  {label}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
+    _mark("start")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and a.gpus > 1:
         launch_ranks(a.gpus)            # never returns
@@ -309,6 +326,7 @@ def main():
     from loco_edit_amd.scheduler import YHCustomScheduler
     from loco_edit_amd import solver
 
+    _mark("imports done")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # LOCO_BENCH_BACKEND=gloo lets several ranks share one GPU (a smoke test of the sharded path on a 1-GPU box);
@@ -338,6 +356,7 @@ def main():
         n_distinct_gpus = len(set(ident))
     else:
         n_distinct_gpus = 1
+    _mark("process group / device ready")
     sched = YHCustomScheduler()
     sched.set_timesteps(100)
     t = float(sched.timesteps[40])
@@ -470,6 +489,8 @@ def main():
             return make_tloco_sd(prec, real=True)
         if name == "celeba_top5":
             cfg, k, keep = CELEBA_DDPM, K_PER_GPU * world, K_PER_GPU * world
+            if K_TOTAL > 0:
+                k = keep = K_TOTAL
         else:
             cfg, k, keep = FFHQ_P2, 64, 20
         params = synth_params(cfg, seed=0)
@@ -496,6 +517,7 @@ def main():
         return dict(cfg=cfg, k=k, keep=keep, eng=eng, params=params, step=step, x=x, mask=mask, v0=v0, streams=n_streams)
 
     w = make_workload(a.workload, a.precision)
+    _mark("workload built")
     eng, cfg, k, keep = w["eng"], w["cfg"], w["k"], w["keep"]
     for _ in range(a.warmup):            # warm-up outside the clock stamps (timed() below then runs 0 more)
         w["step"]()
@@ -504,6 +526,7 @@ def main():
     ck1 = eng.clock_stamp()
     torch.cuda.synchronize()
     sclk = LocoEngine.sclk_mhz(ck0, ck1)
+    _mark("warm-up + timed steps done")
     ms_per_step = elapsed / a.steps * 1e3
     value = keep / (elapsed / a.steps)
     k_local = sharder.rows(k)[1] - sharder.rows(k)[0]
@@ -573,9 +596,10 @@ def main():
                                  for n, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])},
         }
 
+    _mark("profile step done")
     # ---- parity leg (outside the timed region): the metric's second half, vT cosine vs the reference
     parity = None
-    if a.workload == "celeba_top5":
+    if a.workload == "celeba_top5" and not SMOKE_ITERS and not K_TOTAL:
         if world == 1:
             ps, pvT = s, vT
         else:   # the k = 5 solve of the fixture, replicated on every rank (no collective), reported by rank 0
@@ -585,6 +609,7 @@ def main():
         if rank == 0:
             parity = parity_vs_fixture(ps, pvT, "celeba256")
 
+    _mark("parity leg done")
     extra = {}
     e2e = None
     if rank == 0 and world == 1 and a.workload == "celeba_top5" and not a.no_e2e:
@@ -745,6 +770,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": DTYPE_NOTE[a.precision], "data": "synthetic",
+            "smoke": ({"iters": SMOKE_ITERS, "k_total": K_TOTAL} if (SMOKE_ITERS or K_TOTAL) else None),
             "config": {"workload": wl, "probes_total": k, "probes_per_gpu": k_local, "kept": keep, "n_iter": int(n_iter),
                        "mask_L": int(w["mask"].sum().item()), "weights": "synthetic seed 0",
                        **({"streams": w["streams"]} if "streams" in w else {}),
