@@ -368,6 +368,12 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
         if (!n[0]) snprintf(n, 40, "conv_gemm_bf16x3<%d>", a.gemm_tm);
         return n;
     }
+    if (prec == 1 && taps == 9 && a.pers_groups > 0 && !a.dual) {
+        static char pn[6][40];
+        const int mm = (a.mode < 0 || a.mode > 5) ? 2 : a.mode;
+        if (!pn[mm][0]) snprintf(pn[mm], 40, "conv_pers_bf16x3<9,2,4,2,2,%d>", mm);
+        return pn[mm];
+    }
     if (prec == 1 && taps == 9 && a.dual) {
         static char dn[5][40];
         const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;

@@ -136,10 +136,40 @@ int conv_lowp_plan(const ConvArgs& a, int taps, int prec, ConvArgs parts[2]) {
     if (!(a.B & 1)) return 1;
     parts[1] = conv_shift_batch(a, a.B - 1);
     parts[1].dual = 0;
+    parts[1].pers_groups = 0;
     return 2;
 }
 
 void launch_conv_gemm(const ConvArgs& a, hipStream_t st);      // conv_bf16_inst_j.hip (conv_gemm_kernel.h)
+
+bool conv_pers_plan(ConvArgs& a) {
+    // Opt-in (LOCO_CONV_PERS=1: raw / forward forms, 2: every form): measured neutral to slightly negative in the flow (r05:
+    // headline 299.4 vs 300.2 ms, 25-frame decode step 44.1 -> 45.0 ms) although the isolated raw / forward launches gain 5 %
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("LOCO_CONV_PERS"); on = e ? (atoi(e) != 0) : 0; }
+    a.pers_groups = 0;
+    if (!on || a.taps != 9 || a.Cin2 > 0 || a.nsplit != 1 || a.stride != 1 || a.upsample || a.zins || a.pad != 1 || !a.in_padded ||
+        (a.Cin % (2 * BKC)) != 0 || (a.Cout % 128) != 0 || a.B < 2 || a.cot_d || bf16_tile_of(a) != 5)
+        return false;
+    // The raw-input and forward forms only (r05, 128 -> 128 @256^2, 5 probes: 246 -> 232 us raw, 261 -> 248 us GroupNorm + SiLU).  The
+    // tangent / cotangent forms LOSE under a walk over probes (274 -> 276, 128 -> 256: 523 -> 552 us): with one workgroup per
+    // (tile, probe) the five probes of a pixel tile run at the same time on one XCD and share one fetch of the tile's primal
+    // {S, xhat} cache (8 of their 12 bytes per element); walked one after the other by one CU, the cache is fetched five times.
+    // LOCO_CONV_PERS=2 walks them too (A/B).
+    static int all_modes = -1;
+    if (all_modes < 0) { const char* e = getenv("LOCO_CONV_PERS"); all_modes = (e && atoi(e) == 2) ? 1 : 0; }
+    if (!(a.mode == CM_NONE || a.mode == CM_GN_SILU || a.mode == CM_GN_GELU ||
+          (all_modes && (a.mode == CM_TAN_SILU || a.mode == CM_COT_SILU)))) return false;
+    // G workgroups share a tile, each walks ceil(B / G) probes: as many groups as keep the grid within one round of the chip
+    const long wg0 = (long)((a.Hout * a.Wout) / 256) * (a.Cout / 128);
+    int G = wg0 >= 256 ? 1 : (int)(256 / wg0);
+    if (G > a.B) G = a.B;
+    const int per = (a.B + G - 1) / G;
+    // worth it when a workgroup gets at least two probes, the walks are balanced and the grid fills most of the chip
+    if (per < 2 || a.B * 10 < G * per * 8 || wg0 * G < 192) return false;
+    a.pers_groups = G;
+    return true;
+}
 
 bool conv_gemm_plan(ConvArgs& a) {
     static int on = -1;

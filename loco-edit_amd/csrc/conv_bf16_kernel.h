@@ -305,9 +305,106 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
     }
 }
 
+// The same write-out (whole cout tiles, no split-K) in rounds of WM x RPW cout rows through a staging area S that the operand
+// buffers do not overlap: the persistent kernel (PHASE 3 of conv_lowp_body) keeps the next probe's first operands in LDS while
+// the finished tile leaves.  RPW = 16: 2 x 16 x 256 x 4 B = 32 KB per round.
+template <int WM, int WN, int TM, int TN, int RPW>
+__device__ __forceinline__ void conv_lowp_epilogue_rounds(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* const S, const int co0,
+                                                          const int oy0, const int ox0, const int TW, const int tile_id, const int b) {
+    constexpr int NTHR = WM * WN * 64, NT = WN * TN * 32, NQ = NT / 4;
+    constexpr int SROWS = WM * RPW, NTASK = (SROWS * NQ) / NTHR, NRB = RPW / 8;
+    static_assert((RPW == 8 || RPW == 16 || RPW == 32) && (SROWS * NQ) % NTHR == 0 && NQ == 64, "round geometry");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned out_plane = (unsigned)(a.Hout * a.Wout);
+    float* const ob = a.out + (long)b * a.out_bs;
+    const float* const rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+    const float* const b2 = a.bias2 ? a.bias2 + (long)b * a.bias2_bs : nullptr;
+    const bool accu = a.accumulate != 0;
+    const int twsh = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
+    const int ntile = (a.Hout * a.Wout) / NT;
+    float* const sp = (a.st_kind == ST_FWD) ? a.st_part + (long)b * a.Cout * ntile * 2 : nullptr;
+#pragma unroll
+    for (int h = 0; h < TM; ++h) {
+#pragma unroll
+        for (int g0 = 0; g0 < 4; g0 += NRB) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < NRB; ++g)
+#pragma unroll
+                    for (int r3 = 0; r3 < 4; ++r3)
+                        S[(wm * RPW + g * 8 + 4 * khalf + r3) * NT + (wn * TN + j) * 32 + l31] = acc[h][j][(g0 + g) * 4 + r3];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            f32x4 v[NTASK];
+            unsigned off[NTASK];
+            int cos_[NTASK];
+#pragma unroll
+            for (int q = 0; q < NTASK; ++q) {
+                const int t = q * NTHR + tid;
+                const int srow = t / NQ, quad = t & (NQ - 1);
+                v[q] = *reinterpret_cast<const f32x4*>(&S[srow * NT + quad * 4]);
+                const int co = co0 + ((srow / RPW) * TM + h) * 32 + g0 * 8 + (srow % RPW);
+                const int p = quad * 4;
+                cos_[q] = co;
+                off[q] = (unsigned)co * out_plane + (unsigned)((oy0 + (p >> twsh)) * a.Wout + ox0 + (p & (TW - 1)));
+            }
+            if (rb || accu) {
+                f32x4 rv[NTASK];
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+                    if (rb) t4 = a.res_scale * *reinterpret_cast<const f32x4*>(rb + off[q]);
+                    if (accu) t4 += *reinterpret_cast<const f32x4*>(ob + off[q]);
+                    rv[q] = t4;
+                }
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) v[q] += rv[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NTASK; ++q) {
+                float add = 0.f;
+                if (a.bias) add += a.bias[cos_[q]];
+                if (b2) add += b2[cos_[q]];
+                v[q] += add;
+                __builtin_nontemporal_store(v[q], reinterpret_cast<f32x4*>(ob + off[q]));
+            }
+            if (sp) {      // forward GroupNorm statistics of the finished tile: see conv_lowp_epilogue
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    const float pivot = __shfl(v[q][0], 0, 64);
+                    const float d0 = v[q][0] - pivot, d1 = v[q][1] - pivot, d2 = v[q][2] - pivot, d3 = v[q][3] - pivot;
+                    float s1 = (d0 + d1) + (d2 + d3);
+                    float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) {
+                        s1 += __shfl_xor(s1, m, 64);
+                        s2 += __shfl_xor(s2, m, 64);
+                    }
+                    const float m = s1 * (1.0f / NT);
+                    if (lane == 0)
+                        *reinterpret_cast<f32x2*>(sp + ((long)cos_[q] * ntile + tile_id) * 2) = f32x2{pivot + m, s2 - s1 * m};
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the round's read-back is done in every wave
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
 // PHASE 0: the whole kernel.  K-concatenated pair (ResBlock conv2 + its 1x1 shortcut on the block input, one accumulator
 // tile, one write-out): PHASE 1 = the first operator's stage loop only (accumulators zeroed, no epilogue), PHASE 2 = the
 // second operator's stage loop on top of the same accumulators, then the epilogue.
+// PHASE 3 (round 5): PERSISTENT over the probes of one (pixel tile, cout tile).  The workgroup walks probes b, b + G, b + 2G, ...
+// (G = a.pers_groups workgroups share a tile) as ONE continuous stream of chunks: the halo parts and weight stages of the next
+// probe's first chunk are loaded / converted under the current probe's last chunk exactly like the next chunk of the same probe
+// (only the wave-uniform base pointers change between probes of one tile: index setup once per workgroup, the shared primal-cache
+// patch stays in this CU's caches), and the finished tile leaves through a staging area of its own (32 KB rounds behind the
+// operand buffers) so the prefetched operands survive the write-out.  r05 stamps of the 128 -> 128 tangent conv: index setup
+// 2.4 k + prologue 9.0 k of a tile's 94.9 k cycles, every tile.  Needs an even number of chunks (buffer parities restart per probe),
+// whole cout tiles and no split-K.
 template <int PR, int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG, int PHASE = 0>
 __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[TM][TN]) {
     constexpr int NTHR = WM * WN * 64;
@@ -320,6 +417,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     constexpr int NTS = KS;                          // taps per weight stage (one kernel row)
     constexpr int NROW = (TAPS == 9) ? 3 : 1;        // weight stages per channel chunk
     constexpr bool NEEDP = (MODE == CM_TAN_SILU || MODE == CM_COT_SILU);
+    constexpr bool PERS = (PHASE == 3);
     // GEN: general per-pixel staging (stride 2, upsample, zero insertion, partial channel chunks, caller-owned
     // tensors); !GEN: 16-byte loads of 4 consecutive pixels from padded arena tensors (stride-1 convs)
     // STG 3: vector staging in the compact LDS layout of the 128 x 128 tile that fits TWO workgroups per CU (<= 81 920 B: two
@@ -372,7 +470,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     // served from that XCD's L2 instead of HBM once per probe (blocks L and L+8 share an XCD).
     int tile_id, cot_id, zid;
     {
-        const int ntile = (a.Hout * a.Wout) / NT, ncot = (a.Cout + MT - 1) / MT, Z = a.B * a.nsplit;
+        const int ntile = (a.Hout * a.Wout) / NT, ncot = (a.Cout + MT - 1) / MT, Z = PERS ? a.pers_groups : a.B * a.nsplit;
         const int NTC = ntile * ncot, L = blockIdx.x;
         int T = 0;
         if ((ntile & 7) == 0) {
@@ -396,8 +494,12 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     const int oy0 = __builtin_amdgcn_readfirstlane((tile_id / tiles_x) * TH);
     const int ox0 = __builtin_amdgcn_readfirstlane((tile_id % tiles_x) * TW);
     const int co0 = cot_id * MT;
-    const int b = __builtin_amdgcn_readfirstlane(zid / a.nsplit);
-    const int split = __builtin_amdgcn_readfirstlane(zid % a.nsplit);
+    // PERS: zid = the workgroup's group = its first probe; it walks np probes, pstep apart
+    const int b = PERS ? zid : __builtin_amdgcn_readfirstlane(zid / a.nsplit);
+    const int split = PERS ? 0 : __builtin_amdgcn_readfirstlane(zid % a.nsplit);
+    const int pstep = PERS ? a.pers_groups : 1;
+    const int np = PERS ? (a.B - b + pstep - 1) / pstep : 1;
+    int pq = 0;                                       // probe of the walk the stage loop is multiplying (PERS)
 
     if constexpr (XPF && PHASE != 2 && EARLY_W) {
         // The first two weight stages leave BEFORE the per-thread index setup below (a dozen run-time integer divisions,
@@ -592,6 +694,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     // 128-channel conv's halo bytes through the CU's vector-memory path).  `pf_live == false` (wave-uniform) collapses such
     // a load onto one address: every lane reads the same 16 bytes, one cache line per instruction.
     bool pf_live = true, dma_live = true;
+    int pf_dq = 0;                 // PERS: 1 while a halo part of the NEXT probe of the walk is being loaded
 #ifdef LOCO_DUAL_STAMP
     const bool wi_halo = (a.no_deep & 2) != 0, wi_dma = (a.no_deep & 4) != 0, wi_novalu = (a.no_deep & 8) != 0;
 #endif
@@ -599,7 +702,8 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         // wave-uniform chunk base (SGPR pair) + 32-bit per-lane byte offset: global_load saddr form, no 64-bit VALU
         // (32-bit scalar offset arithmetic: one sample's tensor is far below 4 GB)
         const unsigned cb = (unsigned)chunk * ((unsigned)(BKC * 4) * (unsigned)in_plane);
-        const char* pk = reinterpret_cast<const char*>(inb - 16) + cb;
+        const long pofs = PERS ? (long)(pq + pf_dq) * pstep : 0;      // probes past the workgroup's first one (wave-uniform)
+        const char* pk = reinterpret_cast<const char*>(inb + pofs * a.in_bs - 16) + cb;
         const char* sk = reinterpret_cast<const char*>(reinterpret_cast<const float*>(sxb) - 32) + 2u * cb;
         const unsigned pl = (unsigned)in_plane * 4u;
 #pragma unroll
@@ -619,13 +723,16 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         const int c0 = chunk * BKC + v_q4 * 4 + part * KP;    // first channel of this part
         if constexpr (MODE != CM_NONE) {
             if constexpr (NEEDP) {      // {m1,m2} (tangent) or {rstd*m1, rstd*m2} (cotangent) per channel
-                R.cq[0] = *reinterpret_cast<const f32x4_u*>(tcb + 2 * c0);
-                if constexpr (KP == 4) R.cq[1] = *reinterpret_cast<const f32x4_u*>(tcb + 2 * c0 + 4);
+                const float* tq = tcb + pofs * a.tc_bs;
+                R.cq[0] = *reinterpret_cast<const f32x4_u*>(tq + 2 * c0);
+                if constexpr (KP == 4) R.cq[1] = *reinterpret_cast<const f32x4_u*>(tq + 2 * c0 + 4);
             } else if constexpr (KP == 4) {
-                R.cq[0] = *reinterpret_cast<const f32x4_u*>(scb + c0);
-                R.cq[1] = *reinterpret_cast<const f32x4_u*>(shb + c0);
+                R.cq[0] = *reinterpret_cast<const f32x4_u*>(scb + pofs * a.scsh_bs + c0);
+                R.cq[1] = *reinterpret_cast<const f32x4_u*>(shb + pofs * a.scsh_bs + c0);
             } else {
-                const f32x2 sa = *reinterpret_cast<const f32x2_u*>(scb + c0), sb = *reinterpret_cast<const f32x2_u*>(shb + c0);
+                const float* sq_ = scb + pofs * a.scsh_bs;
+                const float* hq_ = shb + pofs * a.scsh_bs;
+                const f32x2 sa = *reinterpret_cast<const f32x2_u*>(sq_ + c0), sb = *reinterpret_cast<const f32x2_u*>(hq_ + c0);
                 R.cq[0] = f32x4{sa[0], sa[1], sb[0], sb[1]};
             }
         }
@@ -868,6 +975,13 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     const int nch = cend - cbeg;
     const int clast = cend - 1;
     auto cclamp = [&](int c) { return __builtin_amdgcn_readfirstlane(c < clast ? c : clast); };   // keep it scalar
+    // chunk x of the current probe's range, possibly past its end: resolves to the chunk to load and sets pf_live / pf_dq
+    auto vres = [&](int x) -> int {
+        if (x <= clast) { pf_live = true; pf_dq = 0; return __builtin_amdgcn_readfirstlane(x); }
+        if (PERS && pq + 1 < np) { pf_live = true; pf_dq = 1; return __builtin_amdgcn_readfirstlane(x - nch); }      // (PERS: cbeg = 0)
+        pf_live = !LIVE_MASK; pf_dq = 0;
+        return clast;
+    };
     auto stage_end = [&]() {
         // all LDS writes of this wave retired, LDS-DMA landed; then a bare s_barrier (no vmcnt drain of newer loads)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -938,10 +1052,14 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                 const int lde = (NPART == 1 && row == 2) ? 0 : -1;                         // part loaded at the stage end
                 constexpr int NLD = KP + (NEEDP ? 2 * KP + 1 : (MODE != CM_NONE ? 2 : 0));
                 {
-                    int c2, r2;
-                    stage_of(ci, row + 2, c2, r2);
-                    dma_live = LIVE_MASK ? (chunk + (row + 2) / NROW <= clast) : true;
-                    dma_w(c2, r2, Wnx2);               // weights of the stage after next
+                    // weights of the stage after next; past the probe's last chunk: the first stages of the walk's next probe
+                    // (PERS: the same cout tile, chunk 0 again) or, at the very end, a collapsed dead load
+                    const int x = chunk + (row + 2) / NROW;
+                    int c2;
+                    if (x <= clast) { c2 = x; dma_live = true; }
+                    else if (PERS && pq + 1 < np) { c2 = x - nch; dma_live = true; }
+                    else { c2 = clast; dma_live = !LIVE_MASK; }
+                    dma_w(__builtin_amdgcn_readfirstlane(c2), (row + 2) % NROW, Wnx2);
                     dma_live = true;
                 }
                 Frag& fa = fr[(P + row) & 1];          // taps 0 and 2 of this stage
@@ -954,7 +1072,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                 __builtin_amdgcn_sched_barrier(0);
                 load_frag(fb, row, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (ld0 >= 0) { pf_live = LIVE_MASK ? (chunk + 2 <= clast) : true; prefetch_h(cclamp(chunk + 2), ld0); pf_live = true; }
+                if (ld0 >= 0) { const int cx = vres(chunk + 2); prefetch_h(cx, ld0); pf_live = true; pf_dq = 0; }
                 mma_frag_tail(fa);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_frag_head(fb);
@@ -974,7 +1092,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                 // conversion and re-load never share a scheduling region: the loads then land directly in the registers
                 // the conversion has finished reading (no copies behind a vmcnt wait)
                 if (cv2 >= 0) { Hs = Hnxt; stage_h(cclamp(chunk + 1), cv2); }
-                if (ld2 >= 0) { pf_live = LIVE_MASK ? (chunk + 1 <= clast) : true; prefetch_h(cclamp(chunk + 1), ld2); pf_live = true; }
+                if (ld2 >= 0) { const int cx = vres(chunk + 1); prefetch_h(cx, ld2); pf_live = true; pf_dq = 0; }
                 mma_frag_tail(fa);
                 __builtin_amdgcn_sched_barrier(0);
                 // the LDS-DMA of this stage (older than the part loads issued in it) must have landed before the barrier
@@ -982,14 +1100,35 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lde >= 0) { pf_live = LIVE_MASK ? (chunk + 2 <= clast) : true; prefetch_h(cclamp(chunk + 2), lde); pf_live = true; }
+                    if (lde >= 0) { const int cx = vres(chunk + 2); prefetch_h(cx, lde); pf_live = true; pf_dq = 0; }
                 }
                 stage_end();
             }
         };
+        if constexpr (PERS) {
+            // one continuous stream of chunks over the probes of the walk (nch is even: the buffer parities restart with each
+            // probe); a finished tile leaves through its own staging area while the next probe's operands wait in the buffers
+            float* const Sst = reinterpret_cast<float*>(Hsb + 2 * HBYTES);
+            for (pq = 0; pq < np; ++pq) {
+                for (int ci = 0; ci < nch; ci += 2) {
+                    chunk_body(std::integral_constant<int, 0>{}, ci);
+                    chunk_body(std::integral_constant<int, 1>{}, ci + 1);
+                }
+                conv_lowp_epilogue_rounds<WM, WN, TM, TN, 16>(a, acc, Sst, co0, oy0, ox0, TW, tile_id, b + pq * pstep);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the walk's last (dead) loads
+            return;
+        } else {
         for (int ci = 0; ci < nch; ci += 2) {
             chunk_body(std::integral_constant<int, 0>{}, ci);
             if (ci + 1 < nch) chunk_body(std::integral_constant<int, 1>{}, ci + 1);
+        }
         }
     } else {
     bool deep_done = false;
@@ -1176,6 +1315,13 @@ __global__ __launch_bounds__(WM * WN * 64, STG == 3 ? 2 : 1) void conv_mfma_f16(
     conv_lowp_body<PR_F16, TAPS, WM, WN, TM, TN, MODE, STG>(a, acc);
 }
 
+// persistent over the probes of a tile (PHASE 3 of conv_lowp_body)
+template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
+__global__ __launch_bounds__(WM * WN * 64, 1) void conv_pers_bf16x3(ConvArgs a) {
+    f32x16 acc[TM][TN];
+    conv_lowp_body<PR_BF16X3, TAPS, WM, WN, TM, TN, MODE, STG, 3>(a, acc);
+}
+
 // K-concatenated ResBlock tail: out = conv3x3(map(in)) + conv1x1(in2) + biases (+ residual): the 3x3 operator of `a` (vector
 // staging, MODE) and, on the same accumulator tile, the 1x1 operator {in2, Cin2, wb2} on the RAW block input (per-pixel
 // staging with the register ring) -- reference models/ddpm/diffusion.py:887-912 (`x = nin_shortcut(x); return x + h`): one
@@ -1206,6 +1352,19 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     const size_t stage_bytes = (size_t)WM * 32 * NT * 4;      // epilogue staging tile S[WM*32 couts][NT pixels]
     if (lds < stage_bytes) lds = stage_bytes;
     dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
+    if constexpr (PR == PR_BF16X3 && TAPS == 9 && STG == 0 && WM == 2 && WN == 4 && TM == 2 && TN == 2) {
+        if (a.pers_groups > 0) {      // conv_pers_plan: one workgroup walks the probes b, b + G, ... of its tile
+            auto pk = &conv_pers_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;
+            static DeviceOnce ponce;
+            if (first_on_device(ponce))
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const size_t plds = (size_t)nwb * KS * MT * rec_bytes<PR>() + 2 * ((size_t)halo_w * halo_h + NDUMMY) * halo_pitch<PR>() +
+                                (size_t)WM * 16 * NT * 4;      // operand buffers + the write-out's own 32 KB staging area
+            dim3 pgrid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.pers_groups);
+            hipLaunchKernelGGL(pk, pgrid, dim3(WM * WN * 64), plds, st, a);
+            return;
+        }
+    }
     auto kern = PR == PR_F16 ? &conv_mfma_f16<TAPS, WM, WN, TM, TN, MODE, STG>
                              : &conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;
     if (lds > 64 * 1024) {

@@ -1315,12 +1315,15 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
         const size_t span = (size_t)c->cfg.max_batch * c->per_sample;
         a.in_padded = (a.in >= c->arenaP && a.in < c->arenaP + span) || (a.in >= c->arenaT && a.in < c->arenaT + span);
     }
+    // 3x3 launches with several probes per (pixel tile, cout tile) workgroup slot: one workgroup walks them (conv_pers_plan)
+    a.pers_groups = 0;
+    if (c->prec == 1 && taps == 9) conv_pers_plan(a);
     // Tail-probe split (bf16x3): when the workgroups of the launch fill whole rounds of the 256 CUs plus a short
     // tail made of the last probes (5 probes x 64 tiles = 320 = 256 + 64), those probes are launched separately
     // with split-K so the tail round is as wide as the chip: 1 + 1/s rounds + a one-sample reduce instead of 2
     // (measured 331.0 vs 334.1 ms per step).
     int tail_probes = 0, tail_split = 1;
-    if (c->prec >= 1 && a.nsplit == 1 && a.B >= 2 && !a.gemm) {
+    if (c->prec >= 1 && a.nsplit == 1 && a.B >= 2 && !a.gemm && !a.pers_groups) {
         const long per_probe = (long)((a.Hout * a.Wout) / conv_bf16_tile_pixels(a)) * ((a.Cout + 127) / 128);
         const long total = per_probe * a.B, r = total % 256;
         const int nchunks = (a.Cin + 15) / 16;
@@ -3218,6 +3221,7 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     a.nsplit = 1; a.partial = c->partial;
     a.partial_floats = c->partial_floats - wfl * 2;                            // (the synthetic weights sit at the end of the workspace)
     if (c->prec == 1 && taps == 1) conv_gemm_plan(a);
+    if (c->prec == 1 && taps == 9) conv_pers_plan(a);
     if (const char* e = getenv("LOCO_DUAL_WHATIF")) a.no_deep = atoi(e);      // stamp build of the dual tile only (bits 2 / 4)
     int saved = g_bf16_tile_override;
     g_bf16_tile_override = tile;

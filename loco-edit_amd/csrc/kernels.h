@@ -108,6 +108,9 @@ struct ConvArgs {
     // workgroup); the activations' split records are written to the END of the workspace `partial` (partial_floats floats)
     int gemm, gemm_tm;
     size_t partial_floats;
+    // 3x3 kernel persistent over the probes of a tile (conv_bf16_kernel.h PHASE 3; set by conv_pers_plan): number of workgroups
+    // that share one (pixel tile, cout tile), each walking the probes b, b + pers_groups, ...; 0: one workgroup per (tile, probe)
+    int pers_groups;
 };
 
 // the conv kernel only; when a.nsplit > 1 the caller follows with launch_conv_splitk_reduce (run_conv does)
@@ -123,6 +126,9 @@ int conv_lowp_plan(const ConvArgs& a, int taps, int prec, ConvArgs parts[2]);
 // a.nsplit) and sets a.gemm / a.gemm_tm; false: the launch stays on the per-pixel kernel with the split-K factor it had.
 // LOCO_CONV_GEMM=0 switches it off (A/B).
 bool conv_gemm_plan(ConvArgs& a);
+// 3x3 launches whose (pixel tile, cout tile) grid is at least as wide as the chip, or divides it: persistent over the probes
+// (sets a.pers_groups; opt-in: LOCO_CONV_PERS=1 | 2, see conv_bf16.hip)
+bool conv_pers_plan(ConvArgs& a);
 // can a launch with these arguments feed a.st_part from its epilogue?  (whole cout tiles of the chosen variant, no split-K)
 bool conv_lowp_can_fuse_stats(const ConvArgs& a);
 int conv_bf16_tile_couts(const ConvArgs& a);

@@ -49,5 +49,8 @@ for k in res["0"]:
     rel = d / a.abs().max().item()
     nan = bool(torch.isnan(b).any())
     print(f"{k}: max|diff| {d:.3e} (rel {rel:.3e}) nan={nan} |ref|max {a.abs().max().item():.3e}")
+    if d != 0.0:
+        ne = (a != b).reshape(a.shape[0], -1)
+        print(f"   differing elements per sample / probe row: {ne.sum(dim=1).tolist()} of {ne.shape[1]}")
     ok = ok and d == 0.0 and not nan
 print(ENVN, "0 vs 1:", "PASS (bit-identical)" if ok else "FAIL")
