@@ -5,6 +5,7 @@
 // [channel][token] conv layout and transposes are never materialised.
 // 64x64 tile, 4 waves (one 32x32 block each), BK = 64 (measured 1.1 ms/step faster than 32), next tile prefetched into registers.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace loco {
 
@@ -83,6 +84,99 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             if (g.beta != 0.f) v += g.beta * (*c);
             if (g.bias) v += g.bias[m];
                 if (g.colbias) v += g.colbias[n];
+            if (g.R) v += g.R[(long)bz * g.srb + (long)hz * g.sch + off];
+            *c = v;
+        }
+    }
+}
+
+// Small products (the 256-token attention of the DDPM denoiser: M = N = 256, K = 512 / 1024, 5 probes): the 64 x 64 tiling gives
+// 80 workgroups of one wave per SIMD, each a serial chain of K / 2 f32 MFMAs at 64 cycles -- 18 - 39 us per launch with two
+// thirds of the chip idle (4 % of the headline step).  Here a workgroup owns a 32 x 32 tile and its four waves split every
+// K-step between them (wave w: k-pairs 8 w ... 8 w + 7 of the 32 of a step), the four partial tiles are summed through LDS in
+// wave order: 4 x the workgroups, a quarter of the chain.  Summation order differs from the kernel above (four interleaved
+// partial chains), the arithmetic is the same exact-fp32 MFMA.
+constexpr int SBM = 32, SBN = 32, SBK = 64;       // (K-steps of 128 measured worse: -0.45 % vs -0.85 % per headline step)
+template <int NSEG>
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g) {
+    __shared__ float As[SBK][SBM + 1];
+    __shared__ float Bs[SBK][SBN + 1];
+    __shared__ float Red[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int m0 = blockIdx.y * SBM, n0 = blockIdx.x * SBN;
+    const int nb2 = g.batch2 > 0 ? g.batch2 : 1;
+    const int bz = blockIdx.z / nb2, hz = blockIdx.z % nb2;
+    const float* A = g.A + (long)bz * g.sab + (long)hz * g.sah;
+    const float* B = g.Bm + (long)bz * g.sbb + (long)hz * g.sbh;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int NE = SBM * SBK / 256;     // 16 elements of A and of B per thread and tile
+    int am[NE], ak[NE], bn[NE], bk[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        int e = tid + i * 256;
+        if (g.sak == 1) { am[i] = e / SBK; ak[i] = e % SBK; } else { ak[i] = e / SBM; am[i] = e % SBM; }
+        if (g.sbn == 1) { bk[i] = e / SBN; bn[i] = e % SBN; } else { bn[i] = e / SBK; bk[i] = e % SBK; }
+    }
+    float ra[NE], rb[NE];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            bool va = (m0 + am[i] < g.M) && (k0 + ak[i] < g.K);
+            bool vb = (n0 + bn[i] < g.N) && (k0 + bk[i] < g.K);
+            long oa = va ? (long)(m0 + am[i]) * g.sam + (long)(k0 + ak[i]) * g.sak : 0;
+            long ob = vb ? (long)(k0 + bk[i]) * g.sbk + (long)(n0 + bn[i]) * g.sbn : 0;
+            float xa = A[oa], xb = B[ob];
+            ra[i] = va ? xa : 0.f;
+            rb[i] = vb ? xb : 0.f;
+        }
+    };
+#pragma unroll
+    for (int seg = 0; seg < NSEG; ++seg) {
+        if (seg) {
+            A = g.A2 + (long)bz * g.sab2 + (long)hz * g.sah;
+            B = g.Bm2 + (long)bz * g.sbb2 + (long)hz * g.sbh;
+        }
+        fetch(0);
+        for (int k0 = 0; k0 < g.K; k0 += SBK) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NE; ++i) { As[ak[i]][am[i]] = ra[i]; Bs[bk[i]][bn[i]] = rb[i]; }
+            __syncthreads();
+            if (k0 + SBK < g.K) fetch(k0 + SBK);
+#pragma unroll
+            for (int kk = 0; kk < SBK / 8; ++kk) {
+                float a = As[2 * (wave * (SBK / 8) + kk) + khalf][l31];
+                float b = Bs[2 * (wave * (SBK / 8) + kk) + khalf][l31];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        }
+    }
+    // waves 1 .. 3 hand their partial tile to wave 0, which sums them in wave order and writes the tile
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += Red[w][r][lane];
+    const int n = n0 + l31;
+    if (n < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (m >= g.M) continue;
+            long off = (long)m * g.scm + (long)n * g.scn;
+            float v = g.alpha * acc[r];
+            float* c = g.C + (long)bz * g.scb + (long)hz * g.sch + off;
+            if (g.beta != 0.f) v += g.beta * (*c);
+            if (g.bias) v += g.bias[m];
+            if (g.colbias) v += g.colbias[n];
             if (g.R) v += g.R[(long)bz * g.srb + (long)hz * g.sch + off];
             *c = v;
         }
@@ -265,6 +359,17 @@ void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t st) {
 }
 
 void launch_gemm(const GemmArgs& g, hipStream_t st) {
+    const int nz = g.batch * (g.batch2 > 0 ? g.batch2 : 1);
+    static int small_on = -1;      // LOCO_GEMM_SMALL=0: always the 64 x 64 tiling (A/B)
+    if (small_on < 0) { const char* e = getenv("LOCO_GEMM_SMALL"); small_on = e ? (atoi(e) != 0) : 1; }
+    // launches whose 64 x 64 grid leaves more than half of the chip idle and whose contraction is long enough to be the cost
+    const long wg64 = (long)((g.N + GBN - 1) / GBN) * ((g.M + GBM - 1) / GBM) * nz;
+    if (small_on && wg64 < 128 && g.K >= 128) {
+        dim3 sg((g.N + SBN - 1) / SBN, (g.M + SBM - 1) / SBM, nz);
+        if (g.A2) hipLaunchKernelGGL(gemm_f32_small_kernel<2>, sg, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(gemm_f32_small_kernel<1>, sg, dim3(256), 0, st, g);
+        return;
+    }
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, g.batch * (g.batch2 > 0 ? g.batch2 : 1));
     if (g.A2) hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, g);

@@ -7,7 +7,7 @@
 # 4. profiles/make_traffic.py on 3.                                          -> traffic.json (+ per-kernel csv), stamped with
 #    the sha256 of the library it was measured on; the script FAILS if that stamp does not match the library in the tree
 # 5. the same kernel-trace summary for the other workloads (configs 3, 4, 5) -> stats_<workload>/
-tag=${1:-r04}
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p $O
