@@ -37,7 +37,7 @@ res = {}
 SETTINGS = ("0", "1") if os.environ.get("DUAL_CHECK_SKIP_REPEAT") else ("0", "0b", "1")      # "0b": the default twice (run-to-run)
 for v in SETTINGS:
     out = f"/tmp/dual_check_{v}.pt"
-    env = dict(os.environ, **{ENVN: v[0]})
+    env = dict(os.environ, **{ENVN: (os.environ.get("DUAL_CHECK_ON", "1") if v[0] == "1" else "0")})      # DUAL_CHECK_ON: the value that means `on`
     subprocess.run([sys.executable, os.path.abspath(__file__), "--child", B, cfg, out], check=True, env=env)
     res[v] = torch.load(out)
 for k in (res["0"] if "0b" in res else ()):

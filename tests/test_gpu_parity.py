@@ -746,6 +746,21 @@ def test_dual_probe_conv_tile_is_bit_identical_to_the_128x256_tile():
 
 
 @pytest.mark.gpu
+def test_persistent_conv_kernel_is_bit_identical_to_one_workgroup_per_tile():
+    """The opt-in 3x3 kernel that walks the probes of a tile as one stream of chunks (conv_lowp_body PHASE 3, LOCO_CONV_PERS=2:
+    every form) against one workgroup per (tile, probe): forward batch, J V and U^T J of 3 samples / probes at 256 x 256 -- the
+    same products in the same order, the same bits (with 3 probes no launch of the default path splits a tail probe over K)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1", DUAL_CHECK_ON="2")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "dual_check.py"), "3", "CELEBA_DDPM", "LOCO_CONV_PERS"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "LOCO_CONV_PERS 0 vs 1: PASS (bit-identical)" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
 def test_edge_cases_empty_mask_single_probe_full_mask(engines):
     """Empty mask is rejected (the reference would produce NaN directions); a single probe and an all-true mask
     (L = n, same operator as mask=None) run through the solver."""

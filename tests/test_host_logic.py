@@ -477,3 +477,22 @@ def test_stop_rule_reference_and_aligned(monkeypatch):
     monkeypatch.setenv("LOCO_STOP_RULE", "lapack")
     with pytest.raises(ValueError):
         run(3, None)
+
+
+def test_synthetic_weights_threaded_and_cached_equal_the_serial_draw():
+    """`config.synth_params` draws the tensors on a thread pool and keeps the last results per process: same values as one
+    PCG64 stream per tensor drawn serially, the parameter list's own order, a fresh dict per call over shared arrays."""
+    import zlib
+    import numpy as np
+    from loco_edit_amd import config as C
+    for cfg, seed in ((C.MID_DDPM, 3), (C.TINY_ADM, 0)):
+        C._SYNTH_CACHE.clear()
+        p1 = C.synth_params(cfg, seed)
+        p2 = C.synth_params(cfg, seed)
+        assert list(p1) == list(C.param_shapes(cfg)) and p1 is not p2 and all(p1[k] is p2[k] for k in p1)
+        for name, shape in C.param_shapes(cfg).items():
+            ref = C._synth_tensor(cfg, seed, name, shape)
+            assert ref.dtype == np.float32 and np.array_equal(ref, p1[name]), name
+        name = max(p1, key=lambda n: p1[n].size)
+        z = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())])).standard_normal(p1[name].shape).astype(np.float32)
+        assert np.array_equal(p1[name], (z / np.sqrt(int(np.prod(p1[name].shape[1:])))).astype(np.float32))
