@@ -50,9 +50,18 @@ static int conv_two_per_cu() {
     if (v < 0) { const char* e = getenv("LOCO_CONV_2WG"); v = e ? (atoi(e) != 0) : 0; }
     return v;
 }
+// 1x1 operators up to this many pixels run the 128 x 128 tile of four waves (two workgroups per CU: one's write-out under the
+// other's K loop) instead of 128 x 256: r05, 5 probes: 256 -> 256 @128^2 74.7 -> 63.5 us, 512 -> 512 @64^2 73.2 -> 64.7, 128 -> 128 @256^2
+// 87.2 -> 81.5; the wide maps at 256^2 are equal or slower (128 -> 256: 159.9 vs 160.6, 256 -> 128: 143.9 vs 150.3).  LOCO_1X1_TILE0_MAXHW
+static int conv_1x1_tile0_maxhw() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LOCO_1X1_TILE0_MAXHW"); v = e ? atoi(e) : 16384; }      // headline step 290.8 -> 289.2 ms (-0.55 %); 0 = off
+    return v;
+}
 int bf16_tile_of(const ConvArgs& a) {
     int tile = conv_bf16_pick_tile(a.Cout, a.Hout * a.Wout, a.B);
     if (tile == 4) tile = 5;
+    if (tile == 5 && a.taps == 1 && !a.gemm && a.B >= 2 && a.Hout * a.Wout <= conv_1x1_tile0_maxhw()) return 0;
     if (tile == 5 && conv_two_per_cu() && a.taps == 9 && a.stride == 1 && !a.upsample && !a.zins && (a.Cin % BKC) == 0 &&
         a.in_padded && a.pad == 1 && a.Wout >= 32) return 6;
     if (a.stride == 2 && tile == 5) tile = 0;   // the double-buffered stride-2 halo of a 256-pixel tile exceeds LDS
