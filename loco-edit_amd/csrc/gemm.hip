@@ -362,9 +362,11 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
     const int nz = g.batch * (g.batch2 > 0 ? g.batch2 : 1);
     static int small_on = -1;      // LOCO_GEMM_SMALL=0: always the 64 x 64 tiling (A/B)
     if (small_on < 0) { const char* e = getenv("LOCO_GEMM_SMALL"); small_on = e ? (atoi(e) != 0) : 1; }
-    // launches whose 64 x 64 grid leaves more than half of the chip idle and whose contraction is long enough to be the cost
+    // launches whose 64 x 64 grid is about one round of the chip or less and whose contraction is long enough to be the cost
     const long wg64 = (long)((g.N + GBN - 1) / GBN) * ((g.M + GBM - 1) / GBM) * nz;
-    if (small_on && wg64 < 128 && g.K >= 128) {
+    static int small_wg = -1;      // LOCO_GEMM_SMALL_WG: largest 64 x 64 grid that still takes the small tiling
+    if (small_wg < 0) { const char* e = getenv("LOCO_GEMM_SMALL_WG"); small_wg = e ? atoi(e) : 320; }      // (r05: 128 -> 289.4 ms per headline step, 200 -> 288.6, 400 -> 288.4)
+    if (small_on && wg64 < small_wg && g.K >= 128) {
         dim3 sg((g.N + SBN - 1) / SBN, (g.M + SBM - 1) / SBM, nz);
         if (g.A2) hipLaunchKernelGGL(gemm_f32_small_kernel<2>, sg, dim3(256), 0, st, g);
         else hipLaunchKernelGGL(gemm_f32_small_kernel<1>, sg, dim3(256), 0, st, g);
