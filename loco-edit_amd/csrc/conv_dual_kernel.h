@@ -12,8 +12,8 @@
 //     used for both probes' halves (24 MFMA groups per tap and wave, 72 x 3 MFMAs per kernel row);
 //   * weights travel by LDS-DMA in a ring of SIX one-tap slots (8 KB each), issued five taps ahead; one raw s_barrier per tap;
 //     operand fragments are read one half-tap ahead across the barrier (nothing exposed but the first tap of a unit);
-//   * the halo of the next chunk is loaded one part (2 of 4 channels x 4 pixels x both probes) at a time into ONE register set and
-//     has 3.5 taps (~3 us) to land before its conversion;
+//   * the halo of the next chunk is loaded one part (2 of 4 channels x 4 pixels x both probes) at a time into ONE register set,
+//     two to four half-taps before its conversion (an L2 hit returns in ~300 cycles, a half-tap is ~1 000);
 //   * the per-thread index setup happens once per workgroup, the workgroup then walks its units (grid = min(units, CUs)).
 // LDS: 4 halo buffers [probe][chunk parity] x 348 records x 80 B = 111 360 B + 6 x 8 192 B = 160 512 B; the epilogue stages the
 // accumulators through the same memory (rounds of 2 x RPW cout rows x 512 pixels) and writes 16-byte nontemporal stores.
@@ -454,9 +454,7 @@ __global__ __launch_bounds__(512, 1) void conv_dual_bf16x3(ConvArgs a, int nunit
             constexpr int tapoff = ((t / 3) * DU_HW + (t % 3)) * HP;
             constexpr int tapoffn = (((t + 1) / 3) * DU_HW + ((t + 1) % 3)) * HP;
             constexpr int AS = (P + t) & 1;
-            unsigned char* const Hc0 = Hb + (P * 2) * HBYTES;             // halo of this chunk, probe 0 / 1
-            unsigned char* const Hc1 = Hb + (P * 2 + 1) * HBYTES;
-            unsigned char* const Hn0 = Hb + ((1 - P) * 2) * HBYTES;       // halo of the next chunk
+            unsigned char* const Hn0 = Hb + ((1 - P) * 2) * HBYTES;       // halo of the next chunk, probe 0 / 1
             unsigned char* const Hn1 = Hb + ((1 - P) * 2 + 1) * HBYTES;
             // vector work of MFMA pair q (0 .. 3) of this tap: half-tap h = 2 t + q / 2, pixel 2 (h & 1) + (q & 1) of a conversion
             auto work = [&](auto qtag) {
