@@ -30,6 +30,7 @@
 // image keys only, so COTK just reads its column of P at Lt + j.
 #include "kernels.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace loco {
 
@@ -47,17 +48,24 @@ constexpr int NBLK = 64;          // streamed tokens per block
 // bytes of one operand region for heads padded to 32 * NCT channels: 2 tensors x 2 NCT records (16 channels each) x 64 rows
 constexpr int region_bytes(int nct) { return 2 * (2 * nct) * NBLK * RP; }
 
+// two fp32 values -> one dword of bf16 hi parts and one of the residuals' bf16 values: ONE v_cvt_pk_bf16_f32 each (the scalar
+// __bf16 casts compile to a conversion per value plus shift / or packing: 11 vector instructions per pair instead of 6; same
+// roundings, same bits -- conv_bf16_kernel.h cvt2)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    float da = a - ha;
+    asm volatile("" : "+v"(da));
+    const float db = b - hb;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){da, db}, bf16x2_));
+}
 __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
-    unsigned h[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 hb = (__bf16)v[j];
-        __bf16 lb = (__bf16)(v[j] - (float)hb);
-        h[j] = __builtin_bit_cast(unsigned short, hb);
-        l[j] = __builtin_bit_cast(unsigned short, lb);
-    }
-    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    split2(v[0], v[1], hi.x, lo.x);
+    split2(v[2], v[3], hi.y, lo.y);
+    split2(v[4], v[5], hi.z, lo.z);
+    split2(v[6], v[7], hi.w, lo.w);
 }
 
 // token-major records of X[c][t] (row stride T): tokens t0 .. t0+ntok-1, 64 channels -> dst[(chunk16 * ntok + tok) * RP].
@@ -155,9 +163,13 @@ __device__ __forceinline__ Frag ld_frag(const unsigned char* rec, int khalf) {
 __device__ __forceinline__ void mma3(f32x16& acc, const Frag& a, const Frag& b) {
     const bf16x8a ah = __builtin_bit_cast(bf16x8a, a.hi), al = __builtin_bit_cast(bf16x8a, a.lo);
     const bf16x8a bh = __builtin_bit_cast(bf16x8a, b.hi), bl = __builtin_bit_cast(bf16x8a, b.lo);
+#if defined(AF_WI) && (AF_WI & 16)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+#else
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+#endif
 }
 // registers 8b .. 8b+7 of a D fragment as the B operand of k-step b
 __device__ __forceinline__ Frag frag_of(const f32x16& d, int b) {
@@ -178,8 +190,11 @@ enum : int { M_TAN = 0, M_COTQ = 1, M_COTK = 2 };
 // step at compile time; a run-time skip splits the block's scheduling region and measured 3.4 % slower)
 // NCT: 32-channel output tiles of the padded head (2: heads up to 64 channels, two workgroups per CU; 3: up to 96 channels
 // -- Stable Diffusion v1's 80-channel heads at its 1024-token level -- one workgroup per CU: 120 KB of operand regions)
+#ifndef AF_WI
+#define AF_WI 0
+#endif
 template <int MODE, int NCK, int NCT, bool TXT = false>
-__global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
+__global__ __launch_bounds__(256, (AF_WI & 8) ? 2 : 1) void attn_flash_kernel(AttnFlashArgs a) {
     constexpr int NREC = 2 * NCT;                  // 16-channel records per token
     constexpr int NOCT = 4 * NCT;                  // octets per token
     constexpr int CHP = 32 * NCT;                  // padded head width
@@ -273,15 +288,21 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
     fetch(0);
     for (int t0 = 0; t0 < U; t0 += NBLK) {
         __syncthreads();                            // the previous block's fragment reads (and the prologue's) are done
+        if (!(AF_WI & 4) || t0 == 0) {
         store_tokens<NBLK, NOCT>(ta, RA, tid);
         store_channels<NCP, CHP>(ca, RB, tid);
         if (MODE == M_TAN) { store_tokens<NBLK, NOCT>(tb, RA + T2, tid); store_channels<NCP, CHP>(cb, RB + T2, tid); }
         if (MODE == M_COTK) { store_channels<NCP, CHP>(cb, RB + T2, tid); if (tid < NBLK) DL[tid] = dreg; }
-        if (t0 + NBLK < U) fetch(t0 + NBLK);        // in flight under this block's MFMAs
+        }
+        if (!(AF_WI & 2) && t0 + NBLK < U) fetch(t0 + NBLK);        // in flight under this block's MFMAs
         // primal probabilities of the tile in the D-fragment layout (rows = streamed tokens, column = own token)
         f32x16 pt[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            if (AF_WI & 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pt[mt][r] = a.scale;
+            } else
             if (MODE != M_COTK) {                   // own = query i (a row of P): 4 consecutive streamed keys per load
                 const float* pr = P + (long)mytok * PS + t0 + 32 * mt + 4 * khalf;      // t0 is the column of P here (text first)
 #pragma unroll
@@ -327,9 +348,9 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 const int jb = mt * 2 + bb;
-                const Frag fw = frag_of(s_[mt], bb);
+                const Frag fw = (AF_WI & 4) ? y1[0] : frag_of(s_[mt], bb);
                 Frag fp;
-                if (MODE != M_COTQ) fp = frag_of(pt[mt], bb);
+                if (MODE != M_COTQ) fp = (AF_WI & 4) ? y1[1] : frag_of(pt[mt], bb);
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     const unsigned char* r1 = RB + (jb * CHP + 32 * ct + l31) * RP;
@@ -365,6 +386,339 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnFlashArgs a) {
         }
 }
 
+
+// =====================================================================================================================
+// Round 5: the same three kernels with every MFMA operand delivered by LDS-DMA from PRE-SPLIT records.
+//
+// What the what-if timing of the kernel above showed (tests/diag/attn_bench.hip, 4096 tokens x 8 heads x 40 channels, 5 probes,
+// tangent 1 922 us): without the streamed operands' global loads 1 229 us, without their conversion + ds_write 1 658 us, without the
+// loads of P 1 433 us, without all three 705 us (of which ~570 us are the MFMAs): two thirds of the launch were exposed memory
+// latency and staging -- the tangent and key-side cotangent kernels hold 323 / 338 registers, i.e. ONE wave per SIMD, and every
+// workgroup of a (probe, head) re-converted the whole k / v / dk / dv (32 query tiles: 32 x the conversion work).
+//   * `attn_split_kernel` converts each operand tensor ONCE per launch into the two record layouts the MFMAs read (token-major
+//     for the score products, channel-major in D-fragment token order for the output products; 64-byte records, 16-byte pieces
+//     XOR-swizzled by (record >> 2) & 3 so that the ds_read_b128 of 16 consecutive records hit 16 disjoint bank groups);
+//   * the attention kernel streams those records global -> LDS by `global_load_lds_dwordx4` (no staging registers, no conversion,
+//     no ds_write): the token-major region is refilled for block t+1 as soon as block t's score products have read it (under the
+//     output products of t), the channel-major region as soon as block t's output products are done (under the score products of
+//     t+1); one raw s_barrier per phase, counted vmcnt waits;
+//   * the own-token fragments come straight from the records; the P tile of block t+1 is loaded into the registers block t frees
+//     while its output products run;
+//   * 64 staging registers less: <= 256 registers, TWO workgroups per CU for heads up to 64 channels;
+//   * the probes of one (query tile, head) are adjacent in dispatch order on one XCD (blocks L, L + 8, ...): the tile's rows of P
+//     are fetched from HBM once per launch, not once per probe (537 MB per head set at 4096 tokens).
+// Same products in the same order as the kernel above: bit-identical results (tests/diag/attn_bench.hip compares the two).
+// The kernel above stays as the fallback when the caller gives no workspace (AttnFlashArgs::ws) or LOCO_FLASH_DMA=0.
+
+constexpr int RSZ = 64;                                       // record bytes
+__device__ __forceinline__ int sw_off(int rec, int piece) { return rec * RSZ + ((piece ^ ((rec >> 2) & 3)) << 4); }
+
+struct SplitJob { const float* src; long bs, hs; int nb, T, layout; unsigned char* dst; };       // layout 0: token-major, 1: channel-major
+struct SplitJobs { SplitJob j[8]; int n, NCK, CHP, nch, NH; };
+
+// grid (max T / 64, NH, sum of nb): one 64-token block of one (sample, head) of one job
+__global__ __launch_bounds__(256) void attn_split_kernel(SplitJobs J) {
+    int z = blockIdx.z, ji = 0;
+    while (ji < J.n - 1 && z >= J.j[ji].nb) { z -= J.j[ji].nb; ++ji; }
+    const SplitJob jb_ = J.j[ji];
+    const int nblk = jb_.T / NBLK, blk = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, Tr = jb_.T, nch = J.nch;
+    if (blk >= nblk) return;
+    const float* X = jb_.src + (long)z * jb_.bs + (long)h * jb_.hs;
+    const int t0 = blk * NBLK;
+    if (jb_.layout == 0) {
+        unsigned char* dst = jb_.dst + (((long)z * J.NH + h) * nblk + blk) * ((long)J.NCK * 4096);
+        for (int e = tid; e < NBLK * 2 * J.NCK; e += 256) {
+            const int tok = e % NBLK, oct = e / NBLK;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (oct * 8 + k < nch) ? X[(long)(oct * 8 + k) * Tr + t0 + tok] : 0.f;
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            const int rec = (oct >> 1) * NBLK + tok;
+            *reinterpret_cast<uint4*>(dst + sw_off(rec, oct & 1)) = hi;
+            *reinterpret_cast<uint4*>(dst + sw_off(rec, 2 + (oct & 1))) = lo;
+        }
+    } else {
+        unsigned char* dst = jb_.dst + (((long)z * J.NH + h) * nblk + blk) * ((long)J.CHP * 256);
+        const int jb = tid & 3;
+        for (int c = tid >> 2; c < J.CHP; c += 64) {
+            f32x4a a[4];
+            if (c < nch) {
+                const f32x4a* p = reinterpret_cast<const f32x4a*>(X + (long)c * Tr + t0 + jb * 16);
+                a[0] = p[0]; a[1] = p[1]; a[2] = p[2]; a[3] = p[3];
+            } else {
+                a[0] = a[1] = a[2] = a[3] = f32x4a{0.f, 0.f, 0.f, 0.f};
+            }
+            const float k0[8] = {a[0][0], a[0][1], a[0][2], a[0][3], a[2][0], a[2][1], a[2][2], a[2][3]};   // khalf 0: tokens 0-3, 8-11
+            const float k1[8] = {a[1][0], a[1][1], a[1][2], a[1][3], a[3][0], a[3][1], a[3][2], a[3][3]};   // khalf 1: 4-7, 12-15
+            uint4 h0, l0, h1, l1;
+            split8(k0, h0, l0);
+            split8(k1, h1, l1);
+            const int rec = jb * J.CHP + c;
+            *reinterpret_cast<uint4*>(dst + sw_off(rec, 0)) = h0;
+            *reinterpret_cast<uint4*>(dst + sw_off(rec, 1)) = h1;
+            *reinterpret_cast<uint4*>(dst + sw_off(rec, 2)) = l0;
+            *reinterpret_cast<uint4*>(dst + sw_off(rec, 3)) = l1;
+        }
+    }
+}
+
+struct FlashRecs {
+    const unsigned char *own1, *own2; long own1_bs, own2_bs;   // token-major records of the own-token operands (sample stride; 0: primal)
+    const unsigned char *sa1, *sa2; long sa1_bs, sa2_bs;       // streamed, token-major (A of the score products)
+    const unsigned char *sb1, *sb2; long sb1_bs, sb2_bs;       // streamed, channel-major (A of the output products)
+    const unsigned char *ta1, *tb1;                            // TXT: the prompt's text blocks in the two layouts (constants)
+    const unsigned char* zero;                                 // a block of zero records (tangents of those constants)
+};
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef const __attribute__((address_space(1))) unsigned char glb_u8;
+
+template <int MODE, int NCK, int NCT, bool TXT = false>
+__global__ __launch_bounds__(256, NCT == 2 ? 2 : 1) void attn_flash_dma_kernel(AttnFlashArgs a, FlashRecs R) {
+    constexpr int CHP = 32 * NCT;
+    constexpr int ABLK = NCK * 4096;               // bytes of a token-major block (64 tokens x NCK records)
+    constexpr int BBLK = CHP * 256;                // bytes of a channel-major block (4 k-steps x CHP rows)
+    constexpr int NTA = MODE == M_TAN ? 2 : 1;     // streamed token-major tensors
+    constexpr int NTB = MODE == M_COTQ ? 1 : 2;    // streamed channel-major tensors
+    constexpr int NPL = MODE == M_COTK ? 33 : 8;   // plain loads per thread and block (P tile; COTK: + delta)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const RA = lds;
+    unsigned char* const RB = lds + NTA * ABLK;
+    float* const DL = reinterpret_cast<float*>(lds + NTA * ABLK + NTB * BBLK);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, nch = a.CH;
+    int tile, b;
+    {
+        const int NTT = (T / NOWN) * a.NH, L = blockIdx.x;
+        if ((NTT & 7) == 0) { const int q_ = L >> 3; b = q_ % a.B; tile = (q_ / a.B) * 8 + (L & 7); }
+        else { b = L % a.B; tile = L / a.B; }
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        b = __builtin_amdgcn_readfirstlane(b);
+    }
+    const int h = tile / (T / NOWN), own0 = (tile % (T / NOWN)) * NOWN;
+    const int mytok = own0 + wave * 32 + l31;
+    const long HS = a.hs, HO = (long)nch * T;
+    const int Lt = TXT ? a.Lt : 0;
+    const int PS = Lt + T;
+    const float* P = a.P + (long)h * T * PS;
+    const float* o = a.o + h * HO;
+    const float* go = MODE != M_TAN ? a.go + (long)b * a.bs_go + h * HO : nullptr;
+    const int nblk = T / NBLK, ntxt = Lt / NBLK;
+    // record bases of this (probe, head)
+    const long hsA = (long)nblk * ABLK, hsB = (long)nblk * BBLK;
+    const unsigned char* const own1 = R.own1 + (long)b * R.own1_bs + h * hsA;
+    const unsigned char* const own2 = MODE == M_TAN ? R.own2 + (long)b * R.own2_bs + h * hsA : nullptr;
+    const unsigned char* const sa1 = R.sa1 + (long)b * R.sa1_bs + h * hsA;
+    const unsigned char* const sa2 = NTA == 2 ? R.sa2 + (long)b * R.sa2_bs + h * hsA : nullptr;
+    const unsigned char* const sb1 = R.sb1 + (long)b * R.sb1_bs + h * hsB;
+    const unsigned char* const sb2 = NTB == 2 ? R.sb2 + (long)b * R.sb2_bs + h * hsB : nullptr;
+    const unsigned char* const ta1 = TXT ? R.ta1 + (long)h * ntxt * ABLK : nullptr;
+    const unsigned char* const tb1 = TXT ? R.tb1 + (long)h * ntxt * BBLK : nullptr;
+
+    // the lane's piece offsets inside a run of 32 records (row l31): hi / lo piece of its k-half, swizzled
+    const int kx = (l31 >> 2) & 3;
+    const unsigned offh = (unsigned)l31 * RSZ + (unsigned)((khalf ^ kx) << 4), offl = (unsigned)l31 * RSZ + (unsigned)(((2 + khalf) ^ kx) << 4);
+
+    // ---- own-token B fragments straight from the records
+    Frag y1[NCK], y2[MODE == M_TAN ? NCK : 1];
+    {
+        const long ob = (long)((own0 >> 6) + (wave >> 1)) * ABLK + (wave & 1) * (32 * RSZ);
+#pragma unroll
+        for (int ck = 0; ck < NCK; ++ck) {
+            y1[ck].hi = *reinterpret_cast<const s16x8a*>(own1 + ob + ck * 4096 + offh);
+            y1[ck].lo = *reinterpret_cast<const s16x8a*>(own1 + ob + ck * 4096 + offl);
+            if (MODE == M_TAN) {
+                y2[ck].hi = *reinterpret_cast<const s16x8a*>(own2 + ob + ck * 4096 + offh);
+                y2[ck].lo = *reinterpret_cast<const s16x8a*>(own2 + ob + ck * 4096 + offl);
+            }
+        }
+    }
+    float delta_own = 0.f;
+    if (MODE == M_COTQ) {
+        float s = 0.f;
+        for (int c = khalf * (CHP / 2); c < khalf * (CHP / 2) + CHP / 2 && c < nch; ++c) s += go[(long)c * T + mytok] * o[(long)c * T + mytok];
+        s += __shfl_xor(s, 32, 64);
+        delta_own = s;
+        if (khalf == 0) a.delta[((long)b * a.NH + h) * T + mytok] = s;
+    }
+
+    f32x16 acc[NCT], acc2[MODE == M_COTK ? NCT : 1];
+#pragma unroll
+    for (int i = 0; i < NCT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; if (MODE == M_COTK) acc2[i][r] = 0.f; }
+    float rsum = 0.f;
+
+    const int NB_ = (TXT && MODE != M_COTK) ? ntxt + nblk : nblk;       // streamed blocks ([text ; image] under TXT)
+    // DMA of streamed block n: the token-major region / the channel-major region
+    auto dma_A = [&](int n) {
+        const bool text = TXT && MODE != M_COTK && n < ntxt;
+        const int bi = __builtin_amdgcn_readfirstlane(text ? n : n - ((TXT && MODE != M_COTK) ? ntxt : 0));
+        const unsigned char* s1 = text ? ta1 + (long)bi * ABLK : sa1 + (long)bi * ABLK;
+#pragma unroll
+        for (int i = 0; i < NCK; ++i)
+            __builtin_amdgcn_global_load_lds((glb_u8*)(s1 + i * 4096 + tid * 16), (lds_u8*)(RA + i * 4096 + wave * 1024), 16, 0, 0);
+        if constexpr (NTA == 2) {
+            const unsigned char* s2 = text ? R.zero : sa2 + (long)bi * ABLK;
+#pragma unroll
+            for (int i = 0; i < NCK; ++i)
+                __builtin_amdgcn_global_load_lds((glb_u8*)(s2 + i * 4096 + tid * 16), (lds_u8*)(RA + ABLK + i * 4096 + wave * 1024), 16, 0, 0);
+        }
+    };
+    auto dma_B = [&](int n) {
+        const bool text = TXT && MODE != M_COTK && n < ntxt;
+        const int bi = __builtin_amdgcn_readfirstlane(text ? n : n - ((TXT && MODE != M_COTK) ? ntxt : 0));
+        const unsigned char* s1 = text ? tb1 + (long)bi * BBLK : sb1 + (long)bi * BBLK;
+#pragma unroll
+        for (int i = 0; i < CHP / 16; ++i)
+            __builtin_amdgcn_global_load_lds((glb_u8*)(s1 + i * 4096 + tid * 16), (lds_u8*)(RB + i * 4096 + wave * 1024), 16, 0, 0);
+        if constexpr (NTB == 2) {
+            const unsigned char* s2 = text ? R.zero : sb2 + (long)bi * BBLK;
+#pragma unroll
+            for (int i = 0; i < CHP / 16; ++i)
+                __builtin_amdgcn_global_load_lds((glb_u8*)(s2 + i * 4096 + tid * 16), (lds_u8*)(RB + BBLK + i * 4096 + wave * 1024), 16, 0, 0);
+        }
+    };
+    // primal probabilities of block n, 32-token half mt, in the D-fragment layout (rows = streamed tokens, column = own token)
+    f32x16 pt[2];
+    float dreg = 0.f;
+    const unsigned p_lane = MODE != M_COTK ? ((unsigned)mytok * (unsigned)PS + 4u * khalf) * 4u
+                                           : ((unsigned)(4 * khalf) * (unsigned)PS + (unsigned)(Lt + mytok)) * 4u;
+    auto load_P = [&](int n, int mt) {
+        const int u = n * NBLK;
+        if (AF_WI & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pt[mt][r] = a.scale;
+            return;
+        }
+        // wave-uniform base (the block's first column / row of P) + a 32-bit lane offset: scalar-base addressing, no 64-bit
+        // address arithmetic per load
+        if (MODE != M_COTK) {
+            const unsigned char* pb = reinterpret_cast<const unsigned char*>(P + u);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const f32x4a x = *reinterpret_cast<const f32x4a*>(pb + (p_lane + (unsigned)(128 * mt + 32 * qd)));
+                pt[mt][4 * qd] = x[0]; pt[mt][4 * qd + 1] = x[1]; pt[mt][4 * qd + 2] = x[2]; pt[mt][4 * qd + 3] = x[3];
+            }
+        } else {
+            if (mt == 0) dreg = a.delta[((long)b * a.NH + h) * T + u + lane];        // (first: its use at the top of the block waits for it alone)
+            const unsigned char* pb = reinterpret_cast<const unsigned char*>(P + (long)u * PS);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned ro = (unsigned)((32 * mt + (r & 3) + 8 * (r >> 2)) * PS) * 4u;       // (wave-uniform)
+                pt[mt][r] = *reinterpret_cast<const float*>(pb + (p_lane + ro));
+            }
+        }
+    };
+
+    // ---- prologue: block 0's token-major records, then its P tile (this order is what the counted wait below relies on)
+    dma_A(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_P(0, 0); load_P(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int n = 0; n < NB_; ++n) {
+        // RA(n) has landed (all but the NPL younger plain loads); every wave is done with block n-1's output products
+        if (MODE == M_COTK && wave == 0) DL[lane] = dreg;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AF_WI & 1) ? 0 : NPL) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!(AF_WI & 2) || n == 0) dma_B(n);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- GEMM 1: S[streamed token][own token]
+        f32x16 s_[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_[mt][r] = 0.f;
+#pragma unroll
+            for (int ck = 0; ck < NCK; ++ck) {
+                Frag fa;
+                fa.hi = *reinterpret_cast<const s16x8a*>(RA + (ck * NBLK + 32 * mt) * RSZ + offh);
+                fa.lo = *reinterpret_cast<const s16x8a*>(RA + (ck * NBLK + 32 * mt) * RSZ + offl);
+                mma3(s_[mt], fa, y1[ck]);
+                if (MODE == M_TAN) {
+                    fa.hi = *reinterpret_cast<const s16x8a*>(RA + ABLK + (ck * NBLK + 32 * mt) * RSZ + offh);
+                    fa.lo = *reinterpret_cast<const s16x8a*>(RA + ABLK + (ck * NBLK + 32 * mt) * RSZ + offl);
+                    mma3(s_[mt], fa, y2[ck]);
+                }
+            }
+        }
+        // P(n) and RB(n) have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float w;
+                if (MODE == M_TAN) { w = a.scale * pt[mt][r] * s_[mt][r]; rsum += w; }
+                else if (MODE == M_COTQ) w = a.scale * pt[mt][r] * (s_[mt][r] - delta_own);
+                else w = a.scale * pt[mt][r] * (s_[mt][r] - DL[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * khalf]);
+                s_[mt][r] = w;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave is done with RA(n); RB(n) is visible
+        asm volatile("" ::: "memory");
+        const bool more = n + 1 < NB_;
+        if (more && !(AF_WI & 2)) dma_A(n + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- GEMM 2: acc[channel][own token] += sum over the 64 streamed tokens; the P tile of block n+1 takes the registers
+        // of each half as soon as that half's products are issued
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int jb = mt * 2 + bb;
+                const Frag fw = (AF_WI & 4) ? y1[0] : frag_of(s_[mt], bb);
+                Frag fp;
+                if (MODE != M_COTQ) fp = (AF_WI & 4) ? y1[1] : frag_of(pt[mt], bb);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const unsigned char* r1 = RB + (jb * CHP + 32 * ct) * RSZ;
+                    Frag f1, f2;
+                    f1.hi = *reinterpret_cast<const s16x8a*>(r1 + offh);
+                    f1.lo = *reinterpret_cast<const s16x8a*>(r1 + offl);
+                    if (NTB == 2) {
+                        f2.hi = *reinterpret_cast<const s16x8a*>(r1 + BBLK + offh);
+                        f2.lo = *reinterpret_cast<const s16x8a*>(r1 + BBLK + offl);
+                    }
+                    if (MODE == M_TAN) {
+                        mma3(acc[ct], f1, fw);                           // v W
+                        mma3(acc[ct], f2, fp);                           // dv P
+                    } else if (MODE == M_COTQ) {
+                        mma3(acc[ct], f1, fw);                           // k G
+                    } else {
+                        mma3(acc[ct], f1, fp);                           // g_o P  -> g_v
+                        mma3(acc2[ct], f2, fw);                          // q G    -> g_k
+                    }
+                }
+            }
+            if (more) load_P(n + 1, mt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue.  D[row = channel][col = own token]
+    if (MODE == M_TAN) rsum += __shfl_xor(rsum, 32, 64);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (c >= nch) continue;
+            const long off = (long)c * T + mytok;
+            if (MODE == M_TAN) {
+                a.out[(long)b * a.bs_out + h * HO + off] = acc[ct][r] - rsum * o[off];
+            } else if (MODE == M_COTQ) {
+                a.gq[(long)b * a.bs_g + h * HS + off] = acc[ct][r];
+            } else {
+                a.gv[(long)b * a.bs_g + h * HS + off] = acc[ct][r];
+                a.gk[(long)b * a.bs_g + h * HS + off] = acc2[ct][r];
+            }
+        }
+}
+
 }  // namespace
 
 bool attn_flash_text_supported(int T, int CH, int Lt) {
@@ -379,7 +733,7 @@ bool attn_flash_supported(int T, int CH) {
 template <int NCK, int NCT, bool TXT = false>
 static void attn_flash_launch_n(int mode, const AttnFlashArgs& a, hipStream_t st) {
     dim3 grid(a.T / NOWN, a.NH, a.B);
-    const size_t ldsb = 2 * region_bytes(NCT);       // NCT 2: 80 KB, two workgroups per CU; NCT 3: 120 KB, one
+    const size_t ldsb = 2 * region_bytes(NCT);       // NCT 2: 80 KB; NCT 3: 120 KB
     auto k0 = &attn_flash_kernel<M_TAN, NCK, NCT, TXT>;
     auto k1 = &attn_flash_kernel<M_COTQ, NCK, NCT, TXT>;
     auto k2 = &attn_flash_kernel<M_COTK, NCK, NCT, TXT>;
@@ -393,7 +747,115 @@ static void attn_flash_launch_n(int mode, const AttnFlashArgs& a, hipStream_t st
     else if (mode == M_COTQ) hipLaunchKernelGGL(k1, grid, dim3(256), ldsb, st, a);
     else hipLaunchKernelGGL(k2, grid, dim3(256), ldsb, st, a);
 }
+
+// ---- the DMA-fed kernels: workspace layout, the split pass, the launches -------------------------------------------------
+static int flash_dma_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LOCO_FLASH_DMA"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static void flash_shape(int CH, bool txt, int& nck, int& nct) {
+    if (txt) { nck = 4; nct = 2; }
+    else if (CH <= 48) { nck = 3; nct = 2; }
+    else if (CH <= 64) { nck = 4; nct = 2; }
+    else if (CH <= 80) { nck = 5; nct = 3; }
+    else { nck = 6; nct = 3; }
+}
+struct FlashWs { size_t tokS, chS, tokT, chT, zero, tan, cot; };
+static FlashWs flash_ws(const AttnFlashArgs& a) {
+    int nck, nct;
+    flash_shape(a.CH, a.Lt > 0, nck, nct);
+    FlashWs w;
+    const size_t ABLK = (size_t)nck * 4096, BBLK = (size_t)nct * 32 * 256;
+    w.tokS = (size_t)a.NH * (a.T / NBLK) * ABLK;  w.chS = (size_t)a.NH * (a.T / NBLK) * BBLK;
+    w.tokT = (size_t)a.NH * (a.Lt / NBLK) * ABLK; w.chT = (size_t)a.NH * (a.Lt / NBLK) * BBLK;
+    w.zero = ABLK > BBLK ? ABLK : BBLK;
+    w.tan = (size_t)(2 + 2 * a.B) * w.tokS + (size_t)(1 + a.B) * w.chS + w.tokT + w.chT + w.zero;
+    w.cot = (size_t)(1 + a.B) * w.tokS + (size_t)(2 + a.B) * w.chS + w.tokT + w.chT + w.zero;
+    return w;
+}
+size_t attn_flash_ws_bytes(const AttnFlashArgs& a) { const FlashWs w = flash_ws(a); return w.tan > w.cot ? w.tan : w.cot; }
+
+static void flash_split(const SplitJobs& J, hipStream_t st) {
+    int nb = 0, tmax = 0;
+    for (int i = 0; i < J.n; ++i) { nb += J.j[i].nb; tmax = J.j[i].T > tmax ? J.j[i].T : tmax; }
+    hipLaunchKernelGGL(attn_split_kernel, dim3(tmax / NBLK, J.NH, nb), dim3(256), 0, st, J);
+}
+
+template <int MODE, int NCK, int NCT, bool TXT>
+static void flash_dma_launch_one(const AttnFlashArgs& a, const FlashRecs& R, hipStream_t st) {
+    constexpr int NTA = MODE == M_TAN ? 2 : 1, NTB = MODE == M_COTQ ? 1 : 2;
+    const size_t ldsb = (size_t)NTA * NCK * 4096 + (size_t)NTB * NCT * 32 * 256 + 256;
+    auto k = &attn_flash_dma_kernel<MODE, NCK, NCT, TXT>;
+    static DeviceOnce once;
+    if (first_on_device(once)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (AF_WI & 8) return;
+    hipLaunchKernelGGL(k, dim3((a.T / NOWN) * a.NH * a.B), dim3(256), ldsb, st, a, R);
+}
+
+template <int NCK, int NCT, bool TXT = false>
+static void attn_flash_dma_n(int mode, const AttnFlashArgs& a, hipStream_t st) {      // mode: M_TAN, or M_COTQ for the cotangent pair
+    const FlashWs w = flash_ws(a);
+    unsigned char* p = a.ws;
+    auto take = [&](size_t n) { unsigned char* r = p; p += n; return r; };
+    SplitJobs J; std::memset(&J, 0, sizeof(J));
+    J.NCK = NCK; J.CHP = 32 * NCT; J.nch = a.CH; J.NH = a.NH;
+    auto job = [&](const float* src, long bs, long hs, int nb, int T, int layout, unsigned char* dst) {
+        J.j[J.n++] = SplitJob{src, bs, hs, nb, T, layout, dst};
+    };
+    const long HO = (long)a.CH * a.T;
+    FlashRecs R; std::memset(&R, 0, sizeof(R));
+    unsigned char* zero = take(w.zero);
+    (void)hipMemsetAsync(zero, 0, w.zero, st);
+    R.zero = zero;
+    if (mode == M_TAN) {
+        unsigned char *rk = take(w.tokS), *rdk = take(a.B * w.tokS), *rq = take(w.tokS), *rdq = take(a.B * w.tokS);
+        unsigned char *rv = take(w.chS), *rdv = take(a.B * w.chS);
+        job(a.k, 0, a.hs, 1, a.T, 0, rk);   job(a.dk, a.bs_d, a.hs, a.B, a.T, 0, rdk);
+        job(a.q, 0, a.hs, 1, a.T, 0, rq);   job(a.dq, a.bs_d, a.hs, a.B, a.T, 0, rdq);
+        job(a.v, 0, a.hs, 1, a.T, 1, rv);   job(a.dv, a.bs_d, a.hs, a.B, a.T, 1, rdv);
+        if (TXT) {
+            unsigned char *rkt = take(w.tokT), *rvt = take(w.chT);
+            job(a.kt, 0, (long)a.CH * a.Lt, 1, a.Lt, 0, rkt); job(a.vt, 0, (long)a.CH * a.Lt, 1, a.Lt, 1, rvt);
+            R.ta1 = rkt; R.tb1 = rvt;
+        }
+        flash_split(J, st);
+        R.own1 = rdq; R.own1_bs = (long)w.tokS; R.own2 = rq; R.own2_bs = 0;
+        R.sa1 = rk; R.sa1_bs = 0; R.sa2 = rdk; R.sa2_bs = (long)w.tokS;
+        R.sb1 = rv; R.sb1_bs = 0; R.sb2 = rdv; R.sb2_bs = (long)w.chS;
+        flash_dma_launch_one<M_TAN, NCK, NCT, TXT>(a, R, st);
+        return;
+    }
+    unsigned char *rgo = take(a.B * w.tokS), *rv = take(w.tokS), *rk = take(w.chS), *rgoc = take(a.B * w.chS), *rq = take(w.chS);
+    job(a.go, a.bs_go, HO, a.B, a.T, 0, rgo);  job(a.v, 0, a.hs, 1, a.T, 0, rv);
+    job(a.k, 0, a.hs, 1, a.T, 1, rk);          job(a.go, a.bs_go, HO, a.B, a.T, 1, rgoc);
+    job(a.q, 0, a.hs, 1, a.T, 1, rq);
+    if (TXT) {
+        unsigned char *rvt = take(w.tokT), *rkt = take(w.chT);
+        job(a.vt, 0, (long)a.CH * a.Lt, 1, a.Lt, 0, rvt); job(a.kt, 0, (long)a.CH * a.Lt, 1, a.Lt, 1, rkt);
+        R.ta1 = rvt; R.tb1 = rkt;
+    }
+    flash_split(J, st);
+    R.own1 = rgo; R.own1_bs = (long)w.tokS;
+    R.sa1 = rv; R.sa1_bs = 0;
+    R.sb1 = rk; R.sb1_bs = 0;
+    flash_dma_launch_one<M_COTQ, NCK, NCT, TXT>(a, R, st);      // g_q and delta_i (read by the second kernel: the kernel boundary orders them)
+    FlashRecs K = R;
+    K.own1 = rv; K.own1_bs = 0;
+    K.sa1 = rgo; K.sa1_bs = (long)w.tokS;
+    K.sb1 = rgoc; K.sb1_bs = (long)w.chS; K.sb2 = rq; K.sb2_bs = 0;
+    flash_dma_launch_one<M_COTK, NCK, NCT, TXT>(a, K, st);      // g_k, g_v
+}
+
 static void attn_flash_launch(int mode, const AttnFlashArgs& a, hipStream_t st) {
+    if (a.ws && flash_dma_on() && attn_flash_ws_bytes(a) <= a.ws_bytes && (mode == M_TAN || mode == M_COTQ)) {
+        if (a.Lt > 0) attn_flash_dma_n<4, 2, true>(mode, a, st);
+        else if (a.CH <= 48) attn_flash_dma_n<3, 2>(mode, a, st);
+        else if (a.CH <= 64) attn_flash_dma_n<4, 2>(mode, a, st);
+        else if (a.CH <= 80) attn_flash_dma_n<5, 3>(mode, a, st);
+        else attn_flash_dma_n<6, 3>(mode, a, st);
+        return;
+    }
     if (a.Lt > 0) { attn_flash_launch_n<4, 2, true>(mode, a, st); return; }      // attn_flash_text_supported: heads of <= 64 channels
     if (a.CH <= 48) attn_flash_launch_n<3, 2>(mode, a, st);
     else if (a.CH <= 64) attn_flash_launch_n<4, 2>(mode, a, st);
@@ -403,6 +865,7 @@ static void attn_flash_launch(int mode, const AttnFlashArgs& a, hipStream_t st) 
 
 void launch_attn_flash_tangent(const AttnFlashArgs& a, hipStream_t st) { attn_flash_launch(M_TAN, a, st); }
 void launch_attn_flash_cotangent(const AttnFlashArgs& a, hipStream_t st) {
+    if (a.ws && flash_dma_on() && attn_flash_ws_bytes(a) <= a.ws_bytes) { attn_flash_launch(M_COTQ, a, st); return; }    // (the pair)
     attn_flash_launch(M_COTQ, a, st);      // g_q and delta_i (read by the second kernel: the kernel boundary orders them)
     attn_flash_launch(M_COTK, a, st);      // g_k, g_v
 }

@@ -1585,6 +1585,7 @@ void sa_tangent(const SA& s) {       // dq, dk, dv in arenaT(qkv) -> do in arena
     const float scale = 1.0f / std::sqrt((float)CH);
     if (c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH)) {
         AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+        fa.ws = reinterpret_cast<unsigned char*>(c->partial); fa.ws_bytes = c->partial_floats * sizeof(float);      // (records of the operands: attn_flash.hip)
         fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = SP; fa.o = oP;
         fa.dq = dq; fa.dk = dk; fa.dv = dv; fa.bs_d = PS; fa.out = oT; fa.bs_out = PS;
         launch_attn_flash_tangent(fa, s.st);
@@ -1619,6 +1620,7 @@ void sa_cotangent(const SA& s) {     // g_o in arenaT(o) -> g_q, g_k, g_v in are
     const float scale = 1.0f / std::sqrt((float)CH);
     if (c->flash_attn && c->prec >= 1 && attn_flash_supported(T, CH)) {
         AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+        fa.ws = reinterpret_cast<unsigned char*>(c->partial); fa.ws_bytes = c->partial_floats * sizeof(float);      // (records of the operands: attn_flash.hip)
         fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = SP; fa.o = oP;
         fa.go = oG; fa.bs_go = PS; fa.gq = gq; fa.gk = gk; fa.gv = gv; fa.bs_g = PS; fa.delta = c->attn_delta;
         launch_attn_flash_cotangent(fa, s.st);
@@ -1713,6 +1715,7 @@ void akv_tangent(const AKV& s) {        // dq, dk, dv in arenaT(qkv) -> do in ar
     float* oT = c->arenaT + c->tens[op.o].off;
     if (c->flash_attn && c->prec >= 1 && attn_flash_text_supported(s.T, s.CH, s.Lp)) {      // no [T x (Lp + T)] tangent (attn_flash.hip TXT)
         AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+        fa.ws = reinterpret_cast<unsigned char*>(c->partial); fa.ws_bytes = c->partial_floats * sizeof(float);      // (records of the operands: attn_flash.hip)
         fa.T = s.T; fa.NH = s.NH; fa.B = s.B; fa.CH = s.CH; fa.scale = s.scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = s.HS;
         fa.P = SP; fa.o = c->arenaP + c->tens[op.o].off; fa.Lt = s.Lp; fa.kt = op.xK; fa.vt = op.xV;
         fa.dq = dq; fa.dk = dk; fa.dv = dv; fa.bs_d = PS; fa.out = oT; fa.bs_out = PS;
@@ -1736,6 +1739,7 @@ void akv_cotangent(const AKV& s) {      // g_o in arenaT(o) -> g_q, g_k, g_v in 
     float* oG = c->arenaT + c->tens[op.o].off;
     if (c->flash_attn && c->prec >= 1 && attn_flash_text_supported(s.T, s.CH, s.Lp)) {
         AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+        fa.ws = reinterpret_cast<unsigned char*>(c->partial); fa.ws_bytes = c->partial_floats * sizeof(float);      // (records of the operands: attn_flash.hip)
         fa.T = s.T; fa.NH = s.NH; fa.B = s.B; fa.CH = s.CH; fa.scale = s.scale; fa.q = q; fa.k = k; fa.v = v; fa.hs = s.HS;
         fa.P = SP; fa.o = c->arenaP + c->tens[op.o].off; fa.Lt = s.Lp; fa.kt = op.xK; fa.vt = op.xV;
         fa.go = oG; fa.bs_go = PS; fa.gq = gq; fa.gk = gk; fa.gv = gv; fa.bs_g = PS; fa.delta = c->attn_delta;
@@ -2107,6 +2111,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 if (op.added_kv) akv_tangent(akv_of(c, op, B, st));
                 else if (flash) {   // do from dq, dk, dv and the primal P / o in one kernel, no [T x T] tangent (attn_flash.hip)
                     AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+                    fa.ws = reinterpret_cast<unsigned char*>(c->partial); fa.ws_bytes = c->partial_floats * sizeof(float);      // (records of the operands: attn_flash.hip)
                     fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = 1.0f / std::sqrt((float)CH);
                     fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = TP(op.S); fa.o = TP(op.o);
                     fa.dq = dq; fa.dk = dk; fa.dv = dv; fa.bs_d = PS; fa.out = TT(op.o); fa.bs_out = PS;
@@ -2399,6 +2404,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                 if (op.added_kv) akv_cotangent(akv_of(c, op, B, st));
                 else if (flash) {   // g_q, g_k, g_v from g_o and the primal q / k / v / P / o, no [T x T] cotangent (attn_flash.hip)
                     AttnFlashArgs fa; std::memset(&fa, 0, sizeof(fa));
+                    fa.ws = reinterpret_cast<unsigned char*>(c->partial); fa.ws_bytes = c->partial_floats * sizeof(float);      // (records of the operands: attn_flash.hip)
                     fa.T = T; fa.NH = NH; fa.B = B; fa.CH = CH; fa.scale = 1.0f / std::sqrt((float)CH);
                     fa.q = q; fa.k = k; fa.v = v; fa.hs = HS; fa.P = TP(op.S); fa.o = TP(op.o);
                     fa.go = TG(op.o); fa.bs_go = PS; fa.gq = gq; fa.gk = gk; fa.gv = gv; fa.bs_g = PS; fa.delta = c->attn_delta;

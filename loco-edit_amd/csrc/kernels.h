@@ -187,7 +187,11 @@ struct AttnFlashArgs {
     // keys / values = [text ; image] in one softmax (DeepFloyd-IF): Lt text columns (a multiple of 64, zero-padded) ahead of
     // the T image columns in every row of P ([NH][T][Lt + T]); kt / vt [NH][CH][Lt] constants.  Lt = 0: plain self-attention
     int Lt; const float *kt, *vt;
+    // round 5: workspace for the operands' pre-split records (attn_flash_ws_bytes); nullptr / too small: the kernels that convert
+    // the operands themselves
+    unsigned char* ws; size_t ws_bytes;
 };
+size_t attn_flash_ws_bytes(const AttnFlashArgs& a);
 bool attn_flash_supported(int T, int CH);     // heads of <= 96 channels, token counts that are multiples of 128
 bool attn_flash_text_supported(int T, int CH, int Lt);   // the [text ; image] form: heads of <= 64 channels
 void launch_attn_flash_tangent(const AttnFlashArgs& a, hipStream_t st);
