@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, NCT == 2 ? 2 : 1) void attn_flash_dma_kernel(A
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const RA = lds;
     unsigned char* const RB = lds + NTA * ABLK;
-    float* const DL = reinterpret_cast<float*>(lds + NTA * ABLK + NTB * BBLK);
+    float* const DL = reinterpret_cast<float*>(lds + NTA * ABLK + NTB * BBLK);      // COTK: delta of the streamed queries, one copy per wave
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.T, nch = a.CH;
@@ -543,6 +543,14 @@ __global__ __launch_bounds__(256, NCT == 2 ? 2 : 1) void attn_flash_dma_kernel(A
         delta_own = s;
         if (khalf == 0) a.delta[((long)b * a.NH + h) * T + mytok] = s;
     }
+    // A "use" of the own fragments in front of the loop: the compiler then waits for their loads HERE.  Left pending into the loop
+    // they cost an s_waitcnt vmcnt(0) in front of the first MFMA of every block (the waitcnt pass cannot count across the back
+    // edge), which also waited for the DMAs that had just been issued: no overlap of RB(n)'s transfer with the score products.
+#pragma unroll
+    for (int ck = 0; ck < NCK; ++ck) {
+        asm volatile("" :: "v"(y1[ck].hi), "v"(y1[ck].lo));
+        if (MODE == M_TAN) asm volatile("" :: "v"(y2[ck].hi), "v"(y2[ck].lo));
+    }
 
     f32x16 acc[NCT], acc2[MODE == M_COTK ? NCT : 1];
 #pragma unroll
@@ -583,7 +591,6 @@ __global__ __launch_bounds__(256, NCT == 2 ? 2 : 1) void attn_flash_dma_kernel(A
     };
     // primal probabilities of block n, 32-token half mt, in the D-fragment layout (rows = streamed tokens, column = own token)
     f32x16 pt[2];
-    float dreg = 0.f;
     const unsigned p_lane = MODE != M_COTK ? ((unsigned)mytok * (unsigned)PS + 4u * khalf) * 4u
                                            : ((unsigned)(4 * khalf) * (unsigned)PS + (unsigned)(Lt + mytok)) * 4u;
     auto load_P = [&](int n, int mt) {
@@ -603,7 +610,11 @@ __global__ __launch_bounds__(256, NCT == 2 ? 2 : 1) void attn_flash_dma_kernel(A
                 pt[mt][4 * qd] = x[0]; pt[mt][4 * qd + 1] = x[1]; pt[mt][4 * qd + 2] = x[2]; pt[mt][4 * qd + 3] = x[3];
             }
         } else {
-            if (mt == 0) dreg = a.delta[((long)b * a.NH + h) * T + u + lane];        // (first: its use at the top of the block waits for it alone)
+            // delta of the block's 64 queries: by DMA into the wave's OWN 256 bytes of LDS (no register, no cross-wave hand-over:
+            // the elementwise step of block n-1 is behind this wave, the wait in front of block n's covers the transfer)
+            if (mt == 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) float*)(a.delta + ((long)b * a.NH + h) * T + u + lane),
+                                                 (__attribute__((address_space(3))) float*)(DL + wave * 64), 4, 0, 0);
             const unsigned char* pb = reinterpret_cast<const unsigned char*>(P + (long)u * PS);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -620,7 +631,6 @@ __global__ __launch_bounds__(256, NCT == 2 ? 2 : 1) void attn_flash_dma_kernel(A
     __builtin_amdgcn_sched_barrier(0);
     for (int n = 0; n < NB_; ++n) {
         // RA(n) has landed (all but the NPL younger plain loads); every wave is done with block n-1's output products
-        if (MODE == M_COTK && wave == 0) DL[lane] = dreg;
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AF_WI & 1) ? 0 : NPL) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -646,8 +656,11 @@ __global__ __launch_bounds__(256, NCT == 2 ? 2 : 1) void attn_flash_dma_kernel(A
                 }
             }
         }
-        // P(n) and RB(n) have landed
+        // P(n) and RB(n) have landed.  (The scheduling fences pin the elementwise step between this wait and the barrier: left free,
+        // the compiler sank it below the next DMA issue, where its own wait for the P registers became a vmcnt(0) on those DMAs.)
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -655,9 +668,11 @@ __global__ __launch_bounds__(256, NCT == 2 ? 2 : 1) void attn_flash_dma_kernel(A
                 float w;
                 if (MODE == M_TAN) { w = a.scale * pt[mt][r] * s_[mt][r]; rsum += w; }
                 else if (MODE == M_COTQ) w = a.scale * pt[mt][r] * (s_[mt][r] - delta_own);
-                else w = a.scale * pt[mt][r] * (s_[mt][r] - DL[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * khalf]);
+                else w = a.scale * pt[mt][r] * (s_[mt][r] - DL[wave * 64 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * khalf]);
+                asm volatile("" : "+v"(w));           // (computed HERE: the optimiser otherwise sinks the step into the next phase's block)
                 s_[mt][r] = w;
             }
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // every wave is done with RA(n); RB(n) is visible
         asm volatile("" ::: "memory");
@@ -749,10 +764,9 @@ static void attn_flash_launch_n(int mode, const AttnFlashArgs& a, hipStream_t st
 }
 
 // ---- the DMA-fed kernels: workspace layout, the split pass, the launches -------------------------------------------------
-static int flash_dma_on() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LOCO_FLASH_DMA"); v = e ? atoi(e) : 1; }
-    return v;
+static int flash_dma_on() {          // LOCO_FLASH_DMA=0: the kernels that convert their operands themselves (A/B switch; read per launch)
+    const char* e = getenv("LOCO_FLASH_DMA");
+    return e ? atoi(e) : 1;
 }
 static void flash_shape(int CH, bool txt, int& nck, int& nct) {
     if (txt) { nck = 4; nct = 2; }
@@ -785,7 +799,7 @@ static void flash_split(const SplitJobs& J, hipStream_t st) {
 template <int MODE, int NCK, int NCT, bool TXT>
 static void flash_dma_launch_one(const AttnFlashArgs& a, const FlashRecs& R, hipStream_t st) {
     constexpr int NTA = MODE == M_TAN ? 2 : 1, NTB = MODE == M_COTQ ? 1 : 2;
-    const size_t ldsb = (size_t)NTA * NCK * 4096 + (size_t)NTB * NCT * 32 * 256 + 256;
+    const size_t ldsb = (size_t)NTA * NCK * 4096 + (size_t)NTB * NCT * 32 * 256 + 1024;
     auto k = &attn_flash_dma_kernel<MODE, NCK, NCT, TXT>;
     static DeviceOnce once;
     if (first_on_device(once)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);

@@ -25,5 +25,8 @@ case $W in
     cd /tmp && export TMPDIR=/tmp; [ -n "$2" ] && export "$2"
     rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/stats -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload ${1:-celeba_top5} --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra > $GRAFT_REPO_ROOT/$O/bench.json 2> $GRAFT_REPO_ROOT/$O/stats.err
     find $GRAFT_REPO_ROOT/$O -name "*kernel_trace.csv" -delete; head -25 $GRAFT_REPO_ROOT/$O/stats/s_kernel_stats.csv | cut -c1-160 ;;
+  attn)         # the attention tangent / cotangent kernels standalone, converting vs DMA-fed, bit comparison + times: [binary ...]
+                # (build here first: tests/diag/attn_build.sh [AF_WI bits ...] -> tests/diag/bin/attn_bench[_wi<bits>])
+    bash tests/diag/attn_wi.sh "$@"; cp gpurun_out/attn_wi.log $O/ ;;
   *) grep "^  [a-z_]*)" $0 ;;
 esac

@@ -1064,6 +1064,42 @@ def test_flash_attention_tangent_and_cotangent(prec, which, monkeypatch):
     assert abs(lhs - rhs) / abs(lhs) < tol
 
 
+@pytest.mark.parametrize("which", ["adm64", "ldm40", "ldm80", "if_text"])
+def test_dma_fed_attention_kernels_are_bit_identical_to_the_converting_ones(which, monkeypatch):
+    """Round 5: the attention tangent / cotangent kernels whose operands arrive by LDS-DMA from records split once per launch
+    (attn_flash.hip `attn_flash_dma_kernel` + `attn_split_kernel`, the default) against the kernels that load and convert their
+    operands themselves (LOCO_FLASH_DMA=0): same products in the same order -- J V and J^T U of 3 probes through the engine are
+    the same bits.  Shapes: 64-channel heads at 1024 / 256 tokens, 40- and 80-channel heads (the padded k-steps / the three
+    channel tiles), and the DeepFloyd-IF form with the prompt's text keys ahead of the image keys (MID_IF: 1024 tokens)."""
+    from loco_edit_amd.config import FLASH_ADM, FLASH_LDM, FLASH_LDM80, MID_IF
+    from loco_edit_amd.hip import LocoEngine
+    cfg = {"adm64": FLASH_ADM, "ldm40": FLASH_LDM, "ldm80": FLASH_LDM80, "if_text": MID_IF}[which]
+    params = synth_params(cfg, 0)
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(1, cfg.in_channels, cfg.resolution, cfg.resolution, generator=gen).to(DEV)
+    eng = LocoEngine(cfg, max_batch=4, device=torch.device(DEV))
+    eng.load_state_dict(params)
+    eng.set_precision("bf16x3")
+    if which == "if_text":
+        from loco_edit_amd.tloco import IFTextConditioner
+        states = torch.randn(1, cfg.context_len, cfg.encoder_dim, generator=gen)
+        context, aug = IFTextConditioner(params, cfg, DEV)(states)
+        eng.set_context(context)
+        eng.set_cond(aug)
+    elif cfg.context_dim:
+        eng.set_context(torch.randn(cfg.context_len, cfg.context_dim, generator=gen).to(DEV).contiguous())
+    V = torch.randn(3, eng.n, generator=gen).to(DEV)
+    Uc = torch.randn(3, eng.n_out, generator=gen).to(DEV)
+    eng.pmp_primal(x, 603.0, 0.5, None, use_et=True)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LOCO_FLASH_DMA", mode)
+        res[mode] = (eng.pmp_jvp(V).clone(), eng.pmp_vjp(Uc).clone())
+    assert bool(torch.isfinite(res["1"][0]).all()) and float(res["1"][0].abs().max()) > 0
+    assert torch.equal(res["0"][0], res["1"][0]), float((res["0"][0] - res["1"][0]).abs().max())
+    assert torch.equal(res["0"][1], res["1"][1]), float((res["0"][1] - res["1"][1]).abs().max())
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """The boundary is a C ABI, not a Python extension: tests/c/loco_abi_smoke.c (C11, no torch, no C++) is compiled
     against include/loco_hip.h + libloco_hip.so, creates a context, loads the parameters from host memory, and runs
