@@ -202,6 +202,9 @@ struct loco_ctx {
     std::map<int, FwdGraph> fwd_graphs;
     bool graph_on = false;
     bool gemm_lowp = true;         // LOCO_GEMM_LOWP=0: every attention product on the exact f32-input kernel (A/B timing)
+    // workspace of the record GEMM (gemm_rec.hip: the operands' split records + K-split partial tiles), one per stream lane, grown
+    // on demand outside stream capture
+    unsigned char* gemm_ws[2] = {nullptr, nullptr}; size_t gemm_ws_bytes[2] = {0, 0}; int lane = 0;
     hipStream_t cap_st = nullptr;  // capture stream (the caller's may be the legacy default stream)
     float* xin_buf = nullptr;      // [max_batch][n] fixed graph input
     float* t_dev = nullptr;        // timestep read by the captured time-embedding kernel
@@ -1222,7 +1225,22 @@ struct Pass {
 
 // attention products: exact fp32 MFMA in the f32 mode and for the short / small ones, split-bf16 on the bf16 matrix
 // pipe for the long contractions of the low-precision modes (decoder mid attention at 4096 tokens)
-inline void attn_gemm(const loco_ctx* c, const GemmArgs& g, hipStream_t st) {
+inline unsigned char* gemm_ws_get(loco_ctx* c, size_t need, hipStream_t st) {
+    const int l = c->lane;
+    if (c->gemm_ws_bytes[l] >= need) return c->gemm_ws[l];
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    if (c->gemm_ws[l]) { (void)hipDeviceSynchronize(); (void)hipFree(c->gemm_ws[l]); c->gemm_ws[l] = nullptr; c->gemm_ws_bytes[l] = 0; }
+    void* p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    c->gemm_ws[l] = static_cast<unsigned char*>(p); c->gemm_ws_bytes[l] = need; c->bytes += need;
+    return c->gemm_ws[l];
+}
+inline bool attn_gemm_rec(const loco_ctx* c, const GemmArgs& g) { return c->prec >= 1 && c->gemm_lowp && gemm_rec_eligible(g); }
+inline void attn_gemm(loco_ctx* c, const GemmArgs& g, hipStream_t st) {
+    if (attn_gemm_rec(c, g)) {        // both operands pre-split into records, LDS-DMA fed (gemm_rec.hip)
+        if (unsigned char* ws = gemm_ws_get(c, gemm_rec_ws_bytes(g), st)) { launch_gemm_rec(g, ws, st); return; }
+    }
     if (c->prec >= 1 && c->gemm_lowp && gemm_prefers_bf16x3(g)) launch_gemm_bf16x3(g, st); else launch_gemm(g, st);
 }
 
@@ -2125,7 +2143,10 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
                 // dS = dq^T k + q^T dk and do = dv P^T + v dP^T: one launch per pair (K-concatenation) where the launches
                 // are latency-shaped (T <= 256: 327.7 vs 330.0 ms per headline step); at 1024 tokens two launches with
                 // beta = 1 measured faster (616 vs 639 ms per tloco_if64 step)
-                const bool kcat = T <= 256;
+                // -- and where the record GEMM takes the product (the decoder's 4096-token head): one write of dS instead of a write
+                // and a read-modify-write (500 vs 276 + 586 us, tests/diag/gemm_rec_bench.hip)
+                bool kcat = T <= 256;
+                if (!kcat && !flash) { GemmArgs g2 = g; g2.A2 = q; g2.Bm2 = dk; g2.sbb2 = PS; kcat = attn_gemm_rec(c, g2); }
                 if (kcat) { g.A2 = q; g.sab2 = 0; g.Bm2 = dk; g.sbb2 = PS; }
                 if (!flash) {
                 attn_gemm(c, g, st);
@@ -2530,10 +2551,12 @@ struct LaneSwap {
         c->eps_buf += (long)s0 * c->n_out; c->ge += (long)s0 * c->n_out; c->gx0 += (long)s0 * c->n_in;
         c->partial += partial_floats / 2; c->partial_floats = partial_floats / 2;
         c->red = c->red2;
+        c->lane = 1;
     }
     ~LaneSwap() {
         c->arenaT = arenaT; c->statsT = statsT; c->partial = partial; c->eps_buf = eps_buf; c->ge = ge; c->gx0 = gx0;
         c->red = red; c->partial_floats = partial_floats; c->stpart = stpart; c->attn_delta = attn_delta;
+        c->lane = 0;
     }
 };
 template <typename F>
@@ -2722,6 +2745,7 @@ static void drop_graphs(loco_ctx* c) {
 void loco_destroy(loco_ctx* c) {
     if (!c) return;
     for (float* p : c->owned) (void)hipFree(p);
+    for (unsigned char* p : c->gemm_ws) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

@@ -197,17 +197,23 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g) {
 // [hi k0-7|hi k8-15|lo k0-7|lo k8-15] (piece index XORed with (row>>2)&3: conflict-free ds_read_b128 fragments).
 typedef __bf16 bf16x8_g __attribute__((ext_vector_type(8)));
 
+// hi / lo halves of eight values: ONE v_cvt_pk_bf16_f32 per pair and half (the scalar __bf16 casts compile to a conversion per
+// value plus shift / or packing: 11 vector instructions per pair instead of 6; same roundings, same bits -- conv_bf16_kernel.h cvt2)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    float da = a - ha;
+    asm volatile("" : "+v"(da));
+    const float db = b - hb;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){da, db}, bf16x2_));
+}
 __device__ __forceinline__ void split_piece(const float* v, uint4& hi, uint4& lo) {
-    unsigned h[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 hb = (__bf16)v[j];
-        __bf16 lb = (__bf16)(v[j] - (float)hb);
-        h[j] = __builtin_bit_cast(unsigned short, hb);
-        l[j] = __builtin_bit_cast(unsigned short, lb);
-    }
-    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    split_pair(v[0], v[1], hi.x, lo.x);
+    split_pair(v[2], v[3], hi.y, lo.y);
+    split_pair(v[4], v[5], hi.z, lo.z);
+    split_pair(v[6], v[7], hi.w, lo.w);
 }
 __device__ __forceinline__ int grec(int row, int piece) { return row * 64 + ((piece ^ ((row >> 2) & 3)) << 4); }
 

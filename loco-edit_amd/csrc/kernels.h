@@ -170,6 +170,11 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& g, hipStream_t st);              // exact fp32 (f32-input MFMA)
 void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t st);       // split-bf16 operands on the bf16 matrix pipe
 bool gemm_prefers_bf16x3(const GemmArgs& g);                      // long contraction, matrix-rate bound on the f32 MFMA
+// round 5 (gemm_rec.hip): the same products with both operands pre-split into records and streamed by LDS-DMA; `ws` must hold
+// gemm_rec_ws_bytes(g) bytes (records of the operands + the partial tiles of a K split)
+bool gemm_rec_eligible(const GemmArgs& g);
+size_t gemm_rec_ws_bytes(const GemmArgs& g);
+void launch_gemm_rec(const GemmArgs& g, unsigned char* ws, hipStream_t st);
 
 // ---- tangent / cotangent of multi-head self-attention without per-probe [T x T] matrices (attn_flash.hip) ----
 // All tensors [channel][token] with the engine's strides; q / k / v (and their tangents / cotangents) of head h start
