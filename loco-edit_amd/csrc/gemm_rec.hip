@@ -306,9 +306,8 @@ void launch_rec_tm(const GemmRecArgs& r, hipStream_t st) {
 }  // namespace
 
 bool gemm_rec_eligible(const GemmArgs& g) {
-    static int on = -1;          // LOCO_GEMM_REC=0: the converting 128 x 128 kernel (A/B switch)
-    if (on < 0) { const char* e = getenv("LOCO_GEMM_REC"); on = e ? atoi(e) : 1; }
-    if (!on || g.bias || g.colbias || g.R) return false;
+    const char* e = getenv("LOCO_GEMM_REC");      // LOCO_GEMM_REC=0: the converting 128 x 128 kernel (A/B switch, read per launch)
+    if ((e && atoi(e) == 0) || g.bias || g.colbias || g.R) return false;
     const double macs = (double)g.M * g.N * g.K * (g.A2 ? 2 : 1) * g.batch * (g.batch2 > 0 ? g.batch2 : 1);
     return g.K >= 256 && g.M >= 128 && g.N >= 256 && macs >= 4e9;
 }

@@ -1100,6 +1100,38 @@ def test_dma_fed_attention_kernels_are_bit_identical_to_the_converting_ones(whic
     assert torch.equal(res["0"][1], res["1"][1]), float((res["0"][1] - res["1"][1]).abs().max())
 
 
+def test_record_gemm_matches_the_converting_gemm_on_a_wide_single_head(monkeypatch):
+    """Round 5: the attention products of a single wide head (the latent decoder's 512-channel mid attention is the case that
+    costs: 4096 tokens; here 1024 tokens x 512 channels, 8 probes -- just past the size rule of `gemm_rec_eligible`) on the
+    record GEMM (gemm_rec.hip: operands split once per launch, LDS-DMA fed, the K-heavy value products split over K with a
+    deterministic reduce) against the GEMM that converts its operand panels per workgroup (LOCO_GEMM_REC=0): J V and J^T U
+    agree to the summation order of the K split (the un-split score products are bit-identical, tests/diag/gemm_rec_bench.hip),
+    and the pair stays adjoint."""
+    from loco_edit_amd.config import UNetConfig
+    from loco_edit_amd.hip import LocoEngine
+    cfg = UNetConfig(resolution=32, ch=512, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(32,), gn_eps=1e-5, arch="adm",
+                     num_heads=1, learn_sigma=True)
+    params = synth_params(cfg, 0)
+    gen = torch.Generator().manual_seed(29)
+    x = torch.randn(1, cfg.in_channels, cfg.resolution, cfg.resolution, generator=gen).to(DEV)
+    eng = LocoEngine(cfg, max_batch=8, device=torch.device(DEV))
+    eng.load_state_dict(params)
+    eng.set_precision("bf16x3")
+    V = torch.randn(8, eng.n, generator=gen).to(DEV)
+    Uc = torch.randn(8, eng.n_out, generator=gen).to(DEV)
+    eng.pmp_primal(x, 603.0, 0.5, None, use_et=True)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LOCO_GEMM_REC", mode)
+        res[mode] = (eng.pmp_jvp(V).clone(), eng.pmp_vjp(Uc).clone())
+    e = [rel(res["1"][0], res["0"][0]), rel(res["1"][1], res["0"][1])]
+    print("record GEMM vs converting GEMM, rel-L2 of J V / J^T U:", e)
+    assert bool(torch.isfinite(res["1"][0]).all()) and float(res["1"][0].abs().max()) > 0
+    assert max(e) < 2e-5, e
+    lhs, rhs = (res["1"][0].double() * Uc.double()).sum(), (V.double() * res["1"][1].double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 5e-4
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """The boundary is a C ABI, not a Python extension: tests/c/loco_abi_smoke.c (C11, no torch, no C++) is compiled
     against include/loco_hip.h + libloco_hip.so, creates a context, loads the parameters from host memory, and runs
