@@ -858,7 +858,9 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
 #endif
         }
     };
-    auto stage_regs = [&](const float (&hvs)[NITEM][8], int chunk, unsigned char* Hd) {
+    // whole_tag: the caller has checked that the operator has whole 16-channel chunks (no per-value channel bound)
+    auto stage_regs = [&](const float (&hvs)[NITEM][8], int chunk, unsigned char* Hd, auto whole_tag) {
+        constexpr bool WHOLE = decltype(whole_tag)::value;
         const int c0 = chunk * BKC;
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
@@ -868,7 +870,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
             for (int k = 0; k < 8; ++k) {
                 int c = c0 + ioct[i] * 8 + k;
                 float r = 0.0f;
-                if (ival[i] && c < a.Cin) {
+                if (ival[i] && (WHOLE || c < a.Cin)) {
                     float d = hvs[i][k];
                     if constexpr (MODE == CM_NONE) {
                         r = d;
@@ -899,7 +901,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     };
     auto stage_h = [&](int chunk, int part) {
         if constexpr (!GEN) { stage_hv(hr, part); return; }
-        stage_regs(hv, chunk, Hs);
+        stage_regs(hv, chunk, Hs, std::false_type{});
     };
 
     // MFMA operand fragments of one tap; two sets alternate so the ds_reads of tap t+1 are in flight under the
@@ -1143,6 +1145,10 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         // across the stage barrier.  (A third W / H buffer with the operand fragments read one stage ahead, as in the 3x3
         // loop, measured no better: profiles/r03_experiments.md #10.)
         constexpr int D = DEEP_D;
+        const long plane_bytes = in_plane * 4;
+        unsigned ivoffb[NITEM];
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) ivoffb[i] = ivoff[i] * 4u;
         float hvr[D][NITEM][8];
         f32x4 wr[D][NWV];
         const unsigned char* const wgb = reinterpret_cast<const unsigned char*>(wg);
@@ -1154,20 +1160,26 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
             const bool live = LIVE_MASK ? (chunk_raw <= clast) : true;
             const int chunk = cclamp(chunk_raw);
             const int c0 = chunk * BKC;
+            // Scalar base (one 64-bit product per chunk, then one add per channel plane) + a 32-bit per-lane BYTE offset masked by the
+            // wave-uniform `live`: the stage loop of this kernel is bound by instruction issue, not by the matrix pipe (r05 stamps:
+            // 2.2 k cycles per stage of 12 MFMAs; ~45 of a stage's ~230 instructions were 64-bit address products, ~27 more the
+            // per-load 64-bit vector adds and compare / select pairs of `live ? off : 0`)
+            const unsigned lm = live ? 0xffffffffu : 0u;
+            const unsigned char* pk = reinterpret_cast<const unsigned char*>(inb) + (long)c0 * plane_bytes;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {       // wave-uniform plane base + per-lane 32-bit offset (ivoff holds the octet)
-                const float* pk = inb + (long)(c0 + k) * in_plane;
+            for (int k = 0; k < 8; ++k) {
 #pragma unroll
-                for (int i = 0; i < NITEM; ++i) hvr[sl][i][k] = pk[live ? ivoff[i] : 0u];
+                for (int i = 0; i < NITEM; ++i) hvr[sl][i][k] = *reinterpret_cast<const float*>(pk + (ivoffb[i] & lm));
+                pk += plane_bytes;
             }
             const unsigned char* wbase = wgb + (unsigned)(chunk * TAPS) * ((unsigned)wpitch * (unsigned)RB);
 #pragma unroll
-            for (int i = 0; i < NWV; ++i) wr[sl][i] = *reinterpret_cast<const f32x4*>(wbase + (live ? wrel[i] : 0u));
+            for (int i = 0; i < NWV; ++i) wr[sl][i] = *reinterpret_cast<const f32x4*>(wbase + (wrel[i] & lm));
         };
         auto commit = [&](auto stag, int chunk, unsigned char* Hd, unsigned char* Wd) {
             constexpr int sl = decltype(stag)::value;
             if constexpr (MODE != CM_NONE) load_consts(chunk);
-            stage_regs(hvr[sl], chunk, Hd);
+            stage_regs(hvr[sl], chunk, Hd, std::true_type{});
 #pragma unroll
             for (int i = 0; i < NWV; ++i)
                 if ((WTOT % NTHR) == 0 || tid + i * NTHR < WTOT)
