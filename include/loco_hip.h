@@ -226,6 +226,12 @@ int  loco_set_streams(loco_ctx* ctx, int32_t n);
  * caller's stream and then runs strictly behind it -- same results, no overlap.  The host can measure which of its streams
  * runs beside its current one (loco_edit_amd.tloco.BranchStreams._pick: two spin kernels) and hand that one over. */
 int  loco_set_side_stream(loco_ctx* ctx, void* stream);
+/* n = number of engine contexts whose passes the host enqueues SIDE BY SIDE on different streams (the guidance branches of
+ * T-LOCO: loco_edit_amd.tloco.BranchStreams; reference: the prompts of one batched U-Net call, edit.py:1319-1322).  A launch
+ * then has about 1 / n of the chip, and the split-K choice of the small-image convolutions aims at 256 / n workgroups instead
+ * of 256: fewer partial tiles and less reduce work for the same occupancy (config 5: 315 -> 296 ms per solve at n = 2).
+ * Default 1.  Results change by the summation order of the split only. */
+int  loco_set_chip_share(loco_ctx* ctx, int32_t n);
 int  loco_get_precision(loco_ctx* ctx);
 
 /* Conditional denoisers (T-LOCO, reference edit.py:1286-1373 `self.unet(x, t, encoder_hidden_states=...)`): a

@@ -29,14 +29,22 @@ int conv_bf16_pick_tile(int Cout, int HW, int B) {
 
 // split-K factor for the split-bf16 kernels: splitting costs a partial round trip + a reduce launch, so only
 // split when the un-split grid would leave more than half of the CUs idle
-int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B) {
+int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip_share) {
     const int HW = Hout * Wout;
     int t = conv_bf16_pick_tile(Cout, HW, B);
     static const int MTs[7] = {128, 128, 32, 64, 128, 128, 128}, NTs[7] = {128, 64, 128, 64, 256, 256, 128};
     long blocks = (long)(HW / NTs[t]) * ((Cout + MTs[t] - 1) / MTs[t]) * B;
     int nchunks = (Cin + BKC - 1) / BKC;
-    if (blocks >= 128 || nchunks < 8) return 1;
-    int want = (int)((256 + blocks - 1) / blocks);
+    // Workgroups a launch should reach: one per CU, or one per CU of the launch's SHARE of the chip -- two guidance branches
+    // enqueue their passes side by side on two streams (tloco.BranchStreams -> loco_set_chip_share(ctx, 2)): each launch then
+    // has about half of the chip, and half the splits mean half the partial traffic and reduce work (config 5: 315 -> 296 ms
+    // per solve).  LOCO_SPLITK_TARGET overrides (A/B switch).
+    static int target_env = -1;
+    if (target_env < 0) { const char* e = getenv("LOCO_SPLITK_TARGET"); target_env = e ? atoi(e) : 0; }
+    int target = target_env > 0 ? target_env : 256 / (chip_share > 1 ? chip_share : 1);
+    if (target < 32) target = 32;
+    if (blocks >= target / 2 || nchunks < 8) return 1;
+    int want = (int)((target + blocks - 1) / blocks);
     int maxs = nchunks / 4;
     if (want > maxs) want = maxs;
     if (want > 32) want = 32;

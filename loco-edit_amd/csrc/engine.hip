@@ -205,6 +205,7 @@ struct loco_ctx {
     // workspace of the record GEMM (gemm_rec.hip: the operands' split records + K-split partial tiles), one per stream lane, grown
     // on demand outside stream capture
     unsigned char* gemm_ws[2] = {nullptr, nullptr}; size_t gemm_ws_bytes[2] = {0, 0}; int lane = 0;
+    int chip_share = 1;            // contexts whose passes the host enqueues side by side on other streams (loco_set_chip_share): split-K aims at 256 / share workgroups
     hipStream_t cap_st = nullptr;  // capture stream (the caller's may be the legacy default stream)
     float* xin_buf = nullptr;      // [max_batch][n] fixed graph input
     float* t_dev = nullptr;        // timestep read by the captured time-embedding kernel
@@ -1300,7 +1301,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
         const size_t span = (size_t)c->cfg.max_batch * c->per_sample;
         ConvArgs t = a;
         t.taps = taps;
-        t.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B) : 2;
+        t.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, c->chip_share) : 2;
         t.in_padded = (a.in >= c->arenaP && a.in < c->arenaP + span) || (a.in >= c->arenaT && a.in < c->arenaT + span);
         t.in2 = second->in; t.in2_bs = second->in_bs; t.Cin2 = second->Cin;
         const long per_probe = (long)((a.Hout * a.Wout) / 256) * ((a.Cout + 127) / 128), total = per_probe * a.B;
@@ -1320,7 +1321,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     if (c->prec == 2) a.wb = a.wh;
     a.taps = taps;
     a.no_deep = c->deep1 ? 0 : 1;
-    a.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B)
+    a.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, c->chip_share)
                             : conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
     if (a.nsplit < 1) a.nsplit = 1;
@@ -2364,7 +2365,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                         // a read-modify-write pass of gn_apply_kernel<2> over g_in -- one unsplit launch of whole cout tiles only
                         ConvArgs t = n;
                         t.taps = 1;
-                        t.nsplit = conv_bf16_pick_nsplit(n.Cin, n.Cout, n.Hout, n.Wout, n.B);
+                        t.nsplit = conv_bf16_pick_nsplit(n.Cin, n.Cout, n.Hout, n.Wout, n.B, c->chip_share);
                         const long per_probe = (long)((n.Hout * n.Wout) / conv_bf16_tile_pixels(t)) * ((n.Cout + 127) / 128);
                         const long total = per_probe * n.B, r = total % 256;
                         if (t.nsplit == 1 && (total <= 256 || r == 0 || r > 160) && conv_lowp_can_fuse_stats(t)) {
@@ -3284,6 +3285,12 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
 int loco_set_streams(loco_ctx* c, int32_t n) {
     if (!c || (n != 1 && n != 2)) return -2;
     c->n_streams = n;
+    return 0;
+}
+
+int loco_set_chip_share(loco_ctx* c, int32_t n) {
+    if (!c || n < 1 || n > 8) return -2;
+    c->chip_share = n;
     return 0;
 }
 

@@ -29,7 +29,7 @@ SYMBOLS = [
     "loco_pmp_primal", "loco_pmp_set_second_mask", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
     "loco_convergence", "loco_convergence_rows", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
     "loco_unet_flops", "loco_workspace_bytes", "loco_clock_stamp", "loco_set_side_stream", "loco_timer_start", "loco_timer_stop",
-    "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision", "loco_set_streams",
+    "loco_profile_enable", "loco_profile_report", "loco_set_precision", "loco_get_precision", "loco_set_streams", "loco_set_chip_share",
     "loco_set_cond", "loco_set_context", "loco_lincomb", "loco_masked_axpby", "loco_latent_sample",
 ]
 
@@ -99,6 +99,7 @@ def load_library():
     lib.loco_set_precision.argtypes = [vp, i32]
     lib.loco_get_precision.argtypes = [vp]
     lib.loco_set_streams.argtypes = [vp, i32]
+    lib.loco_set_chip_share.argtypes = [vp, i32]
     lib.loco_set_cond.argtypes = [vp, vp, vp]
     lib.loco_set_context.argtypes = [vp, vp, vp]
     lib.loco_masked_axpby.argtypes = [vp, vp, vp, f32, f32, i32, vp, vp]
@@ -447,6 +448,11 @@ class LocoEngine:
     def set_streams(self, n: int):
         """Probe groups of a tangent / cotangent pass on 1 (default) or 2 HIP streams (identical results)."""
         self._check(self.lib.loco_set_streams(self._ctx, int(n)), "loco_set_streams")
+
+    def set_chip_share(self, n: int):
+        """n engine contexts run their passes side by side on different streams (T-LOCO's guidance branches): split-K then aims
+        at 256 / n workgroups per launch (include/loco_hip.h `loco_set_chip_share`)."""
+        self._check(self.lib.loco_set_chip_share(self._ctx, int(n)), "loco_set_chip_share")
 
     def set_side_stream(self, stream: "Optional[torch.cuda.Stream]"):
         """The second stream of `set_streams(2)`: a stream the caller measured to run BESIDE its current stream (HIP hands

@@ -334,6 +334,12 @@ class EditDeepFloydIF(object):
             self.branches[name] = eng
         self.engine = self.branches["for"]
         self.branch_streams = BranchStreams(len(self.branches), self.device)
+        if self.branch_streams.enabled:
+            # two guidance branches run every J V / J^T U side by side: each engine sizes its split-K for half of the chip
+            # (include/loco_hip.h loco_set_chip_share; LOCO_CFG_SHARE overrides, 1 = off)
+            share = int(os.environ.get("LOCO_CFG_SHARE", "2"))
+            for eng in self.branches.values():
+                eng.set_chip_share(share)
         self._cond_of: Dict[str, int] = {}
         for name, e in (("for", self.for_prompt_emb), ("edit", self.edit_prompt_emb), ("null", self.null_prompt_emb)):
             self._bind(name, e)
