@@ -807,6 +807,36 @@ def test_probe_batching_is_invariant_full_size(k, engines):
 
 
 @pytest.mark.gpu
+def test_chip_share_changes_the_split_k_only(engines):
+    """Round 5 `loco_set_chip_share`: a context whose passes the host runs beside another context's (T-LOCO's guidance branches)
+    sizes its split-K for its share of the chip.  Same operator, fewer K splits at the small-image levels: J V and J^T U agree
+    with the share-1 engine up to the summation order of the split; out-of-range shares are refused."""
+    cfg = CELEBA_DDPM
+    eng = engines(cfg, "bf16x3")
+    s = _sched()
+    t = float(s.timesteps[40]); at = float(s.alpha_at(t))
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=g).to(DEV)
+    eng.pmp_primal(x, t, at, None)
+    V = torch.randn(5, cfg.n, generator=g).to(DEV)
+    Uc = torch.randn(5, cfg.n, generator=g).to(DEV)
+    res = {}
+    try:
+        for share in (1, 2):
+            eng.set_chip_share(share)
+            res[share] = (eng.pmp_jvp(V).clone(), eng.pmp_vjp(Uc).clone())
+        for bad in (0, 9):
+            with pytest.raises(RuntimeError):
+                eng.set_chip_share(bad)
+    finally:
+        eng.set_chip_share(1)
+    for a, b in zip(res[1], res[2]):
+        assert bool(torch.isfinite(b).all())
+        assert rel(b, a) < 1e-5
+    assert not torch.equal(res[1][0], res[2][0])          # (the 16 x 16 / 8 x 8 levels did change their split)
+
+
+@pytest.mark.gpu
 def test_two_stream_probe_groups_match_single_stream(monkeypatch):
     """LOCO_STREAMS=2: the probes of a batch run as two groups on two streams (own arena samples, own scratch);
     J V and J^T U agree with the single-stream engine up to the rounding of batch-dependent split-K factors."""
