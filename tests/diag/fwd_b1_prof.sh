@@ -9,5 +9,5 @@ R=os.environ['GRAFT_REPO_ROOT']
 rows=list(csv.DictReader(open(R+'/gpurun_out/fb1/f_kernel_stats.csv')))
 tot=sum(float(r['TotalDurationNs']) for r in rows); n=sum(int(r['Calls']) for r in rows)
 print(f"kernel time total {tot/1e6:.1f} ms over {n} launches => {tot/1e6/53:.3f} ms per evaluation, {n/53:.0f} launches per evaluation")
-for r in rows[:8]: print(r['Name'][:70], r['Calls'], f"{float(r['TotalDurationNs'])/1e6/53:.3f} ms/eval", f"{float(r['AverageNs'])/1e3:.1f} us")
+for r in rows[:22]: print(r['Name'][:70], r['Calls'], f"{float(r['TotalDurationNs'])/1e6/53:.3f} ms/eval", f"{float(r['AverageNs'])/1e3:.1f} us")
 PY
