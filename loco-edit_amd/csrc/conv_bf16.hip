@@ -63,7 +63,7 @@ static int conv_two_per_cu() {
 // 87.2 -> 81.5; the wide maps at 256^2 are equal or slower (128 -> 256: 159.9 vs 160.6, 256 -> 128: 143.9 vs 150.3).  LOCO_1X1_TILE0_MAXHW
 static int conv_1x1_tile0_maxhw() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("LOCO_1X1_TILE0_MAXHW"); v = e ? atoi(e) : 16384; }      // headline step 290.8 -> 289.2 ms (-0.55 %); 0 = off
+    if (v < 0) { const char* e = getenv("LOCO_1X1_TILE0_MAXHW"); v = e ? atoi(e) : 65536; }      // headline step 290.8 -> 289.2 ms (-0.55 %) up to 128^2; with the stage loop freed of its address arithmetic also at 256^2 (-0.3 %); 0 = off
     return v;
 }
 int bf16_tile_of(const ConvArgs& a) {
