@@ -813,6 +813,21 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         const int c0 = chunk * BKC;
         if (c0 + BKC <= a.Cin) {
             // fast path: all 16 channels exist -> wave-uniform plane base + per-lane 32-bit offset
+            if constexpr (TAPS == 9 && !NEEDP) {
+                // 3x3 operators on the per-pixel path that read one value per element (stride 2, folded upsampling, caller-owned
+                // inputs; raw and forward forms): one 64-bit product per chunk, one add per plane, 32-bit byte offsets masked by the
+                // wave-uniform `pf_live` (see the register-ring loop of the 1x1 operators).  Not in the 1x1 instances (the shared
+                // subexpressions flipped that loop's address form) and not in the tangent / cotangent forms (config 5 +2.5 %)
+                const unsigned lm = pf_live ? 0xffffffffu : 0u;
+                const long pb4 = in_plane * 4;
+                const unsigned char* pk = reinterpret_cast<const unsigned char*>(inb) + (long)c0 * pb4;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                    for (int i = 0; i < NITEM; ++i) hvd[i][k] = *reinterpret_cast<const float*>(pk + ((ivoff[i] * 4u) & lm));
+                    pk += pb4;
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float* pk = inb + (long)(c0 + k) * in_plane;
@@ -822,6 +837,7 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
                     hvd[i][k] = pk[pf_live ? ivoff[i] : 0u];
                     if constexpr (NEEDP) pv[i][k] = sk[pf_live ? ivoff[i] : 0u];
                 }
+            }
             }
         } else {
 #pragma unroll
