@@ -12,10 +12,13 @@ per step: thin QR of V0, 1 primal pass, 12 x (k tangent passes + k cotangent
 passes + Gram/eig re-orthonormalisation).
 
 Workloads (--workload):
-  celeba_top5 (default, the headline): N GPUs = weak scaling -- every rank keeps 5
-      probes (k = 5 N probes of ONE image sharded over ranks, one RCCL all-gather
-      of the A shards per iteration, the k x k algebra replicated); value = 5 N
-      directions / step time.
+  celeba_top5 (default, the headline): N GPUs = N REPLICAS of the metric's unit -- every
+      rank solves the top-5 basis of its own image (5 probes, no data-path collective:
+      what north_star calls natural for k = 5); value = 5 N directions / step time
+      (barrier on both sides, max over ranks).  The ONE-image form (k = 5 N probes of one
+      image sharded over the ranks, one RCCL all-gather of the A shards per iteration)
+      is timed as the extra line `celeba_top5N_one_image_sharded`: a top-5N basis is not
+      N top-5 bases, so it is not the headline (LOCO_BENCH_K_TOTAL forces it: smoke test).
   p2_k64 (BASELINE config 3): FFHQ-P2 architecture, 64 probes sharded over the N
       ranks (strong scaling, 64/N per rank), keep the leading 20 rows; value = 20 /
       step time.  The default run also times one step of it and reports it under
@@ -102,13 +105,14 @@ def launch_ranks(n):
     sys.exit(r.returncode)
 
 
-def synthetic_inputs(cfg, k, device):
+def synthetic_inputs(cfg, k, device, image=0):
+    """`image` > 0: another image and start block (the replicas of a multi-GPU headline run; 0 = the fixture's inputs)."""
     import torch
-    x = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=torch.Generator().manual_seed(1)).to(device)
+    x = torch.randn(1, 3, cfg.resolution, cfg.resolution, generator=torch.Generator().manual_seed(1 + 1000 * image)).to(device)
     mask = torch.zeros(3, cfg.resolution, cfg.resolution, dtype=torch.bool)
     r = cfg.resolution
     mask[:, r * 110 // 256:r * 130 // 256, r * 70 // 256:r * 110 // 256] = True
-    v0 = torch.randn(cfg.n, k, generator=torch.Generator().manual_seed(7)).to(device)
+    v0 = torch.randn(cfg.n, k, generator=torch.Generator().manual_seed(7 + 1000 * image)).to(device)
     return x, mask.to(device), v0
 
 
@@ -478,7 +482,7 @@ def main():
         return dict(cfg=cfg, k=k, keep=k, eng=ed.engine, params=None, step=step, x=z, mask=mask, v0=v0, branches=2, dec=ed.vae_engine,
                     branch_streams=ed.branch_streams.enabled)
 
-    def make_workload(name, prec):
+    def make_workload(name, prec, sharded=False):
         if name == "tloco_if64":
             return make_tloco(prec)
         if name == "tloco_if_i_m":
@@ -487,8 +491,14 @@ def main():
             return make_tloco_sd(prec)
         if name == "tloco_sd15":
             return make_tloco_sd(prec, real=True)
+        replicas = False
         if name == "celeba_top5":
+            # N > 1: N independent top-5 solves, one image per rank (the metric's unit).  `sharded` (the
+            # extra line) or LOCO_BENCH_K_TOTAL: ONE image, k probes dealt over the ranks, one all-gather per iteration
+            replicas = world > 1 and not sharded and not K_TOTAL
             cfg, k, keep = CELEBA_DDPM, K_PER_GPU * world, K_PER_GPU * world
+            if replicas:
+                k = keep = K_PER_GPU
             if K_TOTAL > 0:
                 k = keep = K_TOTAL
         else:
@@ -505,16 +515,18 @@ def main():
         # --streams 2 (LOCO_STREAMS=2 in the package): the two probe groups of a pass on two HIP streams, the side stream
         # chosen by measurement; 1 when no stream of this process runs beside the current one
         n_streams = eng.set_streams_measured(2) if a.streams == 2 else 1
-        x, mask, v0 = synthetic_inputs(cfg, k, device)
+        x, mask, v0 = synthetic_inputs(cfg, k, device, image=rank if replicas else 0)
+        own = ProbeSharder(None) if replicas else None       # a replica's solve never enters a collective
 
         def step(shard=None):
             # the reference's flow (edit.py:2292-2310 min_iter=10) cut at its 12th iteration: the stop test is evaluated
             # where the reference evaluates it (i = 11: one 2-float readback) inside the timed region; with k >= 2 probes
             # it cannot end the loop (solver.default_stop_rule: LAPACK's sign flips, tests/golden/converge.pt)
             return solver.local_basis(eng, x, t, at, k, mask=mask, min_iter=MIN_ITER, max_iter=N_ITER,
-                                      convergence_threshold=1e-4, v0=v0, sharder=shard or sharder, verbose=False,
+                                      convergence_threshold=1e-4, v0=v0, sharder=shard or own or sharder, verbose=False,
                                       stop_rule="reference")
-        return dict(cfg=cfg, k=k, keep=keep, eng=eng, params=params, step=step, x=x, mask=mask, v0=v0, streams=n_streams)
+        return dict(cfg=cfg, k=k, keep=keep, eng=eng, params=params, step=step, x=x, mask=mask, v0=v0, streams=n_streams,
+                    replicas=replicas)
 
     w = make_workload(a.workload, a.precision)
     _mark("workload built")
@@ -528,8 +540,10 @@ def main():
     sclk = LocoEngine.sclk_mhz(ck0, ck1)
     _mark("warm-up + timed steps done")
     ms_per_step = elapsed / a.steps * 1e3
-    value = keep / (elapsed / a.steps)
-    k_local = sharder.rows(k)[1] - sharder.rows(k)[0]
+    replicas = bool(w.get("replicas"))
+    # replicas: every rank kept `keep` directions of its own image in that (max-over-ranks) time
+    value = keep * (world if replicas else 1) / (elapsed / a.steps)
+    k_local = k if replicas else sharder.rows(k)[1] - sharder.rows(k)[0]
 
     # ---- roofline leg: per-kernel HIP-event profile of one more identical step
     roofline = None
@@ -600,7 +614,7 @@ def main():
     # ---- parity leg (outside the timed region): the metric's second half, vT cosine vs the reference
     parity = None
     if a.workload == "celeba_top5" and not SMOKE_ITERS and not K_TOTAL:
-        if world == 1:
+        if world == 1 or replicas:      # (rank 0's replica runs the fixture's inputs)
             ps, pvT = s, vT
         else:   # the k = 5 solve of the fixture, replicated on every rank (no collective), reported by rank 0
             x5, m5, v05 = synthetic_inputs(cfg, K_PER_GPU, device)
@@ -648,6 +662,25 @@ def main():
             extra[other] = {"value": round(keep / (el / 2), 4), "unit": "edit-directions/s", "streams": n_st,
                             "ms_per_step": round(el / 2 * 1e3, 3), "dtype": DTYPE_NOTE[a.precision],
                             "parity": parity_vs_fixture(s2, vT2, "celeba256")}
+        if world > 1 and replicas:
+            # ONE image, 5 N probes dealt over the ranks (one all-gather of the A shards per iteration, replicated k x k algebra):
+            # the form the sharded solver exists for, as an extra line under its own name -- its unit is a row of a top-5N basis
+            try:
+                ws = make_workload("celeba_top5", a.precision, sharded=True)
+                el, (_, ss, vTs, _) = timed(ws["step"], 2, 1)
+                if rank == 0:
+                    kk = ws["k"]
+                    extra["celeba_top5N_one_image_sharded"] = {
+                        "value": round(kk / (el / 2), 4), "unit": f"rows/s of ONE top-{kk} basis (not {world} top-5 bases)",
+                        "ms_per_step": round(el / 2 * 1e3, 3), "scaling": "weak", "n_gpus": world, "probes_total": kk,
+                        "probes_per_gpu": sharder.rows(kk)[1] - sharder.rows(kk)[0], "n_iter": N_ITER,
+                        "collective": "one all-gather of the A shards per iteration (torch.distributed, backend " + backend + ")",
+                        "orthonormality_err": float(f"{float((vTs.double() @ vTs.double().T - torch.eye(kk, device=device, dtype=torch.float64)).abs().max()):.2e}")}
+                del ws
+            except Exception as ex:
+                if rank == 0:
+                    extra["celeba_top5N_one_image_sharded"] = {"error": repr(ex)[:200]}
+            torch.cuda.empty_cache()
         # BASELINE config 5 next to the headline: T-LOCO null-space basis on the DeepFloyd IF-I-M architecture, 2 CFG branches
         try:
             w3 = make_workload("tloco_if_i_m", a.precision)
@@ -756,8 +789,11 @@ def main():
             scaling = "weak"
         elif a.workload == "celeba_top5":
             metric = "edit-directions/sec (top-5 PMP-Jacobian SVD @256^2) + vT cos-sim vs ref"
-            wl = ("CelebA-HQ DDPM 256x256 top-5 local basis (l_eye-sized mask, L=2400), t=0.6T, 12 power iterations, "
-                  "probes sharded 5 per GPU")
+            wl = ("CelebA-HQ DDPM 256x256 top-5 local basis (l_eye-sized mask, L=2400), t=0.6T, 12 power iterations, " +
+                  ("one GPU" if world == 1 else
+                   f"{world} REPLICAS: every rank solves the top-5 basis of its own image (5 probes per GPU, no data-path collective; "
+                   "the one-image 5N-probe sharded solve is extra_workloads.celeba_top5N_one_image_sharded)" if replicas else
+                   f"ONE image, {k} probes SHARDED over the {world} ranks (one all-gather per iteration): a top-{k} basis, smoke knob"))
             scaling = "weak"
         else:
             metric = "edit-directions/sec (rank-20 of 64 probes, FFHQ-P2 @256^2)"
@@ -771,7 +807,9 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": DTYPE_NOTE[a.precision], "data": "synthetic",
             "smoke": ({"iters": SMOKE_ITERS, "k_total": K_TOTAL} if (SMOKE_ITERS or K_TOTAL) else None),
-            "config": {"workload": wl, "probes_total": k, "probes_per_gpu": k_local, "kept": keep, "n_iter": int(n_iter),
+            "config": {"workload": wl, "multi_gpu_form": ("single" if world == 1 else "replicas" if replicas else "sharded"),
+                       "probes_total": k * (world if replicas else 1), "probes_per_gpu": k_local, "kept": keep * (world if replicas else 1),
+                       "n_iter": int(n_iter),
                        "mask_L": int(w["mask"].sum().item()), "weights": "synthetic seed 0",
                        **({"streams": w["streams"]} if "streams" in w else {}),
                        "convergence_check": ("executed inside the timed region as in the reference flow (min_iter=10, max_iter=12: "
@@ -779,6 +817,10 @@ def main():
                                              else "min_iter == max_iter == 12")},
             "singular_values": [round(float(v), 4) for v in s.tolist()[:5]],
             "parity": parity, "roofline": roofline,
+            # whole image (a5 -> a11) at the headline's 12 iterations per solve and under the CLI's default stop rule
+            # (LOCO_STOP_RULE=reference: five-probe solves run max_iter = 50, as the reference's own loop does)
+            "image_total_s": (e2e or {}).get("image_total_s"),
+            "image_total_reference_stop_rule_s": (e2e or {}).get("image_total_reference_stop_rule_s"),
             **({"cfg_branch_streams": "the CFG branches (one engine context per prompt) run side by side on two HIP streams "
                 "(LOCO_CFG_STREAMS=0: one after the other); kernels of the two branches overlap, so this workload's per-kernel "
                 "averages are durations under overlap, not isolated kernel times"} if w.get("branch_streams") else {}), "cpu_baseline": cpu, "e2e": e2e, "extra_workloads": extra or None,
@@ -786,8 +828,8 @@ def main():
                       "method": "(d s_memtime / d s_memrealtime) x 100 MHz between two one-lane stamps around the timed steps "
                                 "(loco_clock_stamp); rank 0's GPU; the chip's maximum is 2400 MHz"},
             "distinct_gpus": n_distinct_gpus,
-            # the headline scales WEAKLY (5 probes per rank: a wider basis of the same image); the line the north-star
-            # ">= 6x at 8 GPUs" is about is the STRONG-scaling 64-probe workload of the same run:
+            # the headline scales WEAKLY (N replicas: one top-5 solve per rank, each on its own image); the line the
+            # north-star ">= 6x at 8 GPUs" is about is the STRONG-scaling 64-probe workload of the same run:
             "strong_scaling": ({"workload": "p2_k64 (FFHQ-P2 256^2, 64 probes sharded, keep 20)", "value": extra["p2_k64"]["value"],
                                 "unit": "edit-directions/s", "n_gpus": world, "ms_per_step": extra["p2_k64"]["ms_per_step"],
                                 "ideal_speedup_vs_1gpu": extra["p2_k64"]["ideal_speedup_vs_1gpu"],

@@ -96,7 +96,7 @@ bool conv_lowp_can_kcat(const ConvArgs& a) {
 // the epilogue statistics exist on the LDS-staged path of whole cout tiles (conv_bf16_kernel.h) and need the finished
 // sums, i.e. no split-K
 bool conv_lowp_can_fuse_stats(const ConvArgs& a) {
-    return a.nsplit <= 1 && (a.Cout % conv_bf16_tile_couts(a)) == 0;
+    return a.nsplit <= 1 && !a.gemm && (a.Cout % conv_bf16_tile_couts(a)) == 0;      // (the DMA-fed GEMM's epilogue takes none)
 }
 
 template <int PR, int MODE> void launch_kcat_b(const ConvArgs& a, hipStream_t st);   // conv_bf16_inst_*.hip
@@ -196,6 +196,11 @@ bool conv_gemm_plan(ConvArgs& a) {
     if (!on || a.stride != 1 || a.upsample || a.zins || (a.Cin % BKC) != 0 || a.Cin < 320 || (HW % 256) != 0 || (a.Wout % 16) != 0 ||
         a.Cout < 128 || !a.partial || a.Cin2 > 0 || !(a.mode == CM_NONE || a.mode == CM_GN))
         return false;
+    {   // the kernel's 256-pixel tile is TW = min(Wout, 32) columns x 256 / TW rows: both must divide the map (a 48 x 48 map passes
+        // the tests above and would be walked out of bounds: ADVICE r05)
+        const int TW = a.Wout < 32 ? a.Wout : 32;
+        if ((256 % TW) != 0 || (a.Wout % TW) != 0 || (a.Hout % (256 / TW)) != 0) return false;
+    }
     // Where it pays (tests/diag/gemm_check.py, 5 probes, us per launch old -> new incl. the split pass): the split pass costs 8 bytes
     // per input element, so the map must have many cout tiles to spread it over (320 -> 2560 @64^2 190 -> 150, 640 -> 5120 @32^2
     // 180 -> 121, 1280 -> 10240 @16^2 164 -> 104) or be one of the K-heavy, pixel-poor maps the per-pixel kernel runs at 64 - 118

@@ -122,6 +122,30 @@ constexpr int max_halo(int NT, int taps, bool s2) {
     return s2 ? 5 * 65 : 4 * 34;
 }
 
+// Sums of N values per lane over groups of LW consecutive lanes by recursive halving (a reduce-scatter, then a plain butterfly for
+// what is left): step M pairs lane l with l ^ M, each keeps one half of its values and adds the partner's -- N - 1 + log2(LW / N)
+// shuffles instead of N log2(LW) (the epilogue statistics: 32 sums of a 128 x 256 tile over 64 lanes in 32 shuffles, not 192).
+// Afterwards lane l holds, in av[0 .. rs_left), the group totals of the values i + sum_b bit_b(l) (N >> (b + 1)), b < rs_steps.
+constexpr int rs_steps(int n, int lw) { int s = 0; while ((1 << s) < lw && (n >> s) > 1) ++s; return s; }
+template <int N, int M, int LW>
+__device__ __forceinline__ void rs_reduce(float* av, const int lane) {
+    if constexpr (M < LW && N > 1) {
+        constexpr int H = N / 2;
+        const bool up = (lane & M) != 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const float keep = up ? av[i + H] : av[i];
+            const float send = up ? av[i] : av[i + H];
+            av[i] = keep + __shfl_xor(send, M, 64);
+        }
+        rs_reduce<H, M * 2, LW>(av, lane);
+    } else if constexpr (M < LW) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) av[i] += __shfl_xor(av[i], M, 64);
+        rs_reduce<N, M * 2, LW>(av, lane);
+    }
+}
+
 // Epilogue of the low-precision conv kernel: the WM x WN waves (threads 0 .. WM*WN*64-1) write their accumulator tiles.
 // D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 template <int WM, int WN, int TM, int TN>
@@ -156,6 +180,25 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
         const float* const b1 = part ? nullptr : a.bias;
         const bool accu = !part && a.accumulate;
         const int twsh = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
+        // Tangent / cotangent group means of the finished tile (round 6, below): the primal x of the output tensor under the WHOLE
+        // tile is requested here, ahead of the write-out rounds (4 bytes per element, shared by the probes of the tile on one XCD:
+        // served by its L2), and the sums are formed after the last round's stores -- the loads' latency runs under the write-out
+        const bool lin_st = (a.st_kind == ST_TAN || a.st_kind == ST_COT) && !part;
+        constexpr int NV = 2 * TM * NTASK;                 // row sums per lane: {s1, s2} per (round, task)
+        f32x4 xs[TM][NTASK];
+        float av[NV];
+        if (lin_st) {
+#pragma unroll
+            for (int h = 0; h < TM; ++h)
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    const int t = q * NTHR + tid;
+                    const int row = t / NQ, p = (t & (NQ - 1)) * 4;
+                    const int co = co0 + ((row >> 5) * TM + h) * 32 + (row & 31);
+                    const unsigned o = (unsigned)co * (unsigned)out_plane + (unsigned)((oy0 + (p >> twsh)) * a.Wout + ox0 + (p & (TW - 1)));
+                    xs[h][q] = *reinterpret_cast<const f32x4*>(a.st_x + o);
+                }
+        }
 #pragma unroll
         for (int h = 0; h < TM; ++h) {
             if (h > 0) {                                   // the previous round's read-back is done in every wave
@@ -226,12 +269,40 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
                 v[q] += add;
                 __builtin_nontemporal_store(v[q], reinterpret_cast<f32x4*>(ob + off[q]));   // streamed once: keep L2 for the shared primal cache / weights
             }
+            if (lin_st) {      // the lane's share of the round's row sums (see behind the round loop); x was requested before round 0
+                const bool cot = a.st_kind == ST_COT;
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    const f32x4 vv = v[q], xv = xs[h][q];
+                    float s1, s2;
+                    if (!cot) {
+                        s1 = (vv[0] + vv[1]) + (vv[2] + vv[3]);
+                        s2 = fmaf(xv[0], vv[0], xv[1] * vv[1]) + fmaf(xv[2], vv[2], xv[3] * vv[3]);
+                    } else {
+                        const int co = cos_[q], g = co / a.st_cpg;
+                        const float scc = a.st_sc[co], shc = a.st_sh[co];
+                        const float mean = a.st_mr[2 * g], rstd = a.st_mr[2 * g + 1];
+                        const float gm = scc / rstd;
+                        s1 = 0.f; s2 = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float y = fmaf(scc, xv[j], shc);
+                            const float sg = sigmoidf2_(y);
+                            const float z = gm * (sg * (1.0f + y * (1.0f - sg))) * vv[j];      // SiLU networks only (run_conv)
+                            s1 += z;
+                            s2 = fmaf((xv[j] - mean) * rstd, z, s2);
+                        }
+                    }
+                    av[(h * NTASK + q) * 2] = s1;
+                    av[(h * NTASK + q) * 2 + 1] = s2;
+                }
+            }
             // Forward GroupNorm statistics of the finished tile for the norm that consumes this tensor (kernels.h
             // ConvArgs::st_part): the NQ lanes of a task row hold one cout over the tile's NT pixels; sums about a pivot
             // inside the row's data (its first value in this tile: no cancellation of sum x^2 - n mean^2 when |mean| >> std),
-            // butterfly over the row's lanes, one lane writes {mean, M2} of the row tile.  (The tangent / cotangent means
-            // were tried here too: they need the {S, xhat} records of the output tile, 8 more bytes per element read in the
-            // latency-exposed epilogue -- 9-26 us per launch against the 16-21 us of the standalone pass, not adopted.)
+            // butterfly over the row's lanes, one lane writes {mean, M2} of the row tile.  (The tangent / cotangent means:
+            // behind the round loop.  Round 4 tried them here from the {S, xhat} records of the output tile -- 8 more bytes per
+            // element read in the latency-exposed round, 9-26 us per launch against the 16-21 us of the standalone pass.)
             if (a.st_kind == ST_FWD && !part) {
                 const int ntile = (a.Hout * a.Wout) / NT;
                 float* const sp = a.st_part + (long)b * a.Cout * ntile * 2;
@@ -250,6 +321,33 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
                     const int t = q * NTHR + tid;
                     if ((t & (NQ - 1)) == 0)
                         *reinterpret_cast<f32x2*>(sp + ((long)cos_[q] * ntile + tile_id) * 2) = f32x2{pivot + m, s2 - s1 * m};
+                }
+            }
+        }
+        // Tangent / cotangent group means of the finished tile for the norm that consumes this tensor (round 6; kernels.h
+        // ConvArgs::st_part).  Tangent: raw {sum d, sum x d} per cout row (norm-independent: gn_lin_fused_finalize forms
+        // mean(xhat d) = rstd (sum x d - mean sum d) / n in double); cotangent: {sum z, sum xhat z} with the consuming norm's
+        // constants, as gn_tstats_partial<1> computes them.  Replaces that kernel's pass over the tensor (reference op: the
+        // GroupNorm inside jvp / vjp, models/ddpm/diffusion.py:810-811 under edit.py:2455,2479).  Every round left the lane's share
+        // of its row sums in av[]; all 2 x TM x NTASK of them go through ONE recursive-halving reduction over the row's NQ lanes.
+        if (lin_st) {
+            constexpr int LW = NQ < 64 ? NQ : 64, STEPS = rs_steps(NV, LW), LEFT = NV >> STEPS;
+            static_assert((NV & (NV - 1)) == 0, "row sums per lane");
+            rs_reduce<NV, 1, LW>(av, lane);
+            const int gl = lane & (LW - 1);
+            if (gl < (1 << STEPS)) {
+                int base = 0;
+#pragma unroll
+                for (int sb = 0; sb < STEPS; ++sb) base += ((gl >> sb) & 1) * (NV >> (sb + 1));
+                const int ntile = (a.Hout * a.Wout) / NT;
+                float* const sp = a.st_part + (long)b * a.Cout * ntile * 2;
+#pragma unroll
+                for (int i = 0; i < LEFT; ++i) {
+                    const int idx = base + i, hq = idx >> 1;
+                    const int h = hq / NTASK, q = hq - h * NTASK;
+                    const int row = (q * NTHR + tid) / NQ;
+                    const int co = co0 + ((row >> 5) * TM + h) * 32 + (row & 31);
+                    sp[((long)co * ntile + tile_id) * 2 + (idx & 1)] = av[i];
                 }
             }
         }
@@ -948,13 +1046,21 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             f.ah[i] = *reinterpret_cast<const s16x8*>(Ws + tp * MT * RB + aoff_hi[i]);
+#if defined(LOCO_WI_NOLO)
+            if constexpr (NLO) f.al[i] = f.ah[i];      // what-if build (WRONG results): half of the operand fragment reads
+#else
             if constexpr (NLO) f.al[i] = *reinterpret_cast<const s16x8*>(Ws + tp * MT * RB + aoff_lo[i]);
+#endif
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const unsigned char* hp = Hs + tapoff * HP + hbyte[j];     // uniform tap shift + per-lane record base
             f.bh[j] = *reinterpret_cast<const s16x8*>(hp);
+#if defined(LOCO_WI_NOLO)
+            if constexpr (NLO) f.bl[j] = f.bh[j];
+#else
             if constexpr (NLO) f.bl[j] = *reinterpret_cast<const s16x8*>(hp + 32);
+#endif
         }
     };
     auto mma_frag = [&](const Frag& f) {
@@ -983,6 +1089,30 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         } else {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, f.ah[i]), al = __builtin_bit_cast(bf16x8, f.al[i]);
             const bf16x8 bh = __builtin_bit_cast(bf16x8, f.bh[j]), bl = __builtin_bit_cast(bf16x8, f.bl[j]);
+#if defined(LOCO_WI_MFMA16)
+            // what-if build (profiles/r06_experiments.md: WRONG results, timing only): every 32x32x16 MFMA as two 16x16x32 MFMAs of
+            // the same operand registers (same matrix-pipe cycles, same register traffic) -- what the MFMA SHAPE does to the
+            // clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 7)
+            {
+                f32x4 q0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, q1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
+                f32x4 q2 = {acc[i][j][8], acc[i][j][9], acc[i][j][10], acc[i][j][11]}, q3 = {acc[i][j][12], acc[i][j][13], acc[i][j][14], acc[i][j][15]};
+                q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, q0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, q1, 0, 0, 0);
+                q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, q2, 0, 0, 0);
+                q3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, q3, 0, 0, 0);
+                q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, q0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, q1, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[i][j][r] = q0[r]; acc[i][j][4 + r] = q1[r]; acc[i][j][8 + r] = q2[r]; acc[i][j][12 + r] = q3[r]; }
+                return;
+            }
+#elif defined(LOCO_WI_2MFMA)
+            // what-if build (WRONG results): two of the three MFMAs per product -- the slope of the launch time in the MFMA count
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+            (void)al;
+            return;
+#endif
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);

@@ -205,6 +205,8 @@ struct loco_ctx {
     // workspace of the record GEMM (gemm_rec.hip: the operands' split records + K-split partial tiles), one per stream lane, grown
     // on demand outside stream capture
     unsigned char* gemm_ws[2] = {nullptr, nullptr}; size_t gemm_ws_bytes[2] = {0, 0}; int lane = 0;
+    bool fuse_lin = true;          // tangent / cotangent group means taken in the conv epilogues (LOCO_FUSE_LIN=0: standalone passes)
+    int lane_s0 = 0;               // first sample of the lane being enqueued (run_lanes): where its rows of a kept partial buffer start
     int chip_share = 1;            // contexts whose passes the host enqueues side by side on other streams (loco_set_chip_share): split-K aims at 256 / share workgroups
     hipStream_t cap_st = nullptr;  // capture stream (the caller's may be the legacy default stream)
     float* xin_buf = nullptr;      // [max_batch][n] fixed graph input
@@ -1226,12 +1228,28 @@ struct Pass {
 
 // attention products: exact fp32 MFMA in the f32 mode and for the short / small ones, split-bf16 on the bf16 matrix
 // pipe for the long contractions of the low-precision modes (decoder mid attention at 4096 tokens)
+// the captured forward graphs (LOCO_GRAPH=1) hold raw pointers: dropped whenever a buffer they may name is replaced
+static void drop_graphs(loco_ctx* c) {
+    for (auto& kv : c->fwd_graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    c->fwd_graphs.clear();
+}
 inline unsigned char* gemm_ws_get(loco_ctx* c, size_t need, hipStream_t st) {
     const int l = c->lane;
     if (c->gemm_ws_bytes[l] >= need) return c->gemm_ws[l];
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    if (c->gemm_ws[l]) { (void)hipDeviceSynchronize(); (void)hipFree(c->gemm_ws[l]); c->gemm_ws[l] = nullptr; c->gemm_ws_bytes[l] = 0; }
+    if (c->gemm_ws[l]) {
+        // a captured forward graph (LOCO_GRAPH=1) may hold this pointer: the graphs go before the buffer does;
+        // the context's byte count follows the buffer it replaces
+        (void)hipDeviceSynchronize();
+        drop_graphs(c);
+        (void)hipFree(c->gemm_ws[l]);
+        c->bytes -= c->gemm_ws_bytes[l];
+        c->gemm_ws[l] = nullptr; c->gemm_ws_bytes[l] = 0;
+    }
     void* p = nullptr;
     if (hipMalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     c->gemm_ws[l] = static_cast<unsigned char*>(p); c->gemm_ws_bytes[l] = need; c->bytes += need;
@@ -1374,6 +1392,23 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
             if (kept) *rq->keep_ntile = ntile;
             return rq->n ? 1 : 4;
         }
+        // Tangent / cotangent group means in the conv epilogue (round 6, LOCO_FUSE_LIN=0: off): whole cout tiles, no split-K, not the
+        // opt-in persistent / dual-probe kernels (their epilogues take the forward statistics only).  A tangent launch that finishes
+        // one part of a concatenation keeps its (norm-independent) raw sums in the part's buffer, at this lane's samples.
+        if ((rq->kind == ST_TAN || (rq->kind == ST_COT && c->cfg.act == ACT_SILU)) && c->fuse_lin && conv_lowp_can_fuse_stats(x) &&
+            !x.pers_groups && !conv_dual_ok(x)) {      // (the cotangent form is written for SiLU, as ConvArgs::cot_d)
+            const size_t lane_off = (size_t)c->lane_s0 * x.Cout * ntile * 2;
+            const bool keptl = rq->kind == ST_TAN && rq->keep && s0 == 0 && x.B == a.B && lane_off + need <= rq->keep_floats;
+            if (keptl || (rq->n && need <= c->stpart_floats)) {
+                x.st_part = keptl ? rq->keep + lane_off : c->stpart; x.st_kind = rq->kind; x.st_x = rq->prim;
+                if (rq->kind == ST_COT) {
+                    NS sp = nstats(c, c->statsP, *rq->n);
+                    x.st_sc = sp.sc; x.st_sh = sp.sh; x.st_mr = sp.mr; x.st_cpg = rq->n->C / Gn;
+                }
+                if (keptl) *rq->keep_ntile = ntile;
+                return rq->n ? 1 : 4;
+            }
+        }
         return rq->n ? 3 : 0;
     };
     auto stats_after = [&](const ConvArgs& x, int s0, int how) {
@@ -1381,6 +1416,12 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
         const NormP& n = *rq->n;
         if (how == 3) { stats_standalone(c, *rq, x.out, x.out_bs, x.B, HWo, s0, st); return; }
         NS so = nstats(c, rq->stats + (long)s0 * SBs, n);
+        if (rq->kind != ST_FWD) {
+            NS sp = nstats(c, c->statsP, n);
+            launch_gn_lin_fused_finalize(rq->kind, x.st_part, n.C, HWo / conv_bf16_tile_pixels(x), nullptr, 0, x.B, n.C, HWo, Gn,
+                                         sp.mr, so.tst, so.tc, SBs, st);
+            return;
+        }
         launch_gn_fused_finalize(x.st_part, HWo / conv_bf16_tile_pixels(x), x.B, n.C, HWo, Gn, eps_of(c, n), n.gamma, n.beta,
                                  so.mr, so.sc, so.sh, SBs, rq->ss_scale, rq->ss_shift, st);
     };
@@ -1430,9 +1471,11 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     if (!tail_probes) { one(a, 0); return; }
     // tail-probe split: two launches finish the tensor.  Tangent / cotangent statistics are taken once over the whole batch
     // behind them (separate statistics for the few tail probes would add a reduce-with-statistics and a finalize launch per
-    // conv).  FORWARD statistics are per sample and come for free with both launches: the main launch's epilogue partials
-    // (+ one merge launch for its samples), the tail's split-K epilogue -- no pass over the finished tensor.
-    const bool per_part = want && rq && rq->kind == ST_FWD && rq->n;
+    // conv: LOCO_FUSE_LIN=0).  FORWARD statistics are per sample and come for free with both launches: the main launch's epilogue
+    // partials (+ one merge launch for its samples), the tail's split-K epilogue -- no pass over the finished tensor.
+    // (round 6: the tangent / cotangent means likewise -- they are per probe too: the main launch's epilogue partials + one merge
+    // launch, the tail's split-K epilogue)
+    const bool per_part = want && rq && rq->n && (rq->kind == ST_FWD || (c->fuse_lin && HWo % 4 == 0));
     const StatReq* rq_all = (!per_part && rq && rq->kind != ST_NONE && rq->n) ? rq : nullptr;
     if (rq && rq->keep_ntile) *rq->keep_ntile = 0;
     if (!per_part) rq = nullptr;
@@ -1502,6 +1545,22 @@ bool cat_fused_stats(loco_ctx* c, const NormP& n, int tid, float* stats, int B, 
     NS s = nstats(c, stats, n);
     launch_gn_fused_finalize_cat(A.keep, A.C, A.keep_ntile, Bt.keep, Bt.keep_ntile, B, q.C, q.H * q.W, c->cfg.gn_groups,
                                  eps_of(c, n), n.gamma, n.beta, s.mr, s.sc, s.sh, c->stats_per_sample, st);
+    return true;
+}
+
+// the tangent group means of a norm over a concatenation whose two producers both kept their raw {sum d, sum x d} tile partials
+// in this pass (run_conv, ST_TAN): finalised from those instead of a pass over the concatenation (round 6)
+bool cat_fused_tstats(loco_ctx* c, const NormP& n, int tid, int B, hipStream_t st) {
+    const Tens& q = c->tens[tid];
+    if (q.cat_a < 0 || c->prec < 1 || !c->fuse_stats || !c->fuse_lin) return false;
+    const Tens& A = c->tens[q.cat_a];
+    const Tens& Bt = c->tens[q.cat_b];
+    if (A.keep_ntile <= 0 || Bt.keep_ntile <= 0) return false;
+    NS sp = nstats(c, c->statsP, n);
+    NS stt = nstats(c, c->statsT, n);
+    launch_gn_lin_fused_finalize(ST_TAN, A.keep + (size_t)c->lane_s0 * A.C * A.keep_ntile * 2, A.C, A.keep_ntile,
+                                 Bt.keep + (size_t)c->lane_s0 * Bt.C * Bt.keep_ntile * 2, Bt.keep_ntile, B, q.C, q.H * q.W,
+                                 c->cfg.gn_groups, sp.mr, stt.tst, stt.tc, c->stats_per_sample, st);
     return true;
 }
 
@@ -2037,7 +2096,16 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
     auto TT = [&](int id) { return c->arenaT + c->tens[id].off; };   // tangent
     clear_ready(c);
     // tangent group means for the norm that consumes tensor `tid`, delivered with the conv that finishes it
-    auto next_tan = [&](int tid) { return req_lin(c, ST_TAN, consumer_norm(c, tid), TP(tid)); };
+    // (+ the kept raw partials of a concatenation part: the up-path norm over torch.cat([h, skip]) is finalised from both parts')
+    auto next_tan = [&](int tid) {
+        StatReq r = req_lin(c, ST_TAN, consumer_norm(c, tid), TP(tid));
+        Tens& t = c->tens[tid];
+        if (t.cat_of >= 0 && t.keep && c->fuse_lin) {
+            r.kind = ST_TAN; r.stats = c->statsT; r.prim = TP(tid);
+            r.keep = t.keep; r.keep_floats = t.keep_floats; r.keep_ntile = &t.keep_ntile;
+        }
+        return r;
+    };
     for (auto& op : c->ops) {
         const Tens& to = c->tens[op.out];
         const int HW = to.H * to.W;
@@ -2066,7 +2134,7 @@ int tangent_pass(loco_ctx* c, const float* V, int B, hipStream_t st) {
             case OP_RES: {
                 const Tens& ti = c->tens[op.in];
                 const int HWi = ti.H * ti.W;
-                if (!op.n1.ready) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HWi, B, st);
+                if (!op.n1.ready && !cat_fused_tstats(c, op.n1, op.in, B, st)) tangent_stats(c, op.n1, TT(op.in), PS, TP(op.in), HWi, B, st);
                 op.n1.ready = false;
                 ConvArgs a; conv_defaults(a);
                 a.Cin = ti.C;
@@ -2552,12 +2620,12 @@ struct LaneSwap {
         c->eps_buf += (long)s0 * c->n_out; c->ge += (long)s0 * c->n_out; c->gx0 += (long)s0 * c->n_in;
         c->partial += partial_floats / 2; c->partial_floats = partial_floats / 2;
         c->red = c->red2;
-        c->lane = 1;
+        c->lane = 1; c->lane_s0 = s0;
     }
     ~LaneSwap() {
         c->arenaT = arenaT; c->statsT = statsT; c->partial = partial; c->eps_buf = eps_buf; c->ge = ge; c->gx0 = gx0;
         c->red = red; c->partial_floats = partial_floats; c->stpart = stpart; c->attn_delta = attn_delta;
-        c->lane = 0;
+        c->lane = 0; c->lane_s0 = 0;
     }
 };
 template <typename F>
@@ -2678,6 +2746,8 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
             }
         const char* e = getenv("LOCO_FUSE_STATS");
         c->fuse_stats = !(e && atoi(e) == 0);
+        e = getenv("LOCO_FUSE_LIN");
+        c->fuse_lin = !(e && atoi(e) == 0);
         e = getenv("LOCO_FUSE_COT");
         c->fuse_cot = !(e && atoi(e) == 0) && cfg->act == ACT_SILU;     // the epilogue term is written for SiLU
         e = getenv("LOCO_DEEP1");
@@ -2735,13 +2805,6 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
     return 0;
 }
 
-static void drop_graphs(loco_ctx* c) {
-    for (auto& kv : c->fwd_graphs) {
-        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-    }
-    c->fwd_graphs.clear();
-}
 
 void loco_destroy(loco_ctx* c) {
     if (!c) return;
@@ -3224,20 +3287,24 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
         in_e > c->sx_total) { c->err = "bench_conv: shape exceeds the arenas"; return -2; }
     float* in = c->arenaT;
     float* out = c->arenaT + in_e * B;
-    launch_fill_random(in, in_e * B, 1u, 1.0f, st);
-    launch_fill_random(c->arenaP, in_e, 2u, 1.0f, st);
-    launch_fill_random(reinterpret_cast<float*>(c->sxcache), 2 * in_e, 3u, 1.0f, st);
+    // LOCO_BENCH_ZERO (bit 1: activations, bit 2: weights): all-zero operands draw less power in the matrix pipe -- the time
+    // against random data says how much of a launch the chip's clock management decides (MI355X_MICROARCH.md, DVFS give-back)
+    const int bz = getenv("LOCO_BENCH_ZERO") ? atoi(getenv("LOCO_BENCH_ZERO")) : 0;
+    const float zs = (bz & 1) ? 0.0f : 1.0f, zw = (bz & 2) ? 0.0f : 1.0f;
+    launch_fill_random(in, in_e * B, 1u, zs, st);
+    launch_fill_random(c->arenaP, in_e, 2u, zs, st);
+    launch_fill_random(reinterpret_cast<float*>(c->sxcache), 2 * in_e, 3u, zs, st);
     launch_fill_random(c->statsP, c->stats_per_sample, 4u, 1.0f, st);
     launch_fill_random(c->statsT, c->stats_per_sample * B, 5u, 0.01f, st);
     // weights: any conv of matching size is fine for timing; synthesise records in the split-K workspace
     size_t wfl = (size_t)((cin + 15) / 16) * 16 * taps * ((cout + 31) & ~31);
     if (wfl * 2 > c->partial_floats) { c->err = "bench_conv: weights exceed workspace"; return -2; }
     float* wf = c->partial + c->partial_floats - wfl * 2;
-    launch_fill_random(wf, (long)wfl * 2, 6u, 0.05f, st);
+    launch_fill_random(wf, (long)wfl * 2, 6u, 0.05f * zw, st);
     if (c->prec == 1) {      // split-bf16 records: well-formed ones
         const long nrec = (long)((cin + 15) / 16) * taps * ((cout + 31) & ~31);
         hipLaunchKernelGGL(diag_fill_records, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<unsigned char*>(wf), nrec, (cout + 31) & ~31, 7u, 0.05f);
+                           reinterpret_cast<unsigned char*>(wf), nrec, (cout + 31) & ~31, 7u, 0.05f * zw);
     }
     ConvArgs a; conv_defaults(a);
     a.in = in; a.in_bs = in_e; a.Cin = cin; a.Hin = H; a.Win = W;

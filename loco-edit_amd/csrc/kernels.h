@@ -88,8 +88,15 @@ struct ConvArgs {
     int no_deep;     // 1: the 1x1 per-pixel variants keep the two-buffer stage loop (A/B switch of the register ring)
     float* partial;
     int B;
-    // forward-statistics sink (st_kind == ST_FWD): {mean, M2} per (cout row, pixel tile), [B][Cout][pixel tiles][2]
+    // statistics sink of the conv epilogue, [B][Cout][pixel tiles][2] per (cout row, pixel tile) of the FINISHED tensor:
+    //   st_kind == ST_FWD: {mean, M2};
+    //   ST_TAN (round 6): the RAW sums {sum d, sum x d} with x = st_x, the primal of the output tensor (B = 1) -- independent of
+    //       the norm, so one set of partials serves the next block's norm AND the up-path norm over a concatenation;
+    //   ST_COT (round 6): {sum z, sum xhat z}, z = (sc / rstd) act'(sc x + sh) d, with the consuming norm's per-channel
+    //       st_sc / st_sh and per-group {mean, rstd} st_mr (st_cpg channels per group).
+    // Merged per (sample, group) by launch_gn_fused_finalize (FWD) / launch_gn_lin_fused_finalize (TAN, COT).
     float* st_part; int st_kind;
+    const float* st_x; const float* st_sc; const float* st_sh; const float* st_mr; int st_cpg;
     // K-concatenated second operator (conv_bf16_kernel.h conv_lowp_kcat): a 1x1 conv of the RAW tensor in2 [B][Cin2][Hout][Wout]
     // accumulated into the same output tile; its bias travels in `bias2` (bias2_bs = 0).  Cin2 == 0: none.
     const float* in2; long in2_bs; int Cin2; int in2_padded;
@@ -240,6 +247,12 @@ void launch_gn_fused_finalize_cat(const float* partA, int C1, int ntA, const flo
 void launch_gn_fused_finalize(const float* part, int ntile, int B, int C, int HW, int G, float eps, const float* gamma,
                               const float* beta, float* mr, float* sc, float* sh, long stats_bs, const float* ss_scale,
                               const float* ss_shift, hipStream_t st);
+// row-tile partials of a conv epilogue in the tangent / cotangent kinds (ConvArgs::st_part, kind ST_TAN: raw {sum d, sum x d},
+// ST_COT: {sum z, sum xhat z}) -> tst[b][g] = {m1, m2} and its per-channel expansion tc, as launch_gn_tstats writes them.  The
+// channels [0, C1) come from partA (ntA tiles per row), the channels [C1, C) of a concatenation from partB (ntB tiles; nullptr:
+// C1 == C).  mr: the primal {mean, rstd} per group of the consuming norm.
+void launch_gn_lin_fused_finalize(int kind, const float* partA, int C1, int ntA, const float* partB, int ntB, int B, int C, int HW,
+                                  int G, const float* mr, float* tst, float* tc, long tst_bs, hipStream_t st);
 // split-K epilogue (sum of the K-slabs + bias / bias2 / residual / accumulate, as launch_conv_splitk_reduce) that also takes
 // the statistics of the finished tensor and finalises them: replaces the reduce AND the statistics launch behind a split-K conv
 void launch_conv_splitk_reduce_stats(const ConvArgs& a, int kind, int G, float eps, const float* gamma, const float* beta,

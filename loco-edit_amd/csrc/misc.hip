@@ -333,6 +333,54 @@ __global__ __launch_bounds__(64) void gn_fused_finalize_cat_kernel(const float* 
         sh[(long)b * sbs + c] = beta[c] - meanf * rstd * gm;
     }
 }
+// Tangent / cotangent group means from the row-tile partials of a conv epilogue (ConvArgs::st_part, kinds ST_TAN / ST_COT; round
+// 6): one wave per (sample, group) sums the cpg x ntile entries of its group in double and writes what gn_tstats_partial /
+// gn_tstats_finalize write.  Tangent partials are the raw {sum d, sum x d}: mean(xhat d) = rstd (sum x d - mean sum d) / n with the
+// primal {mean, rstd} of the consuming norm; cotangent partials are {sum z, sum xhat z} already.  Channels >= C1 of a
+// concatenation come from the second producer's partials (tangent kind: raw sums do not depend on the norm).
+__global__ __launch_bounds__(64) void gn_lin_fused_finalize_kernel(int kind, const float* partA, int C1, int ntA,
+                                                                   const float* partB, int ntB, int C, int G, double inv_n,
+                                                                   const float* mr, float* tst, float* tc, long tbs) {
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / G, C2 = C - C1;
+    const float2* pa = reinterpret_cast<const float2*>(partA) + (long)b * C1 * ntA;
+    const float2* pb = partB ? reinterpret_cast<const float2*>(partB) + (long)b * C2 * ntB : nullptr;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+        const int c = g * cpg + k;
+        const float2* p = c < C1 ? pa + (long)c * ntA : pb + (long)(c - C1) * ntB;
+        const int nt = c < C1 ? ntA : ntB;
+        for (int i = threadIdx.x; i < nt; i += 64) { const float2 v = p[i]; s1 += (double)v.x; s2 += (double)v.y; }
+    }
+    s1 = __shfl(wave_sum(s1), 0, 64);
+    s2 = __shfl(wave_sum(s2), 0, 64);
+    const float mean = mr[2 * g], rstd = mr[2 * g + 1];
+    float m1, m2;
+    if (kind == ST_TAN) {
+        m1 = (float)(s1 * inv_n);
+        m2 = (float)((double)rstd * (s2 - (double)mean * s1) * inv_n);
+    } else {
+        m1 = (float)(s1 * inv_n);
+        m2 = (float)(s2 * inv_n);
+    }
+    if (threadIdx.x == 0) {
+        float* o = tst + (long)b * tbs + 2 * g;
+        o[0] = m1;
+        o[1] = m2;
+    }
+    if (tc) {      // per-channel expansion for the split-bf16 conv staging; the cotangent form carries rstd
+        const float f = kind == ST_TAN ? 1.0f : rstd;
+        for (int k = threadIdx.x; k < cpg; k += 64) {
+            float* t = tc + (long)b * tbs + 2 * ((long)g * cpg + k);
+            t[0] = f * m1;
+            t[1] = f * m2;
+        }
+    }
+}
+void launch_gn_lin_fused_finalize(int kind, const float* partA, int C1, int ntA, const float* partB, int ntB, int B, int C, int HW,
+                                  int G, const float* mr, float* tst, float* tc, long tst_bs, hipStream_t st) {
+    hipLaunchKernelGGL(gn_lin_fused_finalize_kernel, dim3(G, B), dim3(64), 0, st, kind, partA, C1, ntA, partB, ntB, C, G,
+                       1.0 / ((double)(C / G) * HW), mr, tst, tc, tst_bs);
+}
 void launch_gn_fused_finalize_cat(const float* partA, int C1, int ntA, const float* partB, int ntB, int B, int C, int HW, int G,
                                   float eps, const float* gamma, const float* beta, float* mr, float* sc, float* sh,
                                   long stats_bs, hipStream_t st) {

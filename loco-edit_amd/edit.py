@@ -220,7 +220,7 @@ class EditUncondDiffusion(object):
             xT = self.run_DDIMinversion(idx=idx)
         xt, t, t_idx = self.DDIMforwardsteps(xT, t_start_idx=0, t_end_idx=self.edit_t_idx)
         assert t_idx == self.edit_t_idx
-        print('!!!LOAD VT FROM VT_PATH!!!')
+        print('loading the basis from --vT_path')
         vT_list = [self._load(self.vT_path), self._load(self.vT1_path)]
         BASIS_NAME = "load-basis-2"
         xt_temp = xt.detach().clone()
@@ -261,7 +261,7 @@ class EditUncondDiffusion(object):
             raise FileNotFoundError(
                 f"{mpath} missing: SAM mask generation is outside the hot path (SURVEY.md 2.1 #9); "
                 "provide mask.pt (bool [N,res,res]) as the reference's mask_segmentation.py writes it")
-        print("Loading masks......")
+        print("loading masks")
         masks = torch.load(mpath)
         if self.args.sampling_mode:
             return None, None
@@ -282,7 +282,7 @@ class EditUncondDiffusion(object):
         assert t_idx == self.edit_t_idx
 
         if not self._exists(self.vT_path):
-            print('!!!CALCULATING VT!!!')
+            print('computing the local basis')
             tag = self.args.choose_sem if self.dataset_name in ("CelebA_HQ_mask", "Synthetic") else self.args.mask_index
             save_dir = os.path.join(self.result_folder, "basis", f'local_basis-{self.edit_t}T-select-mask-{tag}')
             os.makedirs(save_dir, exist_ok=True)
@@ -293,7 +293,7 @@ class EditUncondDiffusion(object):
             have_m, have_n = self._exists(vT_modify_path), self._exists(vT_null_path)
             if null_space_projection and mask is not None and not have_m and not have_n and self.pair_solves:
                 # both bases are missing: one pass carries the probes of both solves (solver.local_basis_pair)
-                print('!!!RUN LOCAL PULLBACK FOR EDIR SPACE AND NULL SPACE (shared probe batches)!!!')
+                print('subspace solves: modify space + null space (shared probe batches)')
                 at = self.scheduler.alpha_at(t)
                 (u_modify, s_modify, vT_modify, self.last_n_iter), (u_null, s_null, vT_null, self.last_n_iter_null) = \
                     solver.local_basis_pair(self.engine, xt.to(self.device, torch.float32), float(t), at, pca_rank, mask,
@@ -304,7 +304,7 @@ class EditUncondDiffusion(object):
             elif have_m:
                 vT_modify = self._load(vT_modify_path, map_location=self.device).to(self.device).type(self.dtype)
             else:
-                print('!!!RUN LOCAL PULLBACK FOR EDIR SPACE!!!')
+                print('subspace solve: modify space')
                 u_modify, s_modify, vT_modify = self.local_encoder_decoder_pullback_xt(
                     x=xt, t=t, op=op, block_idx=block_idx, pca_rank=pca_rank,
                     min_iter=10, max_iter=50, convergence_threshold=1e-4, mask=mask, noise=encoder_decoder_by_et)
@@ -315,7 +315,7 @@ class EditUncondDiffusion(object):
             elif null_space_projection and self._exists(vT_null_path):
                 vT_null = self._load(vT_null_path, map_location=self.device).to(self.device).type(self.dtype)
             elif null_space_projection:
-                print('!!!RUN LOCAL PULLBACK FOR NULL SPACE!!!')
+                print('subspace solve: null space')
                 u_null, s_null, vT_null = self.local_encoder_decoder_pullback_xt(
                     x=xt, t=t, op=op, block_idx=block_idx, pca_rank=pca_rank_null,
                     min_iter=10, max_iter=50, convergence_threshold=1e-4, mask=~mask, noise=encoder_decoder_by_et)
@@ -337,7 +337,7 @@ class EditUncondDiffusion(object):
                 self.EXP_NAME = f'{idx}-Edit_xt-noise-{BASIS_NAME}-pc_{pc_idx:0=3d}'
                 self._save(vT[[pc_idx], :], os.path.join(save_dir, f'{self.EXP_NAME}-vT.pt'))
         else:
-            print('!!!LOAD VT FROM VT_PATH!!!')
+            print('loading the basis from --vT_path')
             vT = self._load(self.vT_path).to(self.device, torch.float32)
             BASIS_NAME = f"edit_{self.edit_t}T-load-basis-'{os.path.basename(self.vT_path)}'"
 

@@ -578,7 +578,7 @@ class EditDeepFloydIF(object):
             vT_modify = self._load(paths["vm"], map_location=self.device).to(self.device).type(self.dtype)
             vT_null = self._load(paths["vn"], map_location=self.device).to(self.device).type(self.dtype)
         else:
-            print('!!!RUN LOCAL PULLBACK!!!')
+            print('subspace solve: CFG-combined Jacobian')
             u_modify, s_modify, vT_modify = self.local_encoder_decoder_pullback_xt(
                 xt, t, t_idx, F, E, N, op=op, block_idx=block_idx, pca_rank=pca_rank, chunk_size=5, min_iter=10, max_iter=50,
                 convergence_threshold=1e-3, mask=mask, mode="null+(for-null)")
@@ -627,7 +627,7 @@ class EditDeepFloydIF(object):
                 vT_modify = self.get_v_modify(xt, t, t_idx, F, E, N, mask=mask, mode=self.tilda_v_score_type, jacobian=jacobian)
                 vT_null = None
                 if null_space_projection:
-                    print('!!!RUN LOCAL PULLBACK!!!')
+                    print('subspace solve: CFG-combined Jacobian')
                     _, _, vT_null = self.local_encoder_decoder_pullback_xt(
                         xt, t, t_idx, F, E, N, op=op, block_idx=block_idx, pca_rank=pca_rank_null, chunk_size=5, min_iter=10,
                         max_iter=50, convergence_threshold=1e-3, mask=~mask, mode="null+(for-null)")
@@ -641,7 +641,7 @@ class EditDeepFloydIF(object):
                     if self.sharder.is_main:
                         torch.save(vT[[pc_idx], :], os.path.join(save_dir, f'{self.EXP_NAME}-vT.pt'))
             else:
-                print('!!!LOAD VT FROM VT_PATH!!!')
+                print('loading the basis from --vT_path')
                 vT = self._load(self.vT_path).to(self.device, torch.float32)
                 BASIS_NAME = f"load-basis-'{os.path.basename(self.vT_path)}'"
             original_xt = xt.clone()

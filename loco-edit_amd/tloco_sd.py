@@ -348,7 +348,7 @@ class EditStableDiffusion(EditDeepFloydIF):
             vT_modify = self._load(paths["vm"], map_location=self.device).to(self.device).type(self.dtype)
             vT_null = self._load(paths["vn"], map_location=self.device).to(self.device).type(self.dtype)
         else:
-            print('!!!RUN LOCAL PULLBACK!!!')
+            print('subspace solve: CFG-combined Jacobian')
             u_modify, vT_modify = modify_fn()
             if self.sharder.is_main:
                 if u_modify is not None:

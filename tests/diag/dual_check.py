@@ -2,7 +2,7 @@
 one U^T J of B samples / probes at 256 x 256 in a child process per setting of a 0 / 1 environment switch (default
 LOCO_CONV_DUAL; also LOCO_TSTATS_PB) and compares the outputs (same products in the same order: expected difference exactly 0).
       python3 tests/diag/dual_check.py [B] [cfg] [ENV_NAME]"""
-import os, subprocess, sys
+import os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
@@ -35,11 +35,13 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else "CELEBA_DDPM"
 ENVN = sys.argv[3] if len(sys.argv) > 3 else "LOCO_CONV_DUAL"      # the 0 / 1 switch under test
 res = {}
 SETTINGS = ("0", "1") if os.environ.get("DUAL_CHECK_SKIP_REPEAT") else ("0", "0b", "1")      # "0b": the default twice (run-to-run)
+TMP = tempfile.mkdtemp(prefix="dual_check_")      # private to this run: concurrent runs must not read each other's files
 for v in SETTINGS:
-    out = f"/tmp/dual_check_{v}.pt"
+    out = os.path.join(TMP, f"{v}.pt")
     env = dict(os.environ, **{ENVN: (os.environ.get("DUAL_CHECK_ON", "1") if v[0] == "1" else "0")})      # DUAL_CHECK_ON: the value that means `on`
     subprocess.run([sys.executable, os.path.abspath(__file__), "--child", B, cfg, out], check=True, env=env)
     res[v] = torch.load(out)
+shutil.rmtree(TMP, ignore_errors=True)
 for k in (res["0"] if "0b" in res else ()):
     print(f"{k}: run-to-run difference of the 128 x 256 tile itself: {(res['0'][k] - res['0b'][k]).abs().max().item():.3e}")
 ok = True

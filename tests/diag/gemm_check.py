@@ -26,10 +26,13 @@ import torch
 B = sys.argv[1] if len(sys.argv) > 1 else "5"
 MODE = sys.argv[2] if len(sys.argv) > 2 else "0"      # 0 raw input, 2 GroupNorm affine (attention norm -> q, k, v)
 out = {}
+import shutil, tempfile
+TMP = tempfile.mkdtemp(prefix="gemm_check_")      # private to this run
 for v in ("0", "1"):
-    f = f"/tmp/gemm_check_{v}.pt"
+    f = os.path.join(TMP, f"{v}.pt")
     subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f, B, MODE], check=True, env=dict(os.environ, LOCO_CONV_GEMM=v))
     out[v] = torch.load(f)
+shutil.rmtree(TMP, ignore_errors=True)
 for k in out["0"]:
     (u0, a), (u1, b) = out["0"][k], out["1"][k]
     same = torch.equal(a.view(torch.int32), b.view(torch.int32))

@@ -16,6 +16,8 @@ kern = sys.argv[5] if len(sys.argv) > 5 else "conv_"
 out = os.path.join(ROOT, "gpurun_out", tag)
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp", LOCO_HIP_LIB=os.path.join(ROOT, "loco-edit_amd", "libloco_hip_diag.so"))
+if not os.path.exists(env["LOCO_HIP_LIB"]):      # (make -C loco-edit_amd/csrc diag; the library must travel with the snapshot)
+    sys.exit("pmc_conv_mem.py: " + env["LOCO_HIP_LIB"] + " is missing: nothing would be collected")
 
 lst = subprocess.run(["rocprofv3", "-L"], capture_output=True, text=True, cwd="/tmp", env=env)
 open(os.path.join(out, "rocprofv3_L.txt"), "w").write(lst.stdout + lst.stderr)
@@ -93,3 +95,5 @@ with open(os.path.join(out, f"conv3x3_tan_pmc_mem_{prec}.csv"), "w") as f:
         f.write(f"{k},{res[k][0]:.6g},{res[k][1]}\n")
     f.write("# not offered by rocprofv3 -L on this box: " + " ".join(missing) + "\n")
 print(open(os.path.join(out, f"conv3x3_tan_pmc_mem_{prec}.csv")).read())
+if not res:
+    sys.exit("pmc_conv_mem.py: no counter was collected (see the *.err files under " + out + ")")

@@ -727,6 +727,31 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["probes_total"] == 5 and d["config"]["probes_per_gpu"] == 3 and d["value"] > 0
     assert d["smoke"] == {"iters": 3, "k_total": 5} and d["config"]["n_iter"] == 3
     assert d["roofline"] is not None and d["cpu_baseline"] is None and d["parity"] is None
+    assert d["config"]["multi_gpu_form"] == "sharded" and "SHARDED" in d["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_headline_is_two_replicas_of_the_metrics_unit():
+    """`bench.py --gpus 2` without the k-total knob: the headline is the metric's own unit times two -- every rank solves the
+    top-5 basis of its own image (no data-path collective), value = 10 directions / step time -- and says so in
+    `config.workload` / `config.multi_gpu_form` (a top-10 basis is not two top-5 bases).  Two ranks on the one
+    GPU over gloo, 2 iterations (smoke knob), no extra workloads."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LOCO_BENCH_BACKEND="gloo", LOCO_BENCH_MAX_BATCH="8", LOCO_BENCH_SMOKE_ITERS="2")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--no-extra", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["multi_gpu_form"] == "replicas" and "REPLICAS" in c["workload"]
+    assert c["probes_total"] == 10 and c["probes_per_gpu"] == 5 and c["kept"] == 10
+    assert abs(d["value"] - 10.0 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    assert d["scaling"] == "weak" and len(d["singular_values"]) == 5
 
 
 @pytest.mark.gpu
@@ -1000,6 +1025,21 @@ def _fused_cfgs():
 @pytest.mark.parametrize("cfg", _fused_cfgs(), ids=["tiny", "mid", "tiny_adm", "celeba256", "tiny_adm_xattn", "tiny_latent_xattn",
                                                     "tiny_decoder"])
 def test_statistics_fused_into_epilogues_equal_the_standalone_kernels(cfg, monkeypatch):
+    _fused_vs_standalone(cfg, "LOCO_FUSE_STATS", monkeypatch)
+
+
+@pytest.mark.parametrize("cfg", _fused_cfgs()[:4], ids=["tiny", "mid", "tiny_adm", "celeba256"])
+def test_tangent_and_cotangent_means_fused_into_conv_epilogues_equal_the_standalone_kernels(cfg, monkeypatch):
+    """Round 6: the tangent / cotangent group means of un-split convs with whole cout tiles come from the conv epilogue (raw
+    {sum d, sum x d} / {sum z, sum xhat z} per cout row and pixel tile, merged by gn_lin_fused_finalize; the up-path norms over
+    torch.cat([h, skip]) from both producers' kept partials) instead of gn_tstats_partial's pass over the tensor;
+    LOCO_FUSE_LIN=0 runs the standalone kernels.  Forward outputs are the same bits (the switch does not touch them)."""
+    errs, outs = _fused_vs_standalone(cfg, "LOCO_FUSE_LIN", monkeypatch)
+    for i in (0, 1, 6, 7):
+        assert torch.equal(outs["1"][i], outs["0"][i])
+
+
+def _fused_vs_standalone(cfg, envname, monkeypatch):
     """The GroupNorm statistics a conv's consumer needs (forward mean / rstd, tangent and cotangent group means) are taken
     in the split-K epilogue (one kernel instead of reduce + statistics) or, the forward ones of un-split convs, in the
     conv epilogue (engine.hip run_conv / StatReq); LOCO_FUSE_STATS=0 runs every one of them as its own kernels.  Same
@@ -1016,7 +1056,7 @@ def test_statistics_fused_into_epilogues_equal_the_standalone_kernels(cfg, monke
     ctx = torch.randn(cfg.context_len, cfg.context_dim, generator=gen).to(DEV) if cfg.context_dim else None
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("LOCO_FUSE_STATS", mode)
+        monkeypatch.setenv(envname, mode)
         eng = LocoEngine(cfg, max_batch=8, device=torch.device(DEV))
         eng.load_state_dict(synth_params(cfg, 0))
         if ctx is not None:
@@ -1043,6 +1083,7 @@ def test_statistics_fused_into_epilogues_equal_the_standalone_kernels(cfg, monke
     print("fused vs standalone statistics, rel-L2 per output:", [f"{e:.1e}" for e in errs])
     assert all(bool(torch.isfinite(a).all()) for a in out["1"])
     assert max(errs[:6]) < 3e-5 and max(errs[6:]) < 3e-3, errs
+    return errs, out
 
 
 @pytest.mark.parametrize("which", ["adm64", "ldm40", "ldm80"])
