@@ -54,9 +54,13 @@ int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip
 // A/B switch (default off): the big-image 3x3 convs on 128 x 128 tiles of four waves in the compact LDS layout (STG 3 of
 // conv_bf16_kernel.h, 81 920 B), two workgroups per CU, instead of one 128 x 256 workgroup of eight waves
 static int conv_two_per_cu() {
+#ifdef LOCO_DIAG
     static int v = -1;
     if (v < 0) { const char* e = getenv("LOCO_CONV_2WG"); v = e ? (atoi(e) != 0) : 0; }
     return v;
+#else
+    return 0;      // the compact two-workgroups-per-CU tile is compiled into the diagnostics build only (`make diag`)
+#endif
 }
 // 1x1 operators up to this many pixels run the 128 x 128 tile of four waves (two workgroups per CU: one's write-out under the
 // other's K loop) instead of 128 x 256: r05, 5 probes: 256 -> 256 @128^2 74.7 -> 63.5 us, 512 -> 512 @64^2 73.2 -> 64.7, 128 -> 128 @256^2
@@ -107,6 +111,9 @@ template <int PR, int MODE> void launch_dual_b(const ConvArgs& a, hipStream_t st
 // LOCO_DUAL_MIN_UNITS: fewest dual units (pixel tiles x cout tiles x probe pairs) a launch must have -- below ~3/4 of the CUs
 // the wider tile leaves too much of the chip idle (the 128 x 128 level of the headline: 64 tiles x 2 pairs).
 static int conv_dual_min_units() {
+#ifndef LOCO_DIAG
+    return -1;      // the dual-probe tile is compiled into the diagnostics build only (`make diag`)
+#endif
     static int v = -2;
     if (v == -2) {
         const char* e = getenv("LOCO_CONV_DUAL");
@@ -162,9 +169,12 @@ void launch_conv_gemm(const ConvArgs& a, hipStream_t st);      // conv_bf16_inst
 bool conv_pers_plan(ConvArgs& a) {
     // Opt-in (LOCO_CONV_PERS=1: raw / forward forms, 2: every form): measured neutral to slightly negative in the flow (r05:
     // headline 299.4 vs 300.2 ms, 25-frame decode step 44.1 -> 45.0 ms) although the isolated raw / forward launches gain 5 %
+    a.pers_groups = 0;
+#ifndef LOCO_DIAG
+    return false;      // the persistent form is compiled into the diagnostics build only (`make diag`)
+#endif
     static int on = -1;
     if (on < 0) { const char* e = getenv("LOCO_CONV_PERS"); on = e ? (atoi(e) != 0) : 0; }
-    a.pers_groups = 0;
     if (!on || a.taps != 9 || a.Cin2 > 0 || a.nsplit != 1 || a.stride != 1 || a.upsample || a.zins || a.pad != 1 || !a.in_padded ||
         (a.Cin % (2 * BKC)) != 0 || (a.Cout % 128) != 0 || a.B < 2 || a.cot_d || bf16_tile_of(a) != 5)
         return false;
@@ -247,6 +257,7 @@ static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
         else launch_kcat_b<PR, CM_TAN_SILU>(a, st);
         return;
     }
+#ifdef LOCO_DIAG
     if constexpr (PR == PR_BF16X3) {
         if (taps == 9 && a.dual) {           // conv_lowp_plan checked conv_dual_ok
             switch (a.mode) {
@@ -258,6 +269,7 @@ static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
             return;
         }
     }
+#endif
     if (taps == 9) {
         switch (a.mode) {
             case CM_NONE: launch_tile_b<PR, 9, CM_NONE>(a, st); break;

@@ -180,25 +180,26 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
         const float* const b1 = part ? nullptr : a.bias;
         const bool accu = !part && a.accumulate;
         const int twsh = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
-        // Tangent / cotangent group means of the finished tile (round 6, below): the primal x of the output tensor under the WHOLE
-        // tile is requested here, ahead of the write-out rounds (4 bytes per element, shared by the probes of the tile on one XCD:
-        // served by its L2), and the sums are formed after the last round's stores -- the loads' latency runs under the write-out
+        // Tangent / cotangent group means of the finished tile (round 6, below): what they need of the primal under the round's rows
+        // -- tangent: x of the output tensor (4 bytes per element); cotangent: the consuming norm's cached {S, xhat} records (8
+        // bytes: no transcendental per element here) -- is requested at the top of each round, ahead of its LDS round trip, residual
+        // loads and stores (shared by the probes of the tile on one XCD: served by its L2), and used after the round's stores
         const bool lin_st = (a.st_kind == ST_TAN || a.st_kind == ST_COT) && !part;
+        const bool lin_cot = a.st_kind == ST_COT;
+        // Task q of a round = staging row q * RSTEP + row0, pixels 4 * quad0 ... + 3: the lane's (row0, quad0) are fixed, the task
+        // adds a compile-time row count -- cout and tensor offset of a task are one per-lane base plus a wave-uniform term (scalar
+        // arithmetic), not per-task registers held across the round
+        constexpr int RSTEP = NTHR / NQ;
+        static_assert(NTHR % NQ == 0 && 32 % RSTEP == 0, "epilogue task rows");
+        const int row0 = tid / NQ, quad0 = tid & (NQ - 1);
+        const unsigned pix0 = (unsigned)((oy0 + ((quad0 * 4) >> twsh)) * a.Wout + ox0 + ((quad0 * 4) & (TW - 1)));
+        auto co_of = [&](int h, int q) -> int { return co0 + row0 + (((q * RSTEP) >> 5) * TM + h) * 32 + ((q * RSTEP) & 31); };
+        auto off_of = [&](int h, int q) -> unsigned {
+            const unsigned crow = (unsigned)((((q * RSTEP) >> 5) * TM + h) * 32 + ((q * RSTEP) & 31));      // compile-time after unrolling
+            return (unsigned)(co0 + row0) * (unsigned)out_plane + pix0 + crow * (unsigned)out_plane;
+        };
         constexpr int NV = 2 * TM * NTASK;                 // row sums per lane: {s1, s2} per (round, task)
-        f32x4 xs[TM][NTASK];
         float av[NV];
-        if (lin_st) {
-#pragma unroll
-            for (int h = 0; h < TM; ++h)
-#pragma unroll
-                for (int q = 0; q < NTASK; ++q) {
-                    const int t = q * NTHR + tid;
-                    const int row = t / NQ, p = (t & (NQ - 1)) * 4;
-                    const int co = co0 + ((row >> 5) * TM + h) * 32 + (row & 31);
-                    const unsigned o = (unsigned)co * (unsigned)out_plane + (unsigned)((oy0 + (p >> twsh)) * a.Wout + ox0 + (p & (TW - 1)));
-                    xs[h][q] = *reinterpret_cast<const f32x4*>(a.st_x + o);
-                }
-        }
 #pragma unroll
         for (int h = 0; h < TM; ++h) {
             if (h > 0) {                                   // the previous round's read-back is done in every wave
@@ -210,28 +211,32 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     S[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * NT + (wn * TN + j) * 32 + l31] = acc[h][j][r];
+            // (requested here: the round's accumulator registers are free, the loads fly under the LDS round trip)
+            f32x4 xs[NTASK][2];                            // tangent: [q][0] = x of 4 pixels; cotangent: {S0,x0,S1,x1}, {S2,x2,S3,x3}
+            if (lin_st) {
+#pragma unroll
+                for (int q = 0; q < NTASK; ++q) {
+                    const unsigned o = off_of(h, q);
+                    if (lin_cot) {
+                        const f32x4* sp4 = reinterpret_cast<const f32x4*>(a.st_sx + o);
+                        xs[q][0] = sp4[0];
+                        xs[q][1] = sp4[1];
+                    } else {
+                        xs[q][0] = *reinterpret_cast<const f32x4*>(a.st_x + o);
+                    }
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             f32x4 v[NTASK], rv[NTASK];
-            unsigned off[NTASK];                        // element offset inside one sample's tensor (< 2^31)
-            int cos_[NTASK];
 #pragma unroll
-            for (int q = 0; q < NTASK; ++q) {
-                const int t = q * NTHR + tid;
-                const int row = t / NQ, quad = t & (NQ - 1);
-                v[q] = *reinterpret_cast<const f32x4*>(&S[row * NT + quad * 4]);
-                const int co = co0 + ((row >> 5) * TM + h) * 32 + (row & 31);
-                const int p = quad * 4;
-                const int ty = p >> twsh, tx = p & (TW - 1);
-                cos_[q] = co;
-                off[q] = (unsigned)co * (unsigned)out_plane + (unsigned)((oy0 + ty) * a.Wout + ox0 + tx);
-            }
+            for (int q = 0; q < NTASK; ++q) v[q] = *reinterpret_cast<const f32x4*>(&S[(q * RSTEP + row0) * NT + quad0 * 4]);
             if (rb || accu) {
 #pragma unroll
                 for (int q = 0; q < NTASK; ++q) {
                     f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
-                    if (rb) t4 = a.res_scale * *reinterpret_cast<const f32x4*>(rb + off[q]);
-                    if (accu) t4 += *reinterpret_cast<const f32x4*>(ob + off[q]);
+                    if (rb) t4 = a.res_scale * *reinterpret_cast<const f32x4*>(rb + off_of(h, q));
+                    if (accu) t4 += *reinterpret_cast<const f32x4*>(ob + off_of(h, q));
                     rv[q] = t4;
                 }
 #pragma unroll
@@ -244,12 +249,12 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
                 const float* const tb = a.cot_tst + (long)b * a.cot_tst_bs;
 #pragma unroll
                 for (int q = 0; q < NTASK; ++q) {
-                    const int co = cos_[q], g = co / a.cot_cpg;
+                    const int co = co_of(h, q), g = co / a.cot_cpg;
                     const float scc = a.cot_sc[co], shc = a.cot_sh[co];
                     const float mean = a.cot_mr[2 * g], rstd = a.cot_mr[2 * g + 1];
                     const float m1 = tb[2 * g], m2 = tb[2 * g + 1];
-                    const f32x4 dv = *reinterpret_cast<const f32x4*>(db + off[q]);
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.cot_x + off[q]);
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(db + off_of(h, q));
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.cot_x + off_of(h, q));
                     const float gm = scc / rstd;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -264,34 +269,24 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
 #pragma unroll
             for (int q = 0; q < NTASK; ++q) {
                 float add = 0.f;
-                if (b1) add += b1[cos_[q]];
-                if (b2) add += b2[cos_[q]];
+                if (b1) add += b1[co_of(h, q)];
+                if (b2) add += b2[co_of(h, q)];
                 v[q] += add;
-                __builtin_nontemporal_store(v[q], reinterpret_cast<f32x4*>(ob + off[q]));   // streamed once: keep L2 for the shared primal cache / weights
+                __builtin_nontemporal_store(v[q], reinterpret_cast<f32x4*>(ob + off_of(h, q)));   // streamed once: keep L2 for the shared primal cache / weights
             }
-            if (lin_st) {      // the lane's share of the round's row sums (see behind the round loop); x was requested before round 0
-                const bool cot = a.st_kind == ST_COT;
+            if (lin_st) {      // the lane's share of the round's row sums (see behind the round loop)
 #pragma unroll
                 for (int q = 0; q < NTASK; ++q) {
-                    const f32x4 vv = v[q], xv = xs[h][q];
+                    const f32x4 vv = v[q];
                     float s1, s2;
-                    if (!cot) {
+                    if (!lin_cot) {
+                        const f32x4 xv = xs[q][0];
                         s1 = (vv[0] + vv[1]) + (vv[2] + vv[3]);
                         s2 = fmaf(xv[0], vv[0], xv[1] * vv[1]) + fmaf(xv[2], vv[2], xv[3] * vv[3]);
-                    } else {
-                        const int co = cos_[q], g = co / a.st_cpg;
-                        const float scc = a.st_sc[co], shc = a.st_sh[co];
-                        const float mean = a.st_mr[2 * g], rstd = a.st_mr[2 * g + 1];
-                        const float gm = scc / rstd;
-                        s1 = 0.f; s2 = 0.f;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float y = fmaf(scc, xv[j], shc);
-                            const float sg = sigmoidf2_(y);
-                            const float z = gm * (sg * (1.0f + y * (1.0f - sg))) * vv[j];      // SiLU networks only (run_conv)
-                            s1 += z;
-                            s2 = fmaf((xv[j] - mean) * rstd, z, s2);
-                        }
+                    } else {       // z = S g (the 1 / rstd of the group is applied by gn_lin_fused_finalize)
+                        const float z0 = xs[q][0][0] * vv[0], z1 = xs[q][0][2] * vv[1], z2 = xs[q][1][0] * vv[2], z3 = xs[q][1][2] * vv[3];
+                        s1 = (z0 + z1) + (z2 + z3);
+                        s2 = fmaf(xs[q][0][1], z0, xs[q][0][3] * z1) + fmaf(xs[q][1][1], z2, xs[q][1][3] * z3);
                     }
                     av[(h * NTASK + q) * 2] = s1;
                     av[(h * NTASK + q) * 2 + 1] = s2;
@@ -320,14 +315,14 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
                     const float m = s1 * (1.0f / NT);
                     const int t = q * NTHR + tid;
                     if ((t & (NQ - 1)) == 0)
-                        *reinterpret_cast<f32x2*>(sp + ((long)cos_[q] * ntile + tile_id) * 2) = f32x2{pivot + m, s2 - s1 * m};
+                        *reinterpret_cast<f32x2*>(sp + ((long)co_of(h, q) * ntile + tile_id) * 2) = f32x2{pivot + m, s2 - s1 * m};
                 }
             }
         }
         // Tangent / cotangent group means of the finished tile for the norm that consumes this tensor (round 6; kernels.h
         // ConvArgs::st_part).  Tangent: raw {sum d, sum x d} per cout row (norm-independent: gn_lin_fused_finalize forms
-        // mean(xhat d) = rstd (sum x d - mean sum d) / n in double); cotangent: {sum z, sum xhat z} with the consuming norm's
-        // constants, as gn_tstats_partial<1> computes them.  Replaces that kernel's pass over the tensor (reference op: the
+        // mean(xhat d) = rstd (sum x d - mean sum d) / n in double); cotangent: {sum S g, sum xhat S g} from the consuming norm's
+        // primal cache (gn_lin_fused_finalize divides by rstd: z = (sc / rstd) act'(y) g = S g / rstd, what gn_tstats_partial<1> sums).  Replaces that kernel's pass over the tensor (reference op: the
         // GroupNorm inside jvp / vjp, models/ddpm/diffusion.py:810-811 under edit.py:2455,2479).  Every round left the lane's share
         // of its row sums in av[]; all 2 x TM x NTASK of them go through ONE recursive-halving reduction over the row's NQ lanes.
         if (lin_st) {
@@ -1492,12 +1487,14 @@ __global__ __launch_bounds__(WM * WN * 64, STG == 3 ? 2 : 1) void conv_mfma_f16(
     conv_lowp_body<PR_F16, TAPS, WM, WN, TM, TN, MODE, STG>(a, acc);
 }
 
-// persistent over the probes of a tile (PHASE 3 of conv_lowp_body)
+#ifdef LOCO_DIAG
+// persistent over the probes of a tile (PHASE 3 of conv_lowp_body): diagnostics build only (measured neutral in the flow)
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
 __global__ __launch_bounds__(WM * WN * 64, 1) void conv_pers_bf16x3(ConvArgs a) {
     f32x16 acc[TM][TN];
     conv_lowp_body<PR_BF16X3, TAPS, WM, WN, TM, TN, MODE, STG, 3>(a, acc);
 }
+#endif
 
 // K-concatenated ResBlock tail: out = conv3x3(map(in)) + conv1x1(in2) + biases (+ residual): the 3x3 operator of `a` (vector
 // staging, MODE) and, on the same accumulator tile, the 1x1 operator {in2, Cin2, wb2} on the RAW block input (per-pixel
@@ -1529,6 +1526,7 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
     const size_t stage_bytes = (size_t)WM * 32 * NT * 4;      // epilogue staging tile S[WM*32 couts][NT pixels]
     if (lds < stage_bytes) lds = stage_bytes;
     dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
+#ifdef LOCO_DIAG
     if constexpr (PR == PR_BF16X3 && TAPS == 9 && STG == 0 && WM == 2 && WN == 4 && TM == 2 && TN == 2) {
         if (a.pers_groups > 0) {      // conv_pers_plan: one workgroup walks the probes b, b + G, ... of its tile
             auto pk = &conv_pers_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;
@@ -1542,6 +1540,7 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
             return;
         }
     }
+#endif
     auto kern = PR == PR_F16 ? &conv_mfma_f16<TAPS, WM, WN, TM, TN, MODE, STG>
                              : &conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;
     if (lds > 64 * 1024) {
@@ -1595,10 +1594,12 @@ void launch_tile_b(const ConvArgs& a, hipStream_t st) {
         case 5:                                                           // 128 x 256, 8 compute waves (64 x 64 each)
             launch_one_b<PR, TAPS, 2, 4, 2, 2, MODE>(a, st);
             break;
-        case 6:                                                           // 128 x 128, 4 waves, compact LDS: two workgroups per CU (LOCO_CONV_2WG=1)
+#ifdef LOCO_DIAG
+        case 6:                                                           // 128 x 128, 4 waves, compact LDS: two workgroups per CU (LOCO_CONV_2WG=1; diagnostics build)
             if constexpr (TAPS == 9) { launch_one_b2<PR, TAPS, 2, 2, 2, 2, MODE, 3>(a, st); break; }
             launch_one_b<PR, TAPS, 2, 2, 2, 2, MODE>(a, st);
             break;
+#endif
         case 0: launch_one_b<PR, TAPS, 2, 2, 2, 2, MODE>(a, st); break;
         case 1: launch_one_b<PR, TAPS, 4, 1, 1, 2, MODE>(a, st); break;
         case 2: launch_one_b<PR, TAPS, 1, 4, 1, 1, MODE>(a, st); break;

@@ -1395,16 +1395,13 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
         // Tangent / cotangent group means in the conv epilogue (round 6, LOCO_FUSE_LIN=0: off): whole cout tiles, no split-K, not the
         // opt-in persistent / dual-probe kernels (their epilogues take the forward statistics only).  A tangent launch that finishes
         // one part of a concatenation keeps its (norm-independent) raw sums in the part's buffer, at this lane's samples.
-        if ((rq->kind == ST_TAN || (rq->kind == ST_COT && c->cfg.act == ACT_SILU)) && c->fuse_lin && conv_lowp_can_fuse_stats(x) &&
-            !x.pers_groups && !conv_dual_ok(x)) {      // (the cotangent form is written for SiLU, as ConvArgs::cot_d)
+        const bool cot_cache = rq->kind == ST_COT && rq->n && rq->n->sx_off >= 0 && c->sxcache;      // (its {S, xhat} records exist)
+        if ((rq->kind == ST_TAN || cot_cache) && c->fuse_lin && conv_lowp_can_fuse_stats(x) && !x.pers_groups && !conv_dual_ok(x)) {
             const size_t lane_off = (size_t)c->lane_s0 * x.Cout * ntile * 2;
             const bool keptl = rq->kind == ST_TAN && rq->keep && s0 == 0 && x.B == a.B && lane_off + need <= rq->keep_floats;
             if (keptl || (rq->n && need <= c->stpart_floats)) {
                 x.st_part = keptl ? rq->keep + lane_off : c->stpart; x.st_kind = rq->kind; x.st_x = rq->prim;
-                if (rq->kind == ST_COT) {
-                    NS sp = nstats(c, c->statsP, *rq->n);
-                    x.st_sc = sp.sc; x.st_sh = sp.sh; x.st_mr = sp.mr; x.st_cpg = rq->n->C / Gn;
-                }
+                if (rq->kind == ST_COT) x.st_sx = c->sxcache + rq->n->sx_off;
                 if (keptl) *rq->keep_ntile = ntile;
                 return rq->n ? 1 : 4;
             }

@@ -92,11 +92,11 @@ struct ConvArgs {
     //   st_kind == ST_FWD: {mean, M2};
     //   ST_TAN (round 6): the RAW sums {sum d, sum x d} with x = st_x, the primal of the output tensor (B = 1) -- independent of
     //       the norm, so one set of partials serves the next block's norm AND the up-path norm over a concatenation;
-    //   ST_COT (round 6): {sum z, sum xhat z}, z = (sc / rstd) act'(sc x + sh) d, with the consuming norm's per-channel
-    //       st_sc / st_sh and per-group {mean, rstd} st_mr (st_cpg channels per group).
+    //   ST_COT (round 6): {sum S d, sum xhat S d} with {S = sc act'(sc x + sh), xhat} = st_sx, the consuming norm's primal cache
+    //       records over the output tensor (B = 1); z = (sc / rstd) act'(.) d = S d / rstd: the merge divides by the group's rstd.
     // Merged per (sample, group) by launch_gn_fused_finalize (FWD) / launch_gn_lin_fused_finalize (TAN, COT).
     float* st_part; int st_kind;
-    const float* st_x; const float* st_sc; const float* st_sh; const float* st_mr; int st_cpg;
+    const float* st_x; const float2* st_sx;
     // K-concatenated second operator (conv_bf16_kernel.h conv_lowp_kcat): a 1x1 conv of the RAW tensor in2 [B][Cin2][Hout][Wout]
     // accumulated into the same output tile; its bias travels in `bias2` (bias2_bs = 0).  Cin2 == 0: none.
     const float* in2; long in2_bs; int Cin2; int in2_padded;

@@ -338,29 +338,42 @@ __global__ __launch_bounds__(64) void gn_fused_finalize_cat_kernel(const float* 
 // gn_tstats_finalize write.  Tangent partials are the raw {sum d, sum x d}: mean(xhat d) = rstd (sum x d - mean sum d) / n with the
 // primal {mean, rstd} of the consuming norm; cotangent partials are {sum z, sum xhat z} already.  Channels >= C1 of a
 // concatenation come from the second producer's partials (tangent kind: raw sums do not depend on the norm).
-__global__ __launch_bounds__(64) void gn_lin_fused_finalize_kernel(int kind, const float* partA, int C1, int ntA,
-                                                                   const float* partB, int ntB, int C, int G, double inv_n,
-                                                                   const float* mr, float* tst, float* tc, long tbs) {
+__global__ __launch_bounds__(256) void gn_lin_fused_finalize_kernel(int kind, const float* partA, int C1, int ntA,
+                                                                    const float* partB, int ntB, int C, int G, double inv_n,
+                                                                    const float* mr, float* tst, float* tc, long tbs) {
+    __shared__ double sm[4];
     const int g = blockIdx.x, b = blockIdx.y, cpg = C / G, C2 = C - C1;
     const float2* pa = reinterpret_cast<const float2*>(partA) + (long)b * C1 * ntA;
     const float2* pb = partB ? reinterpret_cast<const float2*>(partB) + (long)b * C2 * ntB : nullptr;
+    // the group's entries are contiguous inside each producer's buffer ([c][tile], channels of a group adjacent): one or two runs
+    const int c0 = g * cpg, c1 = c0 + cpg;
+    const int a0 = c0 < C1 ? c0 : C1, a1 = c1 < C1 ? c1 : C1;                 // channels [a0, a1) from A, [b0, b1) from B
+    const int b0 = (c0 > C1 ? c0 : C1) - C1, b1 = (c1 > C1 ? c1 : C1) - C1;
+    const float2* ra = pa + (long)a0 * ntA; const int na = (a1 - a0) * ntA;
+    const float2* rb = pb ? pb + (long)b0 * ntB : nullptr; const int nb = pb ? (b1 - b0) * ntB : 0;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < cpg; ++k) {
-        const int c = g * cpg + k;
-        const float2* p = c < C1 ? pa + (long)c * ntA : pb + (long)(c - C1) * ntB;
-        const int nt = c < C1 ? ntA : ntB;
-        for (int i = threadIdx.x; i < nt; i += 64) { const float2 v = p[i]; s1 += (double)v.x; s2 += (double)v.y; }
+    for (int i = threadIdx.x; i < na; i += 1024) {       // four independent loads in flight per thread
+        const float2 z = {0.f, 0.f};
+        const float2 v0 = ra[i], v1 = i + 256 < na ? ra[i + 256] : z, v2 = i + 512 < na ? ra[i + 512] : z, v3 = i + 768 < na ? ra[i + 768] : z;
+        s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
     }
-    s1 = __shfl(wave_sum(s1), 0, 64);
-    s2 = __shfl(wave_sum(s2), 0, 64);
+    for (int i = threadIdx.x; i < nb; i += 1024) {
+        const float2 z = {0.f, 0.f};
+        const float2 v0 = rb[i], v1 = i + 256 < nb ? rb[i + 256] : z, v2 = i + 512 < nb ? rb[i + 512] : z, v3 = i + 768 < nb ? rb[i + 768] : z;
+        s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    s1 = block_sum(s1, sm);
+    s2 = block_sum(s2, sm);
     const float mean = mr[2 * g], rstd = mr[2 * g + 1];
     float m1, m2;
     if (kind == ST_TAN) {
         m1 = (float)(s1 * inv_n);
         m2 = (float)((double)rstd * (s2 - (double)mean * s1) * inv_n);
-    } else {
-        m1 = (float)(s1 * inv_n);
-        m2 = (float)(s2 * inv_n);
+    } else {       // cotangent partials are sums of S g and xhat S g: z = S g / rstd
+        m1 = (float)(s1 * inv_n / (double)rstd);
+        m2 = (float)(s2 * inv_n / (double)rstd);
     }
     if (threadIdx.x == 0) {
         float* o = tst + (long)b * tbs + 2 * g;
@@ -369,7 +382,7 @@ __global__ __launch_bounds__(64) void gn_lin_fused_finalize_kernel(int kind, con
     }
     if (tc) {      // per-channel expansion for the split-bf16 conv staging; the cotangent form carries rstd
         const float f = kind == ST_TAN ? 1.0f : rstd;
-        for (int k = threadIdx.x; k < cpg; k += 64) {
+        for (int k = threadIdx.x; k < cpg; k += 256) {
             float* t = tc + (long)b * tbs + 2 * ((long)g * cpg + k);
             t[0] = f * m1;
             t[1] = f * m2;
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(64) void gn_lin_fused_finalize_kernel(int kind, con
 }
 void launch_gn_lin_fused_finalize(int kind, const float* partA, int C1, int ntA, const float* partB, int ntB, int B, int C, int HW,
                                   int G, const float* mr, float* tst, float* tc, long tst_bs, hipStream_t st) {
-    hipLaunchKernelGGL(gn_lin_fused_finalize_kernel, dim3(G, B), dim3(64), 0, st, kind, partA, C1, ntA, partB, ntB, C, G,
+    hipLaunchKernelGGL(gn_lin_fused_finalize_kernel, dim3(G, B), dim3(256), 0, st, kind, partA, C1, ntA, partB, ntB, C, G,
                        1.0 / ((double)(C / G) * HW), mr, tst, tc, tst_bs);
 }
 void launch_gn_fused_finalize_cat(const float* partA, int C1, int ntA, const float* partB, int ntB, int B, int C, int HW, int G,

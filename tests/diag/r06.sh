@@ -16,7 +16,7 @@ case $W in
   ab)           # whole-step A/B of environment configurations: "A=1,B=0" "A=0" ... [-- workload ...]
     timeout 1500 python3 tests/diag/ab_cfg.py "$@" 2>&1 | tee $O/ab.log ;;
   lin)          # the tangent / cotangent means in the conv epilogues: parity tests + A/B
-    timeout 1200 python3 -m pytest tests/test_gpu_parity.py -x -q -k "fused_into" 2>&1 | tail -5 | tee $O/pytest.log
+    timeout 1200 python3 -m pytest tests/test_gpu_parity.py -x -q -k "fused_into or dual_probe or persistent_conv or bench_two_ranks" 2>&1 | tail -5 | tee $O/pytest.log
     timeout 900 python3 tests/diag/ab_cfg.py "LOCO_FUSE_LIN=1" "LOCO_FUSE_LIN=0" 2>&1 | tee $O/ab.log ;;
   kstats)       # rocprofv3 --kernel-trace --stats of two timed headline steps per environment setting: "A=1" "A=0" ...
     cd /tmp && export TMPDIR=/tmp

@@ -754,15 +754,25 @@ def test_bench_two_ranks_headline_is_two_replicas_of_the_metrics_unit():
     assert d["scaling"] == "weak" and len(d["singular_values"]) == 5
 
 
+def _diag_lib():
+    """The diagnostics build (`make -C loco-edit_amd/csrc diag`, built by __graft_entry__.build()): the product library plus the
+    bring-up entry points of include/loco_hip_diag.h and the three opt-in kernel families that measured neutral."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "loco-edit_amd", "libloco_hip_diag.so")
+    assert os.path.exists(path), "libloco_hip_diag.so is missing: run `make -C loco-edit_amd/csrc diag` (or __graft_entry__.build())"
+    return path
+
+
 @pytest.mark.gpu
 def test_dual_probe_conv_tile_is_bit_identical_to_the_128x256_tile():
-    """The opt-in dual-probe 3x3 tile (csrc/conv_dual_kernel.h, LOCO_CONV_DUAL=1: two probes' pixel tiles share each weight
+    """The opt-in dual-probe 3x3 tile of the diagnostics build (csrc/conv_dual_kernel.h, LOCO_CONV_DUAL=1: two probes' pixel tiles share each weight
     stage) against the default kernel on a forward batch, J V and U^T J of 3 samples / probes at 256 x 256 (one pair on the
     dual tile + the odd probe on the 128 x 256 tile): same products in the same order, so the outputs are the same bits.  The
     switch is read once per process: one child process per setting (tests/diag/dual_check.py)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1")
+    # (the tile lives in the diagnostics build; its epilogue takes the forward statistics only, so both settings run the tangent /
+    # cotangent means as standalone passes: the comparison is about the conv kernel, bit for bit)
+    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1", LOCO_HIP_LIB=_diag_lib(), LOCO_FUSE_LIN="0")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "dual_check.py"), "3"], env=env, capture_output=True,
                        text=True, timeout=900)
@@ -777,7 +787,7 @@ def test_persistent_conv_kernel_is_bit_identical_to_one_workgroup_per_tile():
     same products in the same order, the same bits (with 3 probes no launch of the default path splits a tail probe over K)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1", DUAL_CHECK_ON="2")
+    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1", DUAL_CHECK_ON="2", LOCO_HIP_LIB=_diag_lib(), LOCO_FUSE_LIN="0")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "dual_check.py"), "3", "CELEBA_DDPM", "LOCO_CONV_PERS"],
                        env=env, capture_output=True, text=True, timeout=900)
