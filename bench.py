@@ -75,11 +75,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["celeba_top5", "p2_k64", "tloco_if64", "tloco_if_i_m", "tloco_sd", "tloco_sd15"], default="celeba_top5")
-    ap.add_argument("--streams", type=int, choices=[1, 2], default=1,
-                    help="unconditional workloads: probe groups of a tangent / cotangent pass on 1 (default, as the package) or 2 HIP "
-                         "streams.  Two streams raise the throughput (-3.5 ... -3.8 %% per headline solve) by overlapping launches of "
-                         "2 and 3 probes, each of which fills the chip worse than the 5-probe launch: the headline and its "
-                         "per-kernel roofline stay on one stream, the two-stream figure is the extra line celeba_top5_two_streams")
+    ap.add_argument("--streams", type=int, choices=[1, 2], default=int(os.environ.get("LOCO_STREAMS", "2")),
+                    help="unconditional workloads: probe groups of a tangent / cotangent pass on 2 HIP streams (default, as the "
+                         "package since round 6: -3.5 ... -4.7 %% per headline solve, same results) or on 1.  The per-kernel profile "
+                         "behind `roofline` is always taken on ONE stream (isolated kernel durations, the ones rocprofv3 reports for "
+                         "a one-stream run); the one-stream step is the extra line celeba_top5_one_stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end phase timing (inversion ... decode)")

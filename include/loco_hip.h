@@ -102,6 +102,13 @@ int  loco_device_count(void);
 /* Replaces PullBackDDPM(args) construction (diffusion.py:128-143). */
 int  loco_create(const loco_unet_cfg* cfg, loco_ctx** out);
 void loco_destroy(loco_ctx* ctx);
+/* A second context on the SAME parameters (round 6): the reference runs all classifier-free-guidance branches through ONE
+ * U-Net object -- one set of weights (src/modules/edit.py:1319-1322, :655-667).  The fork shares the device copies of the
+ * parent's parameters in every layout and owns only its activation arenas (max_batch samples; <= 0: the parent's), statistics,
+ * scratch and per-prompt constants (loco_set_context / loco_set_cond); results are bit-identical to an independent context
+ * loaded with the same state_dict.  The parent must have all parameters loaded; it may be destroyed first (its parameters are
+ * freed with the last fork). */
+int  loco_fork(loco_ctx* parent, int32_t max_batch, loco_ctx** out);
 const char* loco_last_error(loco_ctx* ctx);
 
 /* Replaces model.load_state_dict (src/utils/utils.py:102-105): one call per

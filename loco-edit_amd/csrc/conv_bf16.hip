@@ -18,7 +18,9 @@ int conv_bf16_pick_tile(int Cout, int HW, int B) {
     if (b1 < 0) { const char* e = getenv("LOCO_B1_TILE"); b1 = e ? atoi(e) : 1024; }
     // single-sample passes (the B = 1 inversion / to-t chains) at 64x64 and below: 64 x 64 tiles fill the chip with a quarter
     // of the split-K of the 128 x 256 tile (LOCO_B1_TILE: largest H*W it applies to, default 32 x 32: 4.29 vs 4.51 ms per evaluation; 0 = off)
-    if (b1 > 0 && B == 1 && HW <= b1 && HW >= 64 && (Cout % 64) == 0) return 3;
+    static int b1_maxb = -1;      // LOCO_B1_TILE_MAXB: largest batch the rule applies to (probe groups of a two-stream pass are 2 - 3 samples)
+    if (b1_maxb < 0) { const char* e = getenv("LOCO_B1_TILE_MAXB"); b1_maxb = e ? atoi(e) : 1; }
+    if (b1 > 0 && B <= b1_maxb && HW <= b1 && HW >= 64 && (Cout % 64) == 0) return 3;
     int t = conv_pick_tile(Cout, HW);
     if (t == 0 && HW >= 256) {
         if (g_bf16_tile_override >= 0) return g_bf16_tile_override;

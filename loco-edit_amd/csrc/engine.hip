@@ -205,6 +205,12 @@ struct loco_ctx {
     // workspace of the record GEMM (gemm_rec.hip: the operands' split records + K-split partial tiles), one per stream lane, grown
     // on demand outside stream capture
     unsigned char* gemm_ws[2] = {nullptr, nullptr}; size_t gemm_ws_bytes[2] = {0, 0}; int lane = 0;
+    // Shared parameter store (loco_fork, round 6): a forked context uses the device copies of its root's parameters (all six
+    // layouts) and owns only its arenas, statistics, scratch and per-prompt constants.  The root stays allocated until its last
+    // fork is destroyed (`forks`, `zombie`).
+    loco_ctx* weights_of = nullptr;
+    int forks = 0;
+    bool zombie = false;
     bool fuse_lin = true;          // tangent / cotangent group means taken in the conv epilogues (LOCO_FUSE_LIN=0: standalone passes)
     int lane_s0 = 0;               // first sample of the lane being enqueued (run_lanes): where its rows of a kept partial buffer start
     int chip_share = 1;            // contexts whose passes the host enqueues side by side on other streams (loco_set_chip_share): split-K aims at 256 / share workgroups
@@ -2803,8 +2809,57 @@ int loco_create(const loco_unet_cfg* cfg, loco_ctx** out) {
 }
 
 
+int loco_fork(loco_ctx* parent, int32_t max_batch, loco_ctx** out) {
+    if (!parent || !out) return -2;
+    *out = nullptr;
+    if (finalize_params(parent)) return -3;
+    loco_ctx* root = parent->weights_of ? parent->weights_of : parent;      // forks of a fork share the root's store
+    loco_unet_cfg cfg = parent->cfg;
+    if (max_batch > 0) cfg.max_batch = max_batch;
+    loco_ctx* c = nullptr;
+    const int rc = loco_create(&cfg, &c);
+    *out = c;
+    if (rc) return rc;
+    if (c->ops.size() != root->ops.size()) { c->err = "loco_fork: programs differ"; return -2; }
+    // the parameter pointers of every operator (program-dependent fields -- tensor ids, statistics offsets -- are the child's own,
+    // identical by construction: same configuration, same build_program)
+    for (size_t i = 0; i < c->ops.size(); ++i) {
+        Op& d = c->ops[i];
+        const Op& s_ = root->ops[i];
+        d.c1 = s_.c1; d.c2 = s_.c2; d.nin = s_.nin; d.qkvc = s_.qkvc; d.proj = s_.proj; d.conv = s_.conv;
+        d.xqc = s_.xqc; d.xproj = s_.xproj;
+        d.pj_in = s_.pj_in; d.to_out1 = s_.to_out1; d.to_out2 = s_.to_out2; d.ff1 = s_.ff1; d.ff2 = s_.ff2; d.pj_out = s_.pj_out;
+        d.n1.gamma = s_.n1.gamma; d.n1.beta = s_.n1.beta; d.n2.gamma = s_.n2.gamma; d.n2.beta = s_.n2.beta;
+        d.nx.gamma = s_.nx.gamma; d.nx.beta = s_.nx.beta;
+        d.xkw = s_.xkw; d.xkb = s_.xkb; d.xvw = s_.xvw; d.xvb = s_.xvb; d.xng = s_.xng; d.xnb = s_.xnb;
+        for (int k = 0; k < 3; ++k) { d.lng[k] = s_.lng[k]; d.lnb[k] = s_.lnb[k]; }
+        d.tproj_off = s_.tproj_off;
+        if (s_.xK) {      // the projected prompt states are per context (loco_set_context)
+            const size_t kv = (size_t)c->tens[d.in].C * c->ctx_Lp;
+            if (dalloc(c, &d.xK, kv) || dalloc(c, &d.xV, kv)) return -1;
+        }
+    }
+    c->td0w = root->td0w; c->td0b = root->td0b; c->td1w = root->td1w; c->td1b = root->td1b; c->freq = root->freq;
+    c->tp_w = root->tp_w; c->tp_b = root->tp_b; c->tproj_total = root->tproj_total;
+    if (dalloc(c, &c->tact, (size_t)cfg.ch * 4) || dalloc(c, &c->tproj, (size_t)(c->tproj_total > 0 ? c->tproj_total : 1))) return -1;
+    c->flops = root->flops;
+    c->prec = parent->prec;
+    c->params.clear(); c->param_order.clear();
+    c->finalized = true;
+    c->weights_of = root;
+    ++root->forks;
+    return 0;
+}
+
+static void destroy_now(loco_ctx* c);
 void loco_destroy(loco_ctx* c) {
     if (!c) return;
+    if (c->forks > 0) { c->zombie = true; return; }      // its forks still read its parameters: freed with the last of them
+    loco_ctx* root = c->weights_of;
+    destroy_now(c);
+    if (root && --root->forks == 0 && root->zombie) destroy_now(root);
+}
+static void destroy_now(loco_ctx* c) {
     for (float* p : c->owned) (void)hipFree(p);
     for (unsigned char* p : c->gemm_ws) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -231,11 +231,12 @@ def _preset_t2i(args, family):
             # DeepFloyd/IF-I-M-v1.0); `--unet_preset if64_standin` / `if64_xattn_standin` select the round-2 / 3 stand-ins
             parts = args.model_name.split("-")               # "DeepFloyd/IF-I-M-v1.0" -> size "M" (edit.py:1204)
             size = parts[2] if len(parts) > 2 and parts[2] in config.IF_I_WIDTH else "M"
-            if size == "XL":
-                # 4.3 B parameters x six layouts per conv operator x one engine context per CFG branch: the three contexts
-                # of the T-LOCO flow do not fit one GPU (config.py); refuse here instead of failing in hipMalloc at load time
-                raise SystemExit("DeepFloyd/IF-I-XL-v1.0: three engine contexts of the 4.3 B-parameter stage-I U-Net exceed one "
-                                 "GPU's memory in this build; use IF-I-M (the shipped scripts' model) or IF-I-L")
+            if size == "XL" and os.environ.get("LOCO_CFG_FORK", "1") == "0":
+                # 4.3 B parameters x six device layouts (24 bytes per parameter) = 103 GB per independently loaded context: three of
+                # them do not fit one GPU.  With the default shared parameter store (loco_fork: the guidance branches are forks of
+                # one loaded context, round 6) the flow holds the parameters once -- ~103 GB + three arenas; not run at size here
+                raise SystemExit("DeepFloyd/IF-I-XL-v1.0: three independently loaded contexts (LOCO_CFG_FORK=0) of the 4.3 B-parameter "
+                                 "stage-I U-Net exceed one GPU's memory; leave LOCO_CFG_FORK at its default (one shared parameter store)")
             args.unet_config = config.if_stage1_config(size)
         args.c_in = 3
     args.image_size = args.unet_config.resolution          # 64: SD latents and the IF stage-I models alike

@@ -24,7 +24,7 @@ DIAG_SYMBOLS = ["loco_bench_conv", "loco_debug_tensor"]
 
 # every symbol include/loco_hip.h declares
 SYMBOLS = [
-    "loco_version", "loco_device_count", "loco_create", "loco_destroy", "loco_last_error",
+    "loco_version", "loco_device_count", "loco_create", "loco_fork", "loco_destroy", "loco_last_error",
     "loco_load_param", "loco_params_missing", "loco_unet_forward", "loco_ddim_step", "loco_sched_step",
     "loco_pmp_primal", "loco_pmp_set_second_mask", "loco_pmp_jvp", "loco_pmp_vjp", "loco_orthonormalize", "loco_qr_rows",
     "loco_convergence", "loco_convergence_rows", "loco_null_project", "loco_edit_axpy", "loco_mask_gather", "loco_mask_count",
@@ -66,6 +66,7 @@ def load_library():
     lib.loco_version.restype = C.c_char_p
     lib.loco_device_count.restype = C.c_int
     lib.loco_create.argtypes = [C.POINTER(LocoCfg), C.POINTER(vp)]
+    lib.loco_fork.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     lib.loco_destroy.argtypes = [vp]
     lib.loco_destroy.restype = None
     lib.loco_last_error.argtypes = [vp]
@@ -167,6 +168,25 @@ class LocoEngine:
             raise RuntimeError(f"loco_create failed ({rc}): {msg}")
         self.n = cfg.n              # elements of the network input (image / latent)
         self.n_out = cfg.n_out      # elements of its output (= n for the denoisers; the decoded image for arch "dec")
+
+    def fork(self, max_batch: Optional[int] = None) -> "LocoEngine":
+        """A second engine context on THIS engine's parameters (loco_fork): shares the device copies of the weights in every
+        layout, owns its arenas / statistics / scratch / per-prompt constants.  What the reference does with one U-Net object
+        for all classifier-free-guidance branches (edit.py:1319-1322, :655-667); bit-identical to an independent engine."""
+        child = object.__new__(LocoEngine)
+        child.lib, child.cfg, child.device = self.lib, self.cfg, self.device
+        child.max_batch = int(max_batch or self.max_batch)
+        child.n, child.n_out = self.n, self.n_out
+        for k, v in self.__dict__.items():      # host-side settings (stream mode ...) that __init__ derives from the arguments
+            if k not in child.__dict__ and k != "_ctx":
+                child.__dict__[k] = v
+        child._ctx = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        rc = self.lib.loco_fork(self._ctx, child.max_batch, C.byref(child._ctx))
+        if rc != 0:
+            msg = self.lib.loco_last_error(child._ctx).decode() if child._ctx else self.lib.loco_last_error(self._ctx).decode()
+            raise RuntimeError(f"loco_fork failed ({rc}): {msg}")
+        return child
 
     def __del__(self):
         try:

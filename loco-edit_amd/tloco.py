@@ -326,9 +326,16 @@ class EditDeepFloydIF(object):
         unet_params = {k: v for k, v in params.items() if not k.startswith(("cond_proj.",) + IFTextConditioner.PREFIXES)}
         self.branches: Dict[str, LocoEngine] = {}
         prec = getattr(args, "precision", None) or os.environ.get("LOCO_PRECISION")
+        # ONE set of weights for the three prompts, as the reference's single U-Net object (edit.py:1319-1322, :655-667): the first
+        # context loads the parameters (six device layouts), the others are forks of it (loco_fork: own arenas, statistics and
+        # prompt constants only; bit-identical to independently loaded contexts).  LOCO_CFG_FORK=0: three independent contexts
+        share_weights = os.environ.get("LOCO_CFG_FORK", "1") != "0"
         for name in ("for", "edit", "null"):
-            eng = LocoEngine(cfg, max_batch=getattr(args, "max_batch", 8), device=self.device)
-            eng.load_state_dict(unet_params)
+            if share_weights and self.branches:
+                eng = self.branches["for"].fork()
+            else:
+                eng = LocoEngine(cfg, max_batch=getattr(args, "max_batch", 8), device=self.device)
+                eng.load_state_dict(unet_params)
             if prec:
                 eng.set_precision(prec)
             self.branches[name] = eng

@@ -54,11 +54,11 @@ def get_custom_diffusion_model(args) -> HipUNet:
     prec = getattr(args, "precision", None) or os.environ.get("LOCO_PRECISION")
     if prec:
         engine.set_precision(prec)
-    # LOCO_STREAMS=2: the two probe groups of a tangent / cotangent pass side by side on two HIP streams (statistics / apply
-    # kernels of one group beside the convolutions of the other: -3.5 ... -3.8 % per 256 x 256 solve on every box measured,
-    # results equal to rounding); the side stream is chosen by measurement, one stream when none runs beside the current one.
-    # Opt-in: the pass then runs as 2- and 3-probe launches, which only pay off through their overlap.
-    if os.environ.get("LOCO_STREAMS", "1") == "2" and torch.device(args.device).type == "cuda":
+    # Two HIP streams (the default since round 6; LOCO_STREAMS=1: one): the two probe groups of a tangent / cotangent pass side by
+    # side (statistics / apply / reduce kernels of one group beside the convolutions of the other: -3.5 ... -4.7 % per 256 x 256
+    # solve on every box measured, results equal to rounding); the side stream is chosen by measurement, one stream when none runs
+    # beside the current one.  Per-kernel durations are then durations under overlap: bench.py takes its per-kernel profile on one.
+    if os.environ.get("LOCO_STREAMS", "2") == "2" and torch.device(args.device).type == "cuda":
         engine.set_streams_measured(2)
     ckpt = getattr(args, "ckpt_path", "")
     if ckpt:

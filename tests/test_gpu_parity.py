@@ -754,6 +754,50 @@ def test_bench_two_ranks_headline_is_two_replicas_of_the_metrics_unit():
     assert d["scaling"] == "weak" and len(d["singular_values"]) == 5
 
 
+@pytest.mark.parametrize("cfg", [TINY_DDPM, TINY_ADM], ids=["tiny", "tiny_adm"])
+def test_forked_context_shares_the_parameters_and_computes_the_same_bits(cfg):
+    """loco_fork (round 6): a second context on the parent's device parameters (all six layouts shared; own arenas, statistics,
+    scratch, prompt constants) -- what the reference does with ONE U-Net object for all guidance branches (edit.py:1319-1322,
+    :655-667).  Forward batch, J V and U^T J of the fork are bit-identical to an independently loaded context, its workspace is
+    smaller by the parameter store, and it outlives its parent."""
+    from loco_edit_amd.hip import LocoEngine
+    s_ = _sched()
+    t = float(s_.timesteps[40]); at = float(s_.alpha_at(s_.timesteps[40]))
+    gen = torch.Generator().manual_seed(11)
+    R = cfg.resolution
+    xs = torch.randn(3, cfg.in_channels, R, R, generator=gen).to(DEV)
+    mask = torch.zeros(cfg.out_ch, R, R, dtype=torch.bool); mask[:, R // 3:R // 2, R // 4:R // 2] = True
+    V = torch.randn(3, cfg.n, generator=gen).to(DEV)
+    params = synth_params(cfg, 0)
+
+    def run(eng):
+        out = [eng.unet_forward(xs, t).clone()]
+        eng.pmp_primal(xs[:1].contiguous(), t, at, mask.to(DEV))
+        U = eng.pmp_jvp(V).clone()
+        out += [U, eng.pmp_vjp(U).clone()]
+        return out
+    a = LocoEngine(cfg, max_batch=4, device=torch.device(DEV)); a.load_state_dict(params)
+    b = LocoEngine(cfg, max_batch=4, device=torch.device(DEV)); b.load_state_dict(params)
+    f = a.fork()
+    f2 = f.fork(max_batch=3)                     # a fork of a fork shares the root's store
+    ref = run(b)
+    assert a.workspace_bytes() == b.workspace_bytes() and f.workspace_bytes() < a.workspace_bytes()
+    for prec in ("bf16x3", "f32"):
+        for e in (a, b, f, f2):
+            e.set_precision(prec)
+        ref = run(b)
+        for e in (f, a, f2):
+            for x, y in zip(run(e), ref):
+                assert torch.equal(x, y)
+    del a                                       # the parent goes first: its parameters stay until the last fork does
+    torch.cuda.synchronize()
+    for x, y in zip(run(f), ref):
+        assert torch.equal(x, y)
+    del f
+    for x, y in zip(run(f2), ref):
+        assert torch.equal(x, y)
+
+
 def _diag_lib():
     """The diagnostics build (`make -C loco-edit_amd/csrc diag`, built by __graft_entry__.build()): the product library plus the
     bring-up entry points of include/loco_hip_diag.h and the three opt-in kernel families that measured neutral."""

@@ -41,9 +41,15 @@ def test_if_presets_routing_and_size(tmp_path, monkeypatch):
     argv_l = argv[:i + 1] + ["DeepFloyd/IF-I-L-v1.0"] + argv[i + 2:]
     assert define_argparser.preset(define_argparser.parse_args(argv_l + ["--device", "cpu"])).unet_config.ch == 320
     import pytest
-    argv_xl = argv[:i + 1] + ["DeepFloyd/IF-I-XL-v1.0"] + argv[i + 2:]      # three 4.3 B-parameter contexts: refused up front
+    # IF-I-XL: one shared parameter store for the three guidance branches (loco_fork, the default) -> accepted; three independently
+    # loaded 4.3 B-parameter contexts (LOCO_CFG_FORK=0) are refused up front
+    argv_xl = argv[:i + 1] + ["DeepFloyd/IF-I-XL-v1.0"] + argv[i + 2:]
+    monkeypatch.delenv("LOCO_CFG_FORK", raising=False)
+    assert define_argparser.preset(define_argparser.parse_args(argv_xl + ["--device", "cpu"])).unet_config.ch == 704
+    monkeypatch.setenv("LOCO_CFG_FORK", "0")
     with pytest.raises(SystemExit, match="IF-I-XL"):
         define_argparser.preset(define_argparser.parse_args(argv_xl + ["--device", "cpu"]))
+    monkeypatch.delenv("LOCO_CFG_FORK")
     with pytest.raises(ValueError):
         K.hf_if_unet_to_native({}, C.FFHQ_P2)
 
