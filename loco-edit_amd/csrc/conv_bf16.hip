@@ -106,6 +106,23 @@ bool conv_lowp_can_fuse_stats(const ConvArgs& a) {
 }
 
 template <int PR, int MODE> void launch_kcat_b(const ConvArgs& a, hipStream_t st);   // conv_bf16_inst_*.hip
+template <int PR, int MODE> void launch_pair_b(const ConvArgs& a, hipStream_t st);   // conv_bf16_inst_k.hip (conv_pair_kernel.h)
+
+// The 16x16x32 tap-pair kernel (conv_pair_kernel.h, round 6) takes the launches the 128 x 256 tile of the lock-step kernel would
+// take when the shape allows: 3x3, stride 1, padded arena input, whole 16-channel chunks in an even number, whole 128-cout tiles,
+// image rows a multiple of the 32-pixel tile width, no split-K, no K-concatenated shortcut.  LOCO_CONV_PAIR=1, diagnostics build.
+bool conv_pair_ok(const ConvArgs& a) {
+#ifndef LOCO_DIAG
+    return false;      // compiled into the diagnostics build only (`make diag`)
+#endif
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("LOCO_CONV_PAIR"); on = e ? (atoi(e) != 0) : 0; }
+    if (!on || a.taps != 9 || a.Cin2 > 0 || a.nsplit != 1 || a.stride != 1 || a.upsample || a.zins || a.pad != 1 || !a.in_padded ||
+        (a.Cin % (2 * BKC)) != 0 || (a.Cout % 128) != 0 || (a.Wout % 32) != 0 || (a.Hout % 8) != 0 || a.pers_groups || a.dual)
+        return false;
+    if (!(a.mode == CM_NONE || a.mode == CM_GN_SILU || a.mode == CM_TAN_SILU || a.mode == CM_COT_SILU)) return false;
+    return bf16_tile_of(a) == 5;
+}
 template <int PR, int MODE> void launch_dual_b(const ConvArgs& a, hipStream_t st);   // conv_bf16_inst_h / _i.hip (conv_dual_kernel.h)
 
 // Dual-probe tile policy.  Opt-in (LOCO_CONV_DUAL=1): measured neutral on the headline (+1.2 %) and on config 3 (-0.2 %) in round 5
@@ -267,6 +284,19 @@ static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
                 case CM_GN_SILU: launch_dual_b<PR, CM_GN_SILU>(a, st); break;
                 case CM_TAN_SILU: launch_dual_b<PR, CM_TAN_SILU>(a, st); break;
                 default: launch_dual_b<PR, CM_COT_SILU>(a, st); break;
+            }
+            return;
+        }
+    }
+#endif
+#ifdef LOCO_DIAG
+    if constexpr (PR == PR_BF16X3) {
+        if (taps == 9 && conv_pair_ok(a)) {
+            switch (a.mode) {
+                case CM_NONE: launch_pair_b<PR, CM_NONE>(a, st); break;
+                case CM_GN_SILU: launch_pair_b<PR, CM_GN_SILU>(a, st); break;
+                case CM_TAN_SILU: launch_pair_b<PR, CM_TAN_SILU>(a, st); break;
+                default: launch_pair_b<PR, CM_COT_SILU>(a, st); break;
             }
             return;
         }

@@ -148,10 +148,38 @@ __device__ __forceinline__ void rs_reduce(float* av, const int lane) {
 
 // Epilogue of the low-precision conv kernel: the WM x WN waves (threads 0 .. WM*WN*64-1) write their accumulator tiles.
 // D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// `stage_round(h, S)`: the wave's accumulator values of write-out round h (cout rows (wm * TM + h) * 32 ... + 31 of the tile) into
+// the staging image S[WM * 32][NT] -- the one place that knows the accumulator layout (conv_pair_kernel.h passes its own)
+template <int WM, int WN, int TM, int TN, class StageRound>
+__device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, StageRound&& stage_round, unsigned char* smem_b, const int co0,
+                                                          const int oy0, const int ox0, const int TW, const int tile_id, const int b,
+                                                          const int split);
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_lowp_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TM][TN], const int co0, const int oy0,
+                                                          const int ox0, const int TW, const int b, const int split);
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem_b, const int co0,
                                                    const int oy0, const int ox0, const int TW, const int tile_id, const int b,
                                                    const int split) {
+    constexpr int NT = WN * TN * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5, wm = wave / WN, wn = wave % WN;
+    if (co0 + WM * TM * 32 <= a.Cout) {
+        conv_lowp_epilogue_staged<WM, WN, TM, TN>(a, [&](const int h, float* S) {      // (h is a constant after unrolling)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    S[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * NT + (wn * TN + j) * 32 + l31] = acc[h][j][r];
+        }, smem_b, co0, oy0, ox0, TW, tile_id, b, split);
+        return;
+    }
+    conv_lowp_epilogue_direct<WM, WN, TM, TN>(a, acc, co0, oy0, ox0, TW, b, split);
+}
+template <int WM, int WN, int TM, int TN, class StageRound>
+__device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, StageRound&& stage_round, unsigned char* smem_b, const int co0,
+                                                          const int oy0, const int ox0, const int TW, const int tile_id, const int b,
+                                                          const int split) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = WM * TM * 32;
     constexpr int NT = WN * TN * 32;
@@ -162,8 +190,7 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
     const int khalf = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const long out_plane = (long)a.Hout * a.Wout;
-    const bool full_co = (co0 + MT <= a.Cout);
-    if (full_co) {
+    {
         // Whole cout tiles leave through LDS: in the accumulator layout a lane owns ONE pixel of 16 couts, i.e. 64 dword
         // stores per lane and tile, and the tile's write-out is bound by store ISSUE, not by bandwidth (512 wave-stores of
         // 256 bytes per workgroup).  Staged through the (now idle) operand buffers as S[cout][pixel], a lane reads back 4
@@ -206,11 +233,7 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    S[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * NT + (wn * TN + j) * 32 + l31] = acc[h][j][r];
+            stage_round(h, S);
             // (requested here: the round's accumulator registers are free, the loads fly under the LDS round trip)
             f32x4 xs[NTASK][2];                            // tangent: [q][0] = x of 4 pixels; cotangent: {S0,x0,S1,x1}, {S2,x2,S3,x3}
             if (lin_st) {
@@ -346,8 +369,16 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
                 }
             }
         }
-        return;
     }
+}
+// partial cout tiles (Cout not a multiple of the tile): straight from the accumulator layout, one dword per store
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_lowp_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TM][TN], const int co0, const int oy0,
+                                                          const int ox0, const int TW, const int b, const int split) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5, wm = wave / WN, wn = wave % WN;
+    const long out_plane = (long)a.Hout * a.Wout;
+    const bool full_co = false;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         int p = (wn * TN + j) * 32 + l31;

@@ -45,14 +45,16 @@ shutil.rmtree(TMP, ignore_errors=True)
 for k in (res["0"] if "0b" in res else ()):
     print(f"{k}: run-to-run difference of the 128 x 256 tile itself: {(res['0'][k] - res['0b'][k]).abs().max().item():.3e}")
 ok = True
+RTOL = float(os.environ.get("DUAL_CHECK_RTOL", "0"))      # > 0: a kernel with another summation order (rel-L2 per output <= RTOL)
 for k in res["0"]:
     a, b = res["0"][k], res["1"][k]
     d = (a - b).abs().max().item()
     rel = d / a.abs().max().item()
+    l2 = ((a - b).norm() / a.norm()).item()
     nan = bool(torch.isnan(b).any())
-    print(f"{k}: max|diff| {d:.3e} (rel {rel:.3e}) nan={nan} |ref|max {a.abs().max().item():.3e}")
-    if d != 0.0:
+    print(f"{k}: max|diff| {d:.3e} (rel {rel:.3e}, rel-L2 {l2:.3e}) nan={nan} |ref|max {a.abs().max().item():.3e}")
+    if d != 0.0 and RTOL == 0:
         ne = (a != b).reshape(a.shape[0], -1)
         print(f"   differing elements per sample / probe row: {ne.sum(dim=1).tolist()} of {ne.shape[1]}")
-    ok = ok and d == 0.0 and not nan
-print(ENVN, "0 vs 1:", "PASS (bit-identical)" if ok else "FAIL")
+    ok = ok and not nan and (d == 0.0 if RTOL == 0 else l2 <= RTOL)
+print(ENVN, "0 vs 1:", ("PASS (bit-identical)" if RTOL == 0 else f"PASS (rel-L2 <= {RTOL:g})") if ok else "FAIL")

@@ -825,6 +825,22 @@ def test_dual_probe_conv_tile_is_bit_identical_to_the_128x256_tile():
 
 
 @pytest.mark.gpu
+def test_tap_pair_16x16x32_conv_kernel_matches_the_32x32x16_kernel():
+    """Round 6: the 3x3 kernel on v_mfma_f32_16x16x32_bf16 with K = two taps x 16 channels (csrc/conv_pair_kernel.h, diagnostics
+    build, LOCO_CONV_PAIR=1: piece-plane LDS images, LDS-DMA un-swizzling, fragments refilled in place) against the 32x32x16 kernel
+    on a forward batch, J V and U^T J of 3 samples / probes at 256 x 256: the same products in another summation order (rel-L2 per
+    output <= 3e-5: another summation order flips a fraction of the downstream split-bf16 roundings; the statistics in both settings as standalone passes so that only the conv kernel differs)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1", DUAL_CHECK_RTOL="3e-5", LOCO_HIP_LIB=_diag_lib(), LOCO_FUSE_LIN="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "dual_check.py"), "3", "CELEBA_DDPM", "LOCO_CONV_PAIR"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "LOCO_CONV_PAIR 0 vs 1: PASS (rel-L2 <= 3e-05)" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
 def test_persistent_conv_kernel_is_bit_identical_to_one_workgroup_per_tile():
     """The opt-in 3x3 kernel that walks the probes of a tile as one stream of chunks (conv_lowp_body PHASE 3, LOCO_CONV_PERS=2:
     every form) against one workgroup per (tile, probe): forward batch, J V and U^T J of 3 samples / probes at 256 x 256 -- the
