@@ -374,6 +374,15 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec) {
         if (!pn[mm][0]) snprintf(pn[mm], 40, "conv_pers_bf16x3<9,2,4,2,2,%d>", mm);
         return pn[mm];
     }
+    {
+        ConvArgs q = a; q.taps = taps;
+        if (prec == 1 && taps == 9 && conv_pair_ok(q)) {      // the 16x16x32 tap-pair kernel (conv_pair_kernel.h)
+            static char pn[5][40];
+            const int mm = (a.mode < 0 || a.mode > 4) ? 0 : a.mode;
+            if (!pn[mm][0]) snprintf(pn[mm], 40, "conv_pair_bf16x3<%d>", mm);
+            return pn[mm];
+        }
+    }
     if (prec == 1 && taps == 9 && a.dual) {
         static char dn[5][40];
         const int mm = (a.mode < 0 || a.mode > 4) ? 2 : a.mode;

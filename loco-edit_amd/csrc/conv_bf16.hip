@@ -110,14 +110,14 @@ template <int PR, int MODE> void launch_pair_b(const ConvArgs& a, hipStream_t st
 
 // The 16x16x32 tap-pair kernel (conv_pair_kernel.h, round 6) takes the launches the 128 x 256 tile of the lock-step kernel would
 // take when the shape allows: 3x3, stride 1, padded arena input, whole 16-channel chunks in an even number, whole 128-cout tiles,
-// image rows a multiple of the 32-pixel tile width, no split-K, no K-concatenated shortcut.  LOCO_CONV_PAIR=1, diagnostics build.
+// image rows a multiple of the 32-pixel tile width, no split-K, no K-concatenated shortcut.  LOCO_CONV_PAIR=0: the 32x32x16 kernel.
 bool conv_pair_ok(const ConvArgs& a) {
-#ifndef LOCO_DIAG
-    return false;      // compiled into the diagnostics build only (`make diag`)
-#endif
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("LOCO_CONV_PAIR"); on = e ? (atoi(e) != 0) : 0; }
-    if (!on || a.taps != 9 || a.Cin2 > 0 || a.nsplit != 1 || a.stride != 1 || a.upsample || a.zins || a.pad != 1 || !a.in_padded ||
+    static int on = -1, minhw = -1;
+    if (on < 0) { const char* e = getenv("LOCO_CONV_PAIR"); on = e ? (atoi(e) != 0) : 1; }
+    // r06 (tests/diag/pair_check.py, 5 probes, 300 launches per number): -5.7 ... -6.2 % raw, -1.3 ... -5.6 % forward, -1.4 ... -4.0 %
+    // tangent / cotangent at 256^2 and 128^2; +-1 % at 64^2 (fewer, shorter tiles: its two-latency prologue shows) -> from 128^2 up
+    if (minhw < 0) { const char* e = getenv("LOCO_PAIR_MINHW"); minhw = e ? atoi(e) : 16384; }
+    if (!on || a.Hout * a.Wout < minhw || a.taps != 9 || a.Cin2 > 0 || a.nsplit != 1 || a.stride != 1 || a.upsample || a.zins || a.pad != 1 || !a.in_padded ||
         (a.Cin % (2 * BKC)) != 0 || (a.Cout % 128) != 0 || (a.Wout % 32) != 0 || (a.Hout % 8) != 0 || a.pers_groups || a.dual)
         return false;
     if (!(a.mode == CM_NONE || a.mode == CM_GN_SILU || a.mode == CM_TAN_SILU || a.mode == CM_COT_SILU)) return false;
@@ -289,7 +289,6 @@ static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
         }
     }
 #endif
-#ifdef LOCO_DIAG
     if constexpr (PR == PR_BF16X3) {
         if (taps == 9 && conv_pair_ok(a)) {
             switch (a.mode) {
@@ -301,7 +300,6 @@ static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
             return;
         }
     }
-#endif
     if (taps == 9) {
         switch (a.mode) {
             case CM_NONE: launch_tile_b<PR, 9, CM_NONE>(a, st); break;

@@ -99,6 +99,11 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
         }
     };
 
+    // the first three pairs leave BEFORE the per-thread index setup below: their L2 -> LDS latency runs under it
+    dma_pair(0, 0);
+    dma_pair(2, 1);
+    dma_pair(4, 2);
+
     // ---- halo staging item of this thread: 4 consecutive halo pixels x 4 channels (quarter chunk v_q4), as conv_lowp_body
     int v_q4 = (tid >> 3) & 3, v_cnt = 0, v_pos0 = -1;
     unsigned v_pm = 0;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
         f32x4 cq;
     };
     HaloRegs hr;
-    auto prefetch_hv = [&](const int chunk_raw, const int part) {
+    auto prefetch_hv = [&](HaloRegs& hr, const int chunk_raw, const int part) {
         const bool live = chunk_raw <= clast;
         const int chunk = __builtin_amdgcn_readfirstlane(live ? chunk_raw : clast);
         const unsigned cb = (unsigned)chunk * (64u * (unsigned)in_plane);
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
         }
     };
     // converts the part in `hr` into the piece planes of halo buffer Hd: channels c = v_q4 * 4 + part * 2 (+ 1) of 4 pixels
-    auto stage_hv = [&](unsigned char* const Hd, const int part, const int p0, const int p1) {
+    auto stage_hv = [&](const HaloRegs& hr, unsigned char* const Hd, const int part, const int p0, const int p1) {
         const int c0 = v_q4 * 4 + part * KP;
         unsigned char* const pl0 = Hd + (c0 >> 3) * PK_PLANE + (c0 & 7) * 2;
 #pragma unroll
@@ -221,23 +226,30 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
     auto horg = [](const int t) -> int { const int c = (t / 9) & 1, tp = t % 9; return c * PK_HBYTES + ((tp / 3) * PK_HW + tp % 3) * 16; };
     auto stage_end = [&](const int left_in_flight) {
         // everything issued before this stage has landed (the LDS-DMA of the previous stage; the part loads a later stage converts)
+#if defined(PKW_NODMA) || defined(PKW_NOLOAD)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (left_in_flight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 + NLD) : "memory");
+#endif
+#ifndef PKW_NOBAR      // what-if builds (timing only, results wrong): no stage barrier / no conversion / no LDS-DMA / no part loads
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
     };
 
-    // ---- prologue: pairs 0, 1, 2 of the weights, the whole first chunk's halo, part A of the second chunk in flight
-    dma_pair(0, 0);
-    dma_pair(2, 1);
-    dma_pair(4, 2);
-    prefetch_hv(0, 0);
-    stage_hv(Hsb, 0, 0, 4);
-    prefetch_hv(0, 1);
-    stage_hv(Hsb, 1, 0, 4);
+    // ---- prologue: (pairs 0, 1, 2 of the weights left above) the whole first chunk's halo, part A of the second chunk in flight
+    {
+        // both parts of the first chunk are loaded together (a second register set that only lives here): one memory latency, not two
+        HaloRegs hr2;
+        prefetch_hv(hr, 0, 0);
+        prefetch_hv(hr2, 0, 1);
+        stage_hv(hr, Hsb, 0, 0, 4);
+        stage_hv(hr2, Hsb, 1, 0, 4);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    prefetch_hv(1, 0);
+    prefetch_hv(hr, 1, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
@@ -255,14 +267,19 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
         const int slot = (g * 9 + S) & 3, nslot = (slot + 1) & 3;
         (void)SLOT; (void)NSLOT_;
         // weights three pairs ahead, into the slot of the pair that ran in the previous stage
-        dma_pair((g * 9 + S + 3) * 2, (slot + 3) & 3);
+        constexpr int CV = (S == 0) ? 0 : (S == 2) ? 1 : (S == 5) ? 2 : (S == 7) ? 3 : -1;      // conversion step of the group
+        // In a conversion stage the LDS-DMA is issued BEHIND the conversion: the compiler cannot count vmcnt past an LDS-DMA and
+        // drains it to 0 in front of the first use of the part's registers -- with the DMA at the top of the stage that is one full
+        // L2 -> LDS latency exposed in four of nine stages (what-if timing, r06_experiments.md section 6: 54 of 245 us)
+#ifndef PKW_NODMA
+        if (CV < 0) dma_pair((g * 9 + S + 3) * 2, (slot + 3) & 3);
+#endif
         const int hcur = sel ? horg(2 * S + 1) : horg(2 * S);        // this pair (the tail of its B fragments is read here)
         const int hnxt = sel ? horg(2 * S + 3) : horg(2 * S + 2);    // the next pair
         load_B(2, hcur);
         load_B(3, hcur);
         load_A(3, slot);
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int CV = (S == 0) ? 0 : (S == 2) ? 1 : (S == 5) ? 2 : (S == 7) ? 3 : -1;      // conversion step of the group
         const int c0 = 2 * g;
         unsigned char* const Hconv = Hsb + (CV < 2 ? PK_HBYTES : 0);      // parts of chunk c0 + 1 go to halo buffer 1, of chunk c0 + 2 to buffer 0
         // Tile order: the pair's B fragments 2, 3 (and A fragment 3) were requested at the top of this stage -- their registers were
@@ -270,20 +287,29 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
         // touches them.  A fragment i is re-read for the next pair as soon as row block i is issued, B fragments 0, 1 inside the
         // last row block; halo conversion (two pixels per region) and the next part's loads sit between.
         mma(0, 0); mma(0, 1); mma(1, 0); mma(1, 1);
-        if (CV >= 0) stage_hv(Hconv, CV & 1, 0, 2);
+#ifndef PKW_NOCONV
+        if (CV >= 0) stage_hv(hr, Hconv, CV & 1, 0, 2);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 2); mma(0, 3);
         __builtin_amdgcn_sched_barrier(0);
         load_A(0, nslot);
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 2); mma(1, 3);
-        if (CV >= 0) stage_hv(Hconv, CV & 1, 2, 4);
+#ifndef PKW_NOCONV
+        if (CV >= 0) stage_hv(hr, Hconv, CV & 1, 2, 4);
+#endif
+#ifndef PKW_NODMA
+        if (CV >= 0) { __builtin_amdgcn_sched_barrier(0); dma_pair((g * 9 + S + 3) * 2, (slot + 3) & 3); }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         load_A(1, nslot);
         __builtin_amdgcn_sched_barrier(0);
         mma(2, 0); mma(2, 1); mma(2, 2); mma(2, 3);
         // then the registers take the next part: B of the same chunk, or A of the chunk after
-        if (CV >= 0) prefetch_hv(c0 + 1 + (CV + 1) / 2, (CV + 1) & 1);
+#ifndef PKW_NOLOAD
+        if (CV >= 0) prefetch_hv(hr, c0 + 1 + (CV + 1) / 2, (CV + 1) & 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         load_A(2, nslot);
         __builtin_amdgcn_sched_barrier(0);

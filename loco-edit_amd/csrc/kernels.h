@@ -136,6 +136,8 @@ bool conv_gemm_plan(ConvArgs& a);
 // 3x3 launches whose (pixel tile, cout tile) grid is at least as wide as the chip, or divides it: persistent over the probes
 // (sets a.pers_groups; opt-in: LOCO_CONV_PERS=1 | 2, see conv_bf16.hip)
 bool conv_pers_plan(ConvArgs& a);
+// does the low-precision 3x3 launch `a` (taps, split-K, pers_groups, dual already decided) run on the 16x16x32 tap-pair kernel?
+bool conv_pair_ok(const ConvArgs& a);
 // can a launch with these arguments feed a.st_part from its epilogue?  (whole cout tiles of the chosen variant, no split-K)
 bool conv_lowp_can_fuse_stats(const ConvArgs& a);
 int conv_bf16_tile_couts(const ConvArgs& a);

@@ -23,6 +23,9 @@ def load(d, cn):
     return agg
 
 def norm(name):
+    m = re.match(r"void loco::(conv_pair_bf16x3)<(\d+)>\(", name)      # round 6: the 16x16x32 tap-pair kernel (same 64-byte-run halo loads)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
     m = re.match(r"void loco::(conv_mfma_\w+)<([\d, ]+?)(?:, (?:true|false))?>\(", name)
     if not m:
         return None
