@@ -237,6 +237,14 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
         __builtin_amdgcn_s_barrier();
 #endif
         asm volatile("" ::: "memory");
+#ifndef PKW_NOTIE
+        // Every fragment read issued so far has returned (the wait above).  The compiler cannot see an inline-asm wait: by its own
+        // count the reads of the previous stage are still pending, and it drains lgkmcnt to 0 in front of the next stage's first
+        // MFMA -- i.e. behind that stage's fresh tail reads: one exposed LDS latency per stage.  Passing the LIVE fragment registers
+        // (A 0 - 2, B 0 - 1: the others are dead here) through an empty asm makes them plain values again.
+        // (one statement: as five separate ones the tangent form spills seven registers)
+        asm volatile("" : "+v"(Ah[0]), "+v"(Al[0]), "+v"(Ah[1]), "+v"(Al[1]), "+v"(Ah[2]), "+v"(Al[2]), "+v"(Bh[0]), "+v"(Bl[0]), "+v"(Bh[1]), "+v"(Bl[1]));
+#endif
     };
 
     // ---- prologue: (pairs 0, 1, 2 of the weights left above) the whole first chunk's halo, part A of the second chunk in flight

@@ -816,7 +816,7 @@ def test_dual_probe_conv_tile_is_bit_identical_to_the_128x256_tile():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # (the tile lives in the diagnostics build; its epilogue takes the forward statistics only, so both settings run the tangent /
     # cotangent means as standalone passes: the comparison is about the conv kernel, bit for bit)
-    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1", LOCO_HIP_LIB=_diag_lib(), LOCO_FUSE_LIN="0")
+    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1", LOCO_HIP_LIB=_diag_lib(), LOCO_FUSE_LIN="0", LOCO_CONV_PAIR="0")      # (both settings against the 32x32x16 kernel)
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "dual_check.py"), "3"], env=env, capture_output=True,
                        text=True, timeout=900)
@@ -826,8 +826,9 @@ def test_dual_probe_conv_tile_is_bit_identical_to_the_128x256_tile():
 
 @pytest.mark.gpu
 def test_tap_pair_16x16x32_conv_kernel_matches_the_32x32x16_kernel():
-    """Round 6: the 3x3 kernel on v_mfma_f32_16x16x32_bf16 with K = two taps x 16 channels (csrc/conv_pair_kernel.h, diagnostics
-    build, LOCO_CONV_PAIR=1: piece-plane LDS images, LDS-DMA un-swizzling, fragments refilled in place) against the 32x32x16 kernel
+    """Round 6: the 3x3 kernel on v_mfma_f32_16x16x32_bf16 with K = two taps x 16 channels (csrc/conv_pair_kernel.h, the default
+    from 128 x 128 images up; LOCO_CONV_PAIR=0 switches it off: piece-plane LDS images, LDS-DMA un-swizzling, fragments refilled in
+    place) against the 32x32x16 kernel
     on a forward batch, J V and U^T J of 3 samples / probes at 256 x 256: the same products in another summation order (rel-L2 per
     output <= 3e-5: another summation order flips a fraction of the downstream split-bf16 roundings; the statistics in both settings as standalone passes so that only the conv kernel differs)."""
     import subprocess, sys
@@ -847,7 +848,7 @@ def test_persistent_conv_kernel_is_bit_identical_to_one_workgroup_per_tile():
     same products in the same order, the same bits (with 3 probes no launch of the default path splits a tail probe over K)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1", DUAL_CHECK_ON="2", LOCO_HIP_LIB=_diag_lib(), LOCO_FUSE_LIN="0")
+    env = dict(os.environ, DUAL_CHECK_SKIP_REPEAT="1", DUAL_CHECK_ON="2", LOCO_HIP_LIB=_diag_lib(), LOCO_FUSE_LIN="0", LOCO_CONV_PAIR="0")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "dual_check.py"), "3", "CELEBA_DDPM", "LOCO_CONV_PERS"],
                        env=env, capture_output=True, text=True, timeout=900)
