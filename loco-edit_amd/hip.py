@@ -66,7 +66,8 @@ def load_library():
     lib.loco_version.restype = C.c_char_p
     lib.loco_device_count.restype = C.c_int
     lib.loco_create.argtypes = [C.POINTER(LocoCfg), C.POINTER(vp)]
-    lib.loco_fork.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    if hasattr(lib, "loco_fork"):      # (a library of an earlier round, loaded by LOCO_HIP_LIB for an A/B: everything but fork works)
+        lib.loco_fork.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     lib.loco_destroy.argtypes = [vp]
     lib.loco_destroy.restype = None
     lib.loco_last_error.argtypes = [vp]
