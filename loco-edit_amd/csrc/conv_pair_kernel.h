@@ -209,9 +209,18 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
         Ah[i] = *reinterpret_cast<const s16x8*>(w);
         Al[i] = *reinterpret_cast<const s16x8*>(w + 512);
     };
-    // hsel = this lane's halo origin for the pair: buffer + tap shift of tap 0 (k-groups 0, 1) or tap 1 (k-groups 2, 3)
-    auto load_B = [&](const int j, const int hsel) {
-        const unsigned char* h = Hsb + hsel + hbl + ((j >> 1) * PK_HW + (j & 1) * 16) * 16;
+    // B fragment j of the pair whose first tap is group tap t0 (0 .. 18, even): k-groups 0, 1 read tap t0, k-groups 2, 3 tap t0 + 1.
+    // The second tap's halo origin lies 16 bytes further (next column), 512 (next kernel row: t0 % 9 = 2 or 5) or one buffer less 70
+    // positions (t0 = 8: first tap of the next chunk) -- three per-lane bases hbl + sel * that distance; everything else (buffer,
+    // tap shift of the first tap, column block, lo plane) is a compile-time immediate of the ds_read (r06 counters: per-stage selects
+    // and address adds made the kernel issue 27 % more vector instructions than the 32x32x16 kernel).
+    const unsigned char* const hb16 = Hsb + hbl + sel * 16;
+    const unsigned char* const hb512 = Hsb + hbl + sel * 512;
+    const unsigned char* const hbW = Hsb + hbl + sel * (PK_HBYTES - (2 * PK_HW + 2) * 16);
+    auto load_B = [&](const int j, const int t0) {
+        const int tp = t0 % 9;
+        const unsigned char* const base = tp == 8 ? hbW : ((tp % 3) == 2 ? hb512 : hb16);
+        const unsigned char* h = base + ((t0 / 9) & 1) * PK_HBYTES + ((tp / 3) * PK_HW + tp % 3) * 16 + ((j >> 1) * PK_HW + (j & 1) * 16) * 16;
         Bh[j] = *reinterpret_cast<const s16x8*>(h);
         Bl[j] = *reinterpret_cast<const s16x8*>(h + 2 * PK_PLANE);
     };
@@ -222,8 +231,6 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[i][j], 0, 0, 0);
     };
-    // byte offset (inside the two halo buffers) of the halo origin of group tap t (0 .. 19; 18, 19 = the next group's taps 0, 1)
-    auto horg = [](const int t) -> int { const int c = (t / 9) & 1, tp = t % 9; return c * PK_HBYTES + ((tp / 3) * PK_HW + tp % 3) * 16; };
     auto stage_end = [&](const int left_in_flight) {
         // everything issued before this stage has landed (the LDS-DMA of the previous stage; the part loads a later stage converts)
 #if defined(PKW_NODMA) || defined(PKW_NOLOAD)
@@ -260,13 +267,10 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
     prefetch_hv(hr, 1, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    {
-        const int hs = sel ? horg(1) : horg(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_A(i, 0);
+    for (int i = 0; i < 4; ++i) load_A(i, 0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) load_B(j, hs);
-    }
+    for (int j = 0; j < 2; ++j) load_B(j, 0);
 
     // ---- nine stages per two chunks
     auto stage = [&](auto stag, const int g) {
@@ -282,8 +286,7 @@ __global__ __launch_bounds__(PK_NTHR, 1) void conv_pair_bf16x3(ConvArgs a) {
 #ifndef PKW_NODMA
         if (CV < 0) dma_pair((g * 9 + S + 3) * 2, (slot + 3) & 3);
 #endif
-        const int hcur = sel ? horg(2 * S + 1) : horg(2 * S);        // this pair (the tail of its B fragments is read here)
-        const int hnxt = sel ? horg(2 * S + 3) : horg(2 * S + 2);    // the next pair
+        constexpr int hcur = 2 * S, hnxt = 2 * S + 2;      // first group tap of this pair (the tail of its B fragments is read here) / of the next
         load_B(2, hcur);
         load_B(3, hcur);
         load_A(3, slot);
