@@ -165,7 +165,7 @@ static ConvArgs conv_shift_batch(const ConvArgs& a, int nb) {
     if (t.tst) t.tst += (long)nb * a.tst_bs;
     if (t.tc) t.tc += (long)nb * a.tc_bs;
     if (t.in2) t.in2 += (long)nb * a.in2_bs;
-    if (t.cot_d) { t.cot_d += (long)nb * a.cot_d_bs; t.cot_tst += (long)nb * a.cot_tst_bs; }
+    if (t.cot_d) { t.cot_d += (long)nb * a.cot_d_bs; t.cot_tc += (long)nb * a.cot_tc_bs; }
     if (t.st_part) t.st_part += (long)nb * a.Cout * ((a.Hout * a.Wout) / conv_bf16_tile_pixels(a)) * 2;
     return t;
 }
@@ -223,8 +223,8 @@ bool conv_gemm_plan(ConvArgs& a) {
     a.gemm = 0;
     const long HW = (long)a.Hout * a.Wout;
     if (!on || a.stride != 1 || a.upsample || a.zins || (a.Cin % BKC) != 0 || a.Cin < 320 || (HW % 256) != 0 || (a.Wout % 16) != 0 ||
-        a.Cout < 128 || !a.partial || a.Cin2 > 0 || !(a.mode == CM_NONE || a.mode == CM_GN))
-        return false;
+        a.Cout < 128 || !a.partial || a.Cin2 > 0 || !(a.mode == CM_NONE || a.mode == CM_GN) || a.cot_d)
+        return false;      // (cot_d: the norm-cotangent term lives in the per-pixel 1x1 kernels' epilogue; this kernel's takes neither it nor statistics)
     {   // the kernel's 256-pixel tile is TW = min(Wout, 32) columns x 256 / TW rows: both must divide the map (a 48 x 48 map passes
         // the tests above and would be walked out of bounds: ADVICE r05)
         const int TW = a.Wout < 32 ? a.Wout : 32;
@@ -244,15 +244,10 @@ bool conv_gemm_plan(ConvArgs& a) {
     if (force_tm < 0) { const char* e = getenv("LOCO_GEMM_TM"); force_tm = e ? atoi(e) : 0; }
     if (no_split < 0) { const char* e = getenv("LOCO_GEMM_NOSPLIT"); no_split = e ? atoi(e) : 0; }
     int tm = force_tm ? force_tm : ((pad256 * 10 <= a.Cout * 11) ? 4 : 2);
-    // a caller that put the norm-cotangent term into this launch's epilogue (ConvArgs::cot_d) did so for ONE unsplit launch of
-    // whole 128-cout tiles: keep exactly that
-    const bool pinned = a.cot_d != nullptr;
-    if (pinned) { if ((a.Cout % 128) != 0) return false; if ((a.Cout % (64 * tm)) != 0) tm = 2; }
     const int mt = 64 * tm;
     const long tiles = (HW / 256) * ((a.Cout + mt - 1) / mt) * a.B;
     const size_t rec_floats = (size_t)a.B * a.Cin * HW;
     int ns = 1;
-    if (tiles < 192 && pinned) return false;
     if (tiles < 192 && !no_split) {
         const int nchunks = a.Cin / BKC;
         ns = (int)((256 + tiles - 1) / tiles);

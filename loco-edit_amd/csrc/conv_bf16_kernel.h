@@ -150,14 +150,19 @@ __device__ __forceinline__ void rs_reduce(float* av, const int lane) {
 // D[row = cout][col = pixel]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 // `stage_round(h, S)`: the wave's accumulator values of write-out round h (cout rows (wm * TM + h) * 32 ... + 31 of the tile) into
 // the staging image S[WM * 32][NT] -- the one place that knows the accumulator layout (conv_pair_kernel.h passes its own)
-template <int WM, int WN, int TM, int TN, class StageRound>
+// EPI: what of the epilogue's optional work is compiled in (its registers are live across the staging round trip either way).
+// EPI_COT1: the norm-cotangent term of a 1x1 operator (ConvArgs::cot_d) -- the per-pixel 1x1 kernels only: the engine puts it
+// into ResBlock shortcut operators; EPI_STATS: the statistics sinks (ConvArgs::st_part) -- not the DMA-fed GEMM, whose launches
+// never carry one (conv_lowp_can_fuse_stats)
+constexpr int EPI_COT1 = 1, EPI_STATS = 2;
+template <int WM, int WN, int TM, int TN, int EPI = EPI_STATS, class StageRound>
 __device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, StageRound&& stage_round, unsigned char* smem_b, const int co0,
                                                           const int oy0, const int ox0, const int TW, const int tile_id, const int b,
                                                           const int split);
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_lowp_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TM][TN], const int co0, const int oy0,
                                                           const int ox0, const int TW, const int b, const int split);
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int EPI = EPI_STATS>
 __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem_b, const int co0,
                                                    const int oy0, const int ox0, const int TW, const int tile_id, const int b,
                                                    const int split) {
@@ -165,7 +170,7 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, khalf = lane >> 5, wm = wave / WN, wn = wave % WN;
     if (co0 + WM * TM * 32 <= a.Cout) {
-        conv_lowp_epilogue_staged<WM, WN, TM, TN>(a, [&](const int h, float* S) {      // (h is a constant after unrolling)
+        conv_lowp_epilogue_staged<WM, WN, TM, TN, EPI>(a, [&](const int h, float* S) {      // (h is a constant after unrolling)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -176,11 +181,12 @@ __device__ __forceinline__ void conv_lowp_epilogue(const ConvArgs& a, f32x16 (&a
     }
     conv_lowp_epilogue_direct<WM, WN, TM, TN>(a, acc, co0, oy0, ox0, TW, b, split);
 }
-template <int WM, int WN, int TM, int TN, class StageRound>
+template <int WM, int WN, int TM, int TN, int EPI, class StageRound>
 __device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, StageRound&& stage_round, unsigned char* smem_b, const int co0,
                                                           const int oy0, const int ox0, const int TW, const int tile_id, const int b,
                                                           const int split) {
     constexpr int NTHR = WM * WN * 64;
+    constexpr bool COT1 = (EPI & EPI_COT1) != 0, STATS = (EPI & EPI_STATS) != 0;
     constexpr int MT = WM * TM * 32;
     constexpr int NT = WN * TN * 32;
     const int tid = threadIdx.x;
@@ -206,13 +212,19 @@ __device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, Sta
         const float* const b2 = (!part && a.bias2) ? a.bias2 + (long)b * a.bias2_bs : nullptr;
         const float* const b1 = part ? nullptr : a.bias;
         const bool accu = !part && a.accumulate;
-        const int twsh = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
+        const int twsh = 31 - __builtin_clz((unsigned)TW);      // (a power of two)
         // Tangent / cotangent group means of the finished tile (round 6, below): what they need of the primal under the round's rows
         // -- tangent: x of the output tensor (4 bytes per element); cotangent: the consuming norm's cached {S, xhat} records (8
         // bytes: no transcendental per element here) -- is requested at the top of each round, ahead of its LDS round trip, residual
         // loads and stores (shared by the probes of the tile on one XCD: served by its L2), and used after the round's stores
-        const bool lin_st = (a.st_kind == ST_TAN || a.st_kind == ST_COT) && !part;
+        const bool lin_st = STATS && (a.st_kind == ST_TAN || a.st_kind == ST_COT) && !part;
         const bool lin_cot = a.st_kind == ST_COT;
+        // Norm-cotangent term (ConvArgs::cot_d; 1x1 operators): its operands -- the cotangent behind the norm (4 bytes per element),
+        // the norm's {S, xhat} records (8, shared by the tile's probes) and the channel's {rstd m1, rstd m2} -- are requested at the
+        // top of the round as well, into the registers the statistics' records use (a launch has one of the two)
+        const bool cot_ep = COT1 && a.cot_d && !part && !lin_st;
+        const float* const cot_db = cot_ep ? a.cot_d + (long)b * a.cot_d_bs : nullptr;
+        const f32x2* const cot_tb = cot_ep ? reinterpret_cast<const f32x2*>(a.cot_tc + (long)b * a.cot_tc_bs) : nullptr;
         // Task q of a round = staging row q * RSTEP + row0, pixels 4 * quad0 ... + 3: the lane's (row0, quad0) are fixed, the task
         // adds a compile-time row count -- cout and tensor offset of a task are one per-lane base plus a wave-uniform term (scalar
         // arithmetic), not per-task registers held across the round
@@ -226,7 +238,7 @@ __device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, Sta
             return (unsigned)(co0 + row0) * (unsigned)out_plane + pix0 + crow * (unsigned)out_plane;
         };
         constexpr int NV = 2 * TM * NTASK;                 // row sums per lane: {s1, s2} per (round, task)
-        float av[NV];
+        float av[STATS ? NV : 1];
 #pragma unroll
         for (int h = 0; h < TM; ++h) {
             if (h > 0) {                                   // the previous round's read-back is done in every wave
@@ -235,8 +247,21 @@ __device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, Sta
             }
             stage_round(h, S);
             // (requested here: the round's accumulator registers are free, the loads fly under the LDS round trip)
-            f32x4 xs[NTASK][2];                            // tangent: [q][0] = x of 4 pixels; cotangent: {S0,x0,S1,x1}, {S2,x2,S3,x3}
-            if (lin_st) {
+            f32x4 xs[(STATS || COT1) ? NTASK : 1][2];      // tangent: [q][0] = x of 4 pixels; cotangent: {S0,x0,S1,x1}, {S2,x2,S3,x3}
+            f32x4 cd[COT1 ? NTASK : 1];
+            if constexpr (COT1) {
+                if (cot_ep) {
+#pragma unroll
+                    for (int q = 0; q < NTASK; ++q) {
+                        const unsigned o = off_of(h, q);
+                        cd[q] = *reinterpret_cast<const f32x4*>(cot_db + o);
+                        const f32x4* sp4 = reinterpret_cast<const f32x4*>(a.cot_sx + o);
+                        xs[q][0] = sp4[0];
+                        xs[q][1] = sp4[1];
+                    }
+                }
+            }
+            if constexpr (STATS) if (lin_st) {
 #pragma unroll
                 for (int q = 0; q < NTASK; ++q) {
                     const unsigned o = off_of(h, q);
@@ -265,27 +290,16 @@ __device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, Sta
 #pragma unroll
                 for (int q = 0; q < NTASK; ++q) v[q] += rv[q];
             }
-            if (a.cot_d && !part) {
-                // norm-cotangent term of the tensor this conv finishes (kernels.h ConvArgs::cot_d): a task row is one channel,
-                // its constants are wave-uniform per group of NQ lanes
-                const float* const db = a.cot_d + (long)b * a.cot_d_bs;
-                const float* const tb = a.cot_tst + (long)b * a.cot_tst_bs;
+            if constexpr (COT1) {
+                if (cot_ep) {      // out += S d - (rstd m1 + xhat rstd m2): a task row is one channel
 #pragma unroll
-                for (int q = 0; q < NTASK; ++q) {
-                    const int co = co_of(h, q), g = co / a.cot_cpg;
-                    const float scc = a.cot_sc[co], shc = a.cot_sh[co];
-                    const float mean = a.cot_mr[2 * g], rstd = a.cot_mr[2 * g + 1];
-                    const float m1 = tb[2 * g], m2 = tb[2 * g + 1];
-                    const f32x4 dv = *reinterpret_cast<const f32x4*>(db + off_of(h, q));
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.cot_x + off_of(h, q));
-                    const float gm = scc / rstd;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float y = fmaf(scc, xv[j], shc);
-                        const float sg = 1.0f / (1.0f + __expf(-y));
-                        const float ds = sg * (1.0f + y * (1.0f - sg));               // silu'(y)
-                        const float xh = (xv[j] - mean) * rstd;
-                        v[q][j] += rstd * (gm * ds * dv[j] - m1 - xh * m2);
+                    for (int q = 0; q < NTASK; ++q) {
+                        const f32x2 tc2 = cot_tb[co_of(h, q)];      // (one per channel: L2, not worth eight register pairs across the round trip)
+                        const float c1 = tc2[0], c2 = tc2[1];
+                        v[q][0] += fmaf(xs[q][0][0], cd[q][0], -fmaf(xs[q][0][1], c2, c1));
+                        v[q][1] += fmaf(xs[q][0][2], cd[q][1], -fmaf(xs[q][0][3], c2, c1));
+                        v[q][2] += fmaf(xs[q][1][0], cd[q][2], -fmaf(xs[q][1][1], c2, c1));
+                        v[q][3] += fmaf(xs[q][1][2], cd[q][3], -fmaf(xs[q][1][3], c2, c1));
                     }
                 }
             }
@@ -297,7 +311,7 @@ __device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, Sta
                 v[q] += add;
                 __builtin_nontemporal_store(v[q], reinterpret_cast<f32x4*>(ob + off_of(h, q)));   // streamed once: keep L2 for the shared primal cache / weights
             }
-            if (lin_st) {      // the lane's share of the round's row sums (see behind the round loop)
+            if constexpr (STATS) if (lin_st) {      // the lane's share of the round's row sums (see behind the round loop)
 #pragma unroll
                 for (int q = 0; q < NTASK; ++q) {
                     const f32x4 vv = v[q];
@@ -321,7 +335,7 @@ __device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, Sta
             // butterfly over the row's lanes, one lane writes {mean, M2} of the row tile.  (The tangent / cotangent means:
             // behind the round loop.  Round 4 tried them here from the {S, xhat} records of the output tile -- 8 more bytes per
             // element read in the latency-exposed round, 9-26 us per launch against the 16-21 us of the standalone pass.)
-            if (a.st_kind == ST_FWD && !part) {
+            if (STATS && a.st_kind == ST_FWD && !part) {
                 const int ntile = (a.Hout * a.Wout) / NT;
                 float* const sp = a.st_part + (long)b * a.Cout * ntile * 2;
 #pragma unroll
@@ -348,7 +362,7 @@ __device__ __forceinline__ void conv_lowp_epilogue_staged(const ConvArgs& a, Sta
         // primal cache (gn_lin_fused_finalize divides by rstd: z = (sc / rstd) act'(y) g = S g / rstd, what gn_tstats_partial<1> sums).  Replaces that kernel's pass over the tensor (reference op: the
         // GroupNorm inside jvp / vjp, models/ddpm/diffusion.py:810-811 under edit.py:2455,2479).  Every round left the lane's share
         // of its row sums in av[]; all 2 x TM x NTASK of them go through ONE recursive-halving reduction over the row's NQ lanes.
-        if (lin_st) {
+        if constexpr (STATS) if (lin_st) {
             constexpr int LW = NQ < 64 ? NQ : 64, STEPS = rs_steps(NV, LW), LEFT = NV >> STEPS;
             static_assert((NV & (NV - 1)) == 0, "row sums per lane");
             rs_reduce<NV, 1, LW>(av, lane);
@@ -596,7 +610,13 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
     const int wm = wave / WN, wn = wave % WN;
 
     const int S = a.stride;
-    const int TW = a.Wout < 32 ? a.Wout : 32;
+    // Pixel tile: TW x NT / TW pixels, TW = 32 columns (or the image width when smaller) -- except for a pointwise operator at
+    // stride 1, which has no halo to keep compact: its tile is NT CONSECUTIVE pixels of the plane (whole image rows, or a run
+    // inside one), so every channel of the tile is one contiguous run for the staging loads, the write-out and the epilogue's
+    // operand streams instead of NT / 32 segments of 128 bytes (same bits; these launches are bound by memory: -3 ... -4 %)
+    // (image widths that are a power of two: the run then divides the tile or the row)
+    const int TW = (TAPS == 1 && PHASE == 0 && a.stride == 1 && !a.upsample && !a.zins && (a.Wout & (a.Wout - 1)) == 0)
+                       ? (a.Wout < NT ? a.Wout : NT) : (a.Wout < 32 ? a.Wout : 32);
     const int TH = NT / TW;
     const int tiles_x = a.Wout / TW;
     // Block order: the probes (and K-splits) of one (pixel tile, cout tile) are adjacent in dispatch order
@@ -1500,20 +1520,26 @@ __device__ __forceinline__ void conv_lowp_body(const ConvArgs& a, f32x16 (&acc)[
         return;
     }
     LP_STAMP(3);
-    conv_lowp_epilogue<WM, WN, TM, TN>(a, acc, smem_b, co0, oy0, ox0, TW, tile_id, b, split);
+    conv_lowp_epilogue<WM, WN, TM, TN, (TAPS == 1 && PHASE == 0) ? (EPI_COT1 | EPI_STATS) : EPI_STATS>(a, acc, smem_b, co0, oy0, ox0, TW, tile_id, b, split);
     LP_STAMP(4);
 #undef LP_STAMP
 }
 
 // ---------------------------------------------------------------------------
 // Kernel entry points: one name per arithmetic so profiles tell them apart.
+// Waves per SIMD the register allocation has to leave room for.  The four-wave (256-thread) tiles of the 1x1 operators count on TWO
+// workgroups per CU -- one's write-out under the other's stage loop; these launches are bound by memory latency, not by the matrix
+// pipe -- and a four-wave workgroup alone only asks for one wave per SIMD: without the bound the allocator took 304 registers
+// (240 + 64 accumulation registers) once the epilogue carried the tangent / cotangent sums (round 6), i.e. ONE workgroup per CU
+// (128 -> 256 @256^2 with the norm-cotangent term: 375 -> 500 us in the flow).  STG 3: the compact 3x3 tile built for two per CU.
+constexpr int lowp_min_waves(int taps, int nthr, int stg) { return (stg == 3 || (taps == 1 && nthr <= 256)) ? 2 : 1; }
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
-__global__ __launch_bounds__(WM * WN * 64, STG == 3 ? 2 : 1) void conv_mfma_bf16x3(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, lowp_min_waves(TAPS, WM * WN * 64, STG)) void conv_mfma_bf16x3(ConvArgs a) {
     f32x16 acc[TM][TN];
     conv_lowp_body<PR_BF16X3, TAPS, WM, WN, TM, TN, MODE, STG>(a, acc);
 }
 template <int TAPS, int WM, int WN, int TM, int TN, int MODE, int STG>
-__global__ __launch_bounds__(WM * WN * 64, STG == 3 ? 2 : 1) void conv_mfma_f16(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, lowp_min_waves(TAPS, WM * WN * 64, STG)) void conv_mfma_f16(ConvArgs a) {
     f32x16 acc[TM][TN];
     conv_lowp_body<PR_F16, TAPS, WM, WN, TM, TN, MODE, STG>(a, acc);
 }

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_bf16x3(ConvArgs a, const uns
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    conv_lowp_epilogue<WM, WN, TM, TN>(a, acc, smem_b, co0, oy0, ox0, TW, tile_id, b, split);
+    conv_lowp_epilogue<WM, WN, TM, TN, 0>(a, acc, smem_b, co0, oy0, ox0, TW, tile_id, b, split);      // (no statistics sink, no norm-cotangent term: conv_gemm_plan)
 }
 
 void launch_conv_gemm(const ConvArgs& a, hipStream_t st);      // conv_bf16_inst_j.hip

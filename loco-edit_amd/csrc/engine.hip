@@ -2439,10 +2439,11 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                         t.nsplit = conv_bf16_pick_nsplit(n.Cin, n.Cout, n.Hout, n.Wout, n.B, c->chip_share);
                         const long per_probe = (long)((n.Hout * n.Wout) / conv_bf16_tile_pixels(t)) * ((n.Cout + 127) / 128);
                         const long total = per_probe * n.B, r = total % 256;
-                        if (t.nsplit == 1 && (total <= 256 || r == 0 || r > 160) && conv_lowp_can_fuse_stats(t)) {
-                            n.cot_d = TG(op.a1); n.cot_d_bs = PS; n.cot_x = TP(op.in);
-                            n.cot_sc = sp.sc; n.cot_sh = sp.sh; n.cot_mr = sp.mr;
-                            n.cot_tst = stt.tst; n.cot_tst_bs = c->stats_per_sample; n.cot_cpg = ti.C / G;
+                        if (t.nsplit == 1 && (total <= 256 || r == 0 || r > 160) && conv_lowp_can_fuse_stats(t) && op.n1.sx_off >= 0 &&
+                            c->sxcache) {
+                            // (from norm1's {S, xhat} records and the per-channel {rstd m1, rstd m2} its cotangent statistics left)
+                            n.cot_d = TG(op.a1); n.cot_d_bs = PS; n.cot_sx = c->sxcache + op.n1.sx_off;
+                            n.cot_tc = stt.tc; n.cot_tc_bs = c->stats_per_sample;
                             cot_in_epilogue = true;
                         }
                     }
@@ -3370,6 +3371,15 @@ int loco_bench_conv(loco_ctx* c, int32_t cin, int32_t cout, int32_t H, int32_t W
     if (a.cpg < 1) a.cpg = 1;
     a.nsplit = 1; a.partial = c->partial;
     a.partial_floats = c->partial_floats - wfl * 2;                            // (the synthetic weights sit at the end of the workspace)
+    if (getenv("LOCO_BENCH_COT") && atoi(getenv("LOCO_BENCH_COT")) && taps == 1) {
+        // the ResBlock shortcut's cotangent form: norm-cotangent term in the epilogue (synthetic operands behind the output tensor)
+        if ((in_e + 2 * out_e) * B > (long)c->cfg.max_batch * c->per_sample || out_e > c->sx_total ||
+            2L * cout > c->stats_per_sample) { c->err = "bench_conv: cot operands exceed the arenas"; return -2; }
+        launch_fill_random(out + out_e * B, out_e * B, 8u, zs, st);
+        if (out_e > in_e) launch_fill_random(reinterpret_cast<float*>(c->sxcache), 2 * out_e, 3u, zs, st);
+        a.cot_d = out + out_e * B; a.cot_d_bs = out_e; a.cot_sx = c->sxcache; a.cot_tc = c->statsT; a.cot_tc_bs = c->stats_per_sample;
+    }
+    if (getenv("LOCO_BENCH_ACC") && atoi(getenv("LOCO_BENCH_ACC"))) a.accumulate = 1;
     if (c->prec == 1 && taps == 1) conv_gemm_plan(a);
     if (c->prec == 1 && taps == 9) conv_pers_plan(a);
     if (const char* e = getenv("LOCO_DUAL_WHATIF")) a.no_deep = atoi(e);      // stamp build of the dual tile only (bits 2 / 4)

@@ -101,13 +101,15 @@ struct ConvArgs {
     // accumulated into the same output tile; its bias travels in `bias2` (bias2_bs = 0).  Cin2 == 0: none.
     const float* in2; long in2_bs; int Cin2; int in2_padded;
     const void* wb2;
-    // Norm-cotangent term added in the epilogue (conv_lowp_epilogue, whole cout tiles, no split-K): the cotangent of a
-    // GroupNorm + SiLU whose INPUT is this conv's output tensor,  out += rstd * ((sc / rstd) silu'(sc x + sh) d - m1 - xhat m2)
-    // with d = cot_d (cotangent behind the norm, [B][Cout][H][W]), x = cot_x (primal input of the norm, B = 1), per-channel
-    // cot_sc / cot_sh, per-group {mean, rstd} cot_mr and {m1, m2} cot_tst -- what gn_apply_kernel<2> computes as its own
-    // pass over the tensor (ResBlock cotangent: g_in = nin^T g_out + norm1^T g_a1 in one write-out).  nullptr: none.
-    const float* cot_d; long cot_d_bs; const float* cot_x;
-    const float* cot_sc; const float* cot_sh; const float* cot_mr; const float* cot_tst; long cot_tst_bs; int cot_cpg;
+    // Norm-cotangent term added in the epilogue of a 1x1 operator (conv_lowp_epilogue, whole cout tiles, no split-K): the cotangent
+    // of a GroupNorm + activation whose INPUT is this conv's output tensor,
+    //     out += S d - (rstd m1 + xhat rstd m2)
+    // with d = cot_d (cotangent behind the norm, [B][Cout][H][W]), {S = sc act'(sc x + sh), xhat} = cot_sx (that norm's primal cache
+    // records over the output tensor, B = 1: no transcendental per element here, and the probes of a tile share the records through
+    // L2) and {rstd m1, rstd m2} = cot_tc per (sample, channel) (what the cotangent statistics leave for the conv staging) -- what
+    // gn_apply_kernel<2> computes as its own pass over the tensor (ResBlock cotangent: g_in = nin^T g_out + norm1^T g_a1 in one
+    // write-out).  nullptr: none.
+    const float* cot_d; long cot_d_bs; const float2* cot_sx; const float* cot_tc; long cot_tc_bs;
     int act;           // ActKind of the prologue modes (exact-fp32 kernel, split-K statistics epilogue)
     float res_scale;   // out = conv + bias + res_scale * res  (DeepFloyd-IF: (x + h) / sqrt 2 with the conv's weights pre-scaled); conv_defaults: 1
     int dual;          // 1: run on the dual-probe tile of conv_dual_kernel.h (B even; set by conv_lowp_plan, never by the engine)

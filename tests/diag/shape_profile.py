@@ -23,5 +23,8 @@ rep = eng.profile_report()
 eng.profile_enable(False)
 tot = sum(v["ms"] for v in rep.values())
 print(f"conv total {tot:.2f} ms for one JVP+VJP (k=5)")
-for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:45]:
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 45      # rows; argv[2]: substring filter on the key ("|t1_" = the 1x1 maps)
+F = sys.argv[2] if len(sys.argv) > 2 else ""
+if F: print(f"rows matching {F!r}: {sum(v['ms'] for k, v in rep.items() if F in k):.2f} ms")
+for k, v in [kv for kv in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]) if F in kv[0]][:N]:
     print(f"{k:80s} n={v['launches']:3d} ms={v['ms']:7.3f} ({100*v['ms']/tot:4.1f}%) {v['flops']/v['ms']/1e9:7.1f} TF/s")

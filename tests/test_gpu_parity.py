@@ -1110,6 +1110,17 @@ def test_tangent_and_cotangent_means_fused_into_conv_epilogues_equal_the_standal
         assert torch.equal(outs["1"][i], outs["0"][i])
 
 
+@pytest.mark.parametrize("cfg", [_fused_cfgs()[1], _fused_cfgs()[3]], ids=["mid", "celeba256"])
+def test_norm_cotangent_term_in_the_shortcut_operators_epilogue_equals_the_standalone_pass(cfg, monkeypatch):
+    """ResBlock cotangent g_in = nin^T g_out + norm1^T g_a1 (models/ddpm/diffusion.py:887-912 under edit.py:2479): the second term
+    is added in the 1x1 shortcut operator's epilogue from norm1's {S, xhat} records and the per-channel {rstd m1, rstd m2}
+    (ConvArgs::cot_d) instead of gn_apply_kernel<2>'s read-modify-write pass over g_in; LOCO_FUSE_COT=0 runs that pass.  The
+    switch touches the cotangent pass only."""
+    errs, outs = _fused_vs_standalone(cfg, "LOCO_FUSE_COT", monkeypatch)
+    for i in (0, 1, 2, 4, 6, 7, 8, 10):
+        assert torch.equal(outs["1"][i], outs["0"][i])
+
+
 def _fused_vs_standalone(cfg, envname, monkeypatch):
     """The GroupNorm statistics a conv's consumer needs (forward mean / rstd, tangent and cotangent group means) are taken
     in the split-K epilogue (one kernel instead of reduce + statistics) or, the forward ones of un-split convs, in the
