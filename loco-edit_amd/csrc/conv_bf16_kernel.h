@@ -1598,8 +1598,10 @@ static void launch_one_b2(const ConvArgs& a, hipStream_t st) {
         }
     }
 #endif
-    auto kern = PR == PR_F16 ? &conv_mfma_f16<TAPS, WM, WN, TM, TN, MODE, STG>
-                             : &conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;
+    // (if constexpr: a ?: of the two addresses instantiates BOTH arithmetics' kernels in every translation unit)
+    void (*kern)(ConvArgs);
+    if constexpr (PR == PR_F16) kern = &conv_mfma_f16<TAPS, WM, WN, TM, TN, MODE, STG>;
+    else kern = &conv_mfma_bf16x3<TAPS, WM, WN, TM, TN, MODE, STG>;
     if (lds > 64 * 1024) {
         static DeviceOnce once;
         if (first_on_device(once)) {
@@ -1635,7 +1637,9 @@ void launch_kcat_b(const ConvArgs& a, hipStream_t st) {
     // LDS of the 3x3 phase (three weight stages + two halo buffers); the 1x1 phase and the epilogue tile fit inside it
     size_t lds = (size_t)3 * 3 * MT * rec_bytes<PR>() + 2 * ((size_t)(TW + 2) * (TH + 2) + NDUMMY) * halo_pitch<PR>();
     dim3 grid(((a.Hout * a.Wout) / NT) * ((a.Cout + MT - 1) / MT) * a.B * a.nsplit);
-    auto kern = PR == PR_F16 ? &conv_kcat_f16<WM, WN, TM, TN, MODE> : &conv_kcat_bf16x3<WM, WN, TM, TN, MODE>;
+    void (*kern)(ConvArgs);
+    if constexpr (PR == PR_F16) kern = &conv_kcat_f16<WM, WN, TM, TN, MODE>;
+    else kern = &conv_kcat_bf16x3<WM, WN, TM, TN, MODE>;
     static DeviceOnce once;
     if (first_on_device(once))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
