@@ -1402,7 +1402,8 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
         // opt-in persistent / dual-probe kernels (their epilogues take the forward statistics only).  A tangent launch that finishes
         // one part of a concatenation keeps its (norm-independent) raw sums in the part's buffer, at this lane's samples.
         const bool cot_cache = rq->kind == ST_COT && rq->n && rq->n->sx_off >= 0 && c->sxcache;      // (its {S, xhat} records exist)
-        if ((rq->kind == ST_TAN || cot_cache) && c->fuse_lin && conv_lowp_can_fuse_stats(x) && !x.pers_groups && !conv_dual_ok(x)) {
+        // (not next to a norm-cotangent term: the epilogue holds one of the two in its record registers, ConvArgs::cot_d)
+        if ((rq->kind == ST_TAN || cot_cache) && c->fuse_lin && !x.cot_d && conv_lowp_can_fuse_stats(x) && !x.pers_groups && !conv_dual_ok(x)) {
             const size_t lane_off = (size_t)c->lane_s0 * x.Cout * ntile * 2;
             const bool keptl = rq->kind == ST_TAN && rq->keep && s0 == 0 && x.B == a.B && lane_off + need <= rq->keep_floats;
             if (keptl || (rq->n && need <= c->stpart_floats)) {
