@@ -31,9 +31,17 @@ int conv_bf16_pick_tile(int Cout, int HW, int B) {
 
 // split-K factor for the split-bf16 kernels: splitting costs a partial round trip + a reduce launch, so only
 // split when the un-split grid would leave more than half of the CUs idle
-int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip_share) {
+static int conv_1x1_tile0_maxhw();
+int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip_share, int taps) {
     const int HW = Hout * Wout;
     int t = conv_bf16_pick_tile(Cout, HW, B);
+    if (t == 4) t = 5;
+    static int taps_aware = -1, use_ceil = -1, minch = -1;      // A/B switches of the round-6 rule below
+    if (taps_aware < 0) { const char* e = getenv("LOCO_SPLITK_TAPS"); taps_aware = e ? atoi(e) : 1; }
+    if (use_ceil < 0) { const char* e = getenv("LOCO_SPLITK_CEIL"); use_ceil = e ? atoi(e) : 0; }
+    if (minch < 0) { const char* e = getenv("LOCO_SPLITK_MINCH"); minch = e ? atoi(e) : 4; if (minch < 1) minch = 1; }
+    // (the 1x1 operators' 128 x 128 tile: bf16_tile_of -- twice the workgroups of the 128 x 256 tile this count assumed until round 6)
+    if (taps_aware && taps == 1 && t == 5 && B >= 2 && HW <= conv_1x1_tile0_maxhw()) t = 0;
     static const int MTs[7] = {128, 128, 32, 64, 128, 128, 128}, NTs[7] = {128, 64, 128, 64, 256, 256, 128};
     long blocks = (long)(HW / NTs[t]) * ((Cout + MTs[t] - 1) / MTs[t]) * B;
     int nchunks = (Cin + BKC - 1) / BKC;
@@ -46,8 +54,11 @@ int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip
     int target = target_env > 0 ? target_env : 256 / (chip_share > 1 ? chip_share : 1);
     if (target < 32) target = 32;
     if (blocks >= target / 2 || nchunks < 8) return 1;
-    int want = (int)((target + blocks - 1) / blocks);
-    int maxs = nchunks / 4;
+    // Round 6: the LARGEST factor whose workgroups still fit the target in one round (floor).  The rounded-up quotient put 20 tiles x
+    // 13 splits = 260 workgroups on 256 CUs (1024 -> 512 @16^2, 5 probes): four of them ran as a second round of a launch whose
+    // workgroups hold one CU each, and 86 - 127 tiles got 3 splits = two rounds of thirds instead of one round of halves.
+    int want = use_ceil ? (int)((target + blocks - 1) / blocks) : (int)(target / blocks);
+    int maxs = nchunks / minch;
     if (want > maxs) want = maxs;
     if (want > 32) want = 32;
     return want < 1 ? 1 : want;

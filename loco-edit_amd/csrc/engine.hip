@@ -1345,7 +1345,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     if (c->prec == 2) a.wb = a.wh;
     a.taps = taps;
     a.no_deep = c->deep1 ? 0 : 1;
-    a.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, c->chip_share)
+    a.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, c->chip_share, taps)
                             : conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
     if (a.nsplit < 1) a.nsplit = 1;
@@ -2437,7 +2437,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                         // a read-modify-write pass of gn_apply_kernel<2> over g_in -- one unsplit launch of whole cout tiles only
                         ConvArgs t = n;
                         t.taps = 1;
-                        t.nsplit = conv_bf16_pick_nsplit(n.Cin, n.Cout, n.Hout, n.Wout, n.B, c->chip_share);
+                        t.nsplit = conv_bf16_pick_nsplit(n.Cin, n.Cout, n.Hout, n.Wout, n.B, c->chip_share, 1);
                         const long per_probe = (long)((n.Hout * n.Wout) / conv_bf16_tile_pixels(t)) * ((n.Cout + 127) / 128);
                         const long total = per_probe * n.B, r = total % 256;
                         if (t.nsplit == 1 && (total <= 256 || r == 0 || r > 160) && conv_lowp_can_fuse_stats(t) && op.n1.sx_off >= 0 &&
