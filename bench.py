@@ -709,7 +709,8 @@ def main():
         if world == 1:
             try:
                 w4 = make_workload("tloco_sd15", a.precision)
-                el, (_, s4, vT4, _) = timed(w4["step"], 1, 1)
+                el2, (_, s4, vT4, _) = timed(w4["step"], 2, 1)      # two timed steps: single steps of this two-context workload scatter
+                el = el2 / 2
                 Fu, Fd = w4["eng"].unet_flops(), w4["dec"].unet_flops()
                 extra["tloco_sd15"] = {
                     "value": round(w4["k"] / el, 4), "unit": "edit-directions/s (top-5 basis, decoded-image Jacobian w.r.t. the latent)",

@@ -53,6 +53,7 @@ int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip
     if (target_env < 0) { const char* e = getenv("LOCO_SPLITK_TARGET"); target_env = e ? atoi(e) : 0; }
     int target = target_env > 0 ? target_env : 256 / (chip_share > 1 ? chip_share : 1);
     if (target < 32) target = 32;
+    // (aiming the two-per-CU 1x1 tile at two workgroups per CU measured +0.5 %: more partial traffic than overlap)
     if (blocks >= target / 2 || nchunks < 8) return 1;
     // Round 6: the LARGEST factor whose workgroups still fit the target in one round (floor).  The rounded-up quotient put 20 tiles x
     // 13 splits = 260 workgroups on 256 CUs (1024 -> 512 @16^2, 5 probes): four of them ran as a second round of a launch whose
