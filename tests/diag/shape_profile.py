@@ -16,14 +16,27 @@ x = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(1)).to(d
 mask = torch.zeros(3, 256, 256, dtype=torch.bool); mask[:, 110:130, 70:110] = True
 eng.pmp_primal(x, t, at, mask.to(dev))
 K = int(os.environ.get("SHAPE_PROFILE_K", "5"))      # probes per pass (a two-stream pass runs groups of 3 and 2)
-V = torch.randn(K, CELEBA_DDPM.n, generator=torch.Generator().manual_seed(2)).to(dev)
-U = eng.pmp_jvp(V); A = eng.pmp_vjp(U); torch.cuda.synchronize()
-eng.profile_enable(2)
-U = eng.pmp_jvp(V); A = eng.pmp_vjp(U)
-rep = eng.profile_report()
-eng.profile_enable(False)
+FWD = int(os.environ.get("SHAPE_PROFILE_FWD", "0"))   # > 0: one denoiser evaluation of this many frames instead (the DDIM chains: 1, the decode: 21 / 25)
+if FWD:
+    eng2 = LocoEngine(CELEBA_DDPM, max_batch=32) if FWD > 8 else eng
+    if eng2 is not eng: eng2.load_state_dict(synth_params(CELEBA_DDPM, 0))
+    xb = torch.randn(FWD, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(dev)
+    eng2.unet_forward(xb, t); torch.cuda.synchronize()
+    eng2.profile_enable(2)
+    eng2.unet_forward(xb, t)
+    rep = eng2.profile_report()
+    eng2.profile_enable(False)
+    what = f"one denoiser evaluation of {FWD} frames"
+else:
+    V = torch.randn(K, CELEBA_DDPM.n, generator=torch.Generator().manual_seed(2)).to(dev)
+    U = eng.pmp_jvp(V); A = eng.pmp_vjp(U); torch.cuda.synchronize()
+    eng.profile_enable(2)
+    U = eng.pmp_jvp(V); A = eng.pmp_vjp(U)
+    rep = eng.profile_report()
+    eng.profile_enable(False)
+    what = f"one JVP+VJP (k={K})"
 tot = sum(v["ms"] for v in rep.values())
-print(f"conv total {tot:.2f} ms for one JVP+VJP (k={K})")
+print(f"conv total {tot:.2f} ms for {what}")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 45      # rows; argv[2]: substring filter on the key ("|t1_" = the 1x1 maps)
 F = sys.argv[2] if len(sys.argv) > 2 else ""
 if F: print(f"rows matching {F!r}: {sum(v['ms'] for k, v in rep.items() if F in k):.2f} ms")
