@@ -1,6 +1,7 @@
 // Split-bf16 ("bf16x3") convolution: tile heuristics and dispatch.  The kernel template lives in
 // conv_bf16_kernel.h and is instantiated per (TAPS, MODE) in conv_bf16_inst_*.hip.
 #include "kernels.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace loco {
@@ -274,6 +275,13 @@ bool conv_gemm_plan(ConvArgs& a) {
 
 template <int PR>
 static void launch_lowp(const ConvArgs& a, int taps, hipStream_t st) {
+    // The norm-cotangent term exists in ONE place: the staged epilogue of the per-pixel 1x1 kernels (EPI_COT1), un-split launches of
+    // whole cout tiles.  Anything else would drop it silently -- refuse loudly (the engine plans such launches only: run_conv).
+    if (a.cot_d && (taps != 1 || a.gemm || a.nsplit > 1 || a.Cin2 > 0 || (a.Cout % conv_bf16_tile_couts(a)) != 0 || a.st_kind == ST_TAN || a.st_kind == ST_COT)) {
+        fprintf(stderr, "loco: ConvArgs::cot_d on a launch whose epilogue has no norm-cotangent term (taps %d, gemm %d, nsplit %d, Cout %d, st_kind %d)\n",
+                taps, a.gemm, a.nsplit, a.Cout, a.st_kind);
+        abort();
+    }
     if constexpr (PR == PR_BF16X3) {
         if (taps == 1 && a.gemm) { launch_conv_gemm(a, st); return; }
     }
