@@ -560,6 +560,12 @@ def main():
     if rank == 0 and not a.no_profile:
         rep = eng.profile_report()
         eng.profile_enable(False)
+        if os.environ.get("LOCO_BENCH_SHAPES"):      # diagnostics: one more step profiled per LAYER SHAPE, dumped for tests/diag/shape_excess.py
+            eng.profile_enable(2)
+            w["step"]()
+            torch.cuda.synchronize()
+            json.dump(eng.profile_report(), open(os.environ["LOCO_BENCH_SHAPES"], "w"))
+            eng.profile_enable(False)
         dom = max(rep.items(), key=lambda kv: kv[1]["ms"])
         name, r = dom
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12

@@ -5,6 +5,8 @@ One process per setting (the switches are read once).    python3 tests/diag/nin_
 import glob, os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [(128, 256, 256, 5), (128, 256, 128, 5), (256, 512, 64, 5), (128, 384, 128, 5), (256, 128, 128, 4), (512, 512, 32, 5)]
+if os.environ.get("NIN_SHAPES"):      # "cin,cout,hw,B;..."
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["NIN_SHAPES"].split(";") if t]
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     import torch
@@ -25,7 +27,7 @@ import torch
 iters = sys.argv[1] if len(sys.argv) > 1 else "200"
 libs = sys.argv[2:] or [os.path.join(ROOT, "loco-edit_amd", "libloco_hip_diag.so")] + sorted(glob.glob(os.path.join(ROOT, "tests", "diag", "libwi", "*.so")))
 TMP = tempfile.mkdtemp(prefix="nin_check_")
-for cot in ("0", "1"):
+for cot in os.environ.get("NIN_COT", "0,1").split(","):
     ref = None
     for lib in libs:
         f = os.path.join(TMP, "o.pt")
