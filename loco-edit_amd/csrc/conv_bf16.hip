@@ -33,7 +33,7 @@ int conv_bf16_pick_tile(int Cout, int HW, int B) {
 // split-K factor for the split-bf16 kernels: splitting costs a partial round trip + a reduce launch, so only
 // split when the un-split grid would leave more than half of the CUs idle
 static int conv_1x1_tile0_maxhw();
-int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip_share, int taps) {
+int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip_share, int taps, int lanes) {
     const int HW = Hout * Wout;
     int t = conv_bf16_pick_tile(Cout, HW, B);
     if (t == 4) t = 5;
@@ -52,7 +52,10 @@ int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip
     // per solve).  LOCO_SPLITK_TARGET overrides (A/B switch).
     static int target_env = -1;
     if (target_env < 0) { const char* e = getenv("LOCO_SPLITK_TARGET"); target_env = e ? atoi(e) : 0; }
-    int target = target_env > 0 ? target_env : 256 / (chip_share > 1 ? chip_share : 1);
+    // (lanes == 2: the launch belongs to one of the two probe groups a pass runs side by side on two streams (run_lanes): the other
+    //  group's launches want CUs too, and a factor that fills all 256 serialises the two -- 240 measured best, 251.2 - 251.6 against
+    //  253.5 - 254.0 ms per step at 256 and 251.5 - 252.5 at 224; on ONE stream 256 is: 259.2 - 259.8 against 260.4 - 261.2 at 224)
+    int target = target_env > 0 ? target_env : (chip_share > 1 ? 256 / chip_share : (lanes == 2 ? 240 : 256));
     if (target < 32) target = 32;
     // (aiming the two-per-CU 1x1 tile at two workgroups per CU measured +0.5 %: more partial traffic than overlap)
     if (blocks >= target / 2 || nchunks < 8) return 1;

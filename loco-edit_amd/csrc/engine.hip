@@ -212,6 +212,7 @@ struct loco_ctx {
     int forks = 0;
     bool zombie = false;
     bool fuse_lin = true;          // tangent / cotangent group means taken in the conv epilogues (LOCO_FUSE_LIN=0: standalone passes)
+    int lanes_active = 1;          // 2 while run_lanes enqueues the two probe groups of a pass on two streams (split-K then aims below the whole chip)
     int lane_s0 = 0;               // first sample of the lane being enqueued (run_lanes): where its rows of a kept partial buffer start
     int chip_share = 1;            // contexts whose passes the host enqueues side by side on other streams (loco_set_chip_share): split-K aims at 256 / share workgroups
     hipStream_t cap_st = nullptr;  // capture stream (the caller's may be the legacy default stream)
@@ -1325,7 +1326,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
         const size_t span = (size_t)c->cfg.max_batch * c->per_sample;
         ConvArgs t = a;
         t.taps = taps;
-        t.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, c->chip_share) : 2;
+        t.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, c->chip_share, 9, c->lanes_active) : 2;
         t.in_padded = (a.in >= c->arenaP && a.in < c->arenaP + span) || (a.in >= c->arenaT && a.in < c->arenaT + span);
         t.in2 = second->in; t.in2_bs = second->in_bs; t.Cin2 = second->Cin;
         const long per_probe = (long)((a.Hout * a.Wout) / 256) * ((a.Cout + 127) / 128), total = per_probe * a.B;
@@ -1345,7 +1346,7 @@ void run_conv(loco_ctx* c, ConvArgs& a, int taps, hipStream_t st, const StatReq*
     if (c->prec == 2) a.wb = a.wh;
     a.taps = taps;
     a.no_deep = c->deep1 ? 0 : 1;
-    a.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, c->chip_share, taps)
+    a.nsplit = c->prec >= 1 ? conv_bf16_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, c->chip_share, taps, c->lanes_active)
                             : conv_pick_nsplit(a.Cin, a.Cout, a.Hout, a.Wout, a.B, taps);
     while (a.nsplit > 1 && (size_t)a.nsplit * a.B * a.Cout * a.Hout * a.Wout > c->partial_floats) a.nsplit >>= 1;
     if (a.nsplit < 1) a.nsplit = 1;
@@ -2437,7 +2438,7 @@ int cotangent_pass(loco_ctx* c, const float* ge, const float* gx0, float* Aout, 
                         // a read-modify-write pass of gn_apply_kernel<2> over g_in -- one unsplit launch of whole cout tiles only
                         ConvArgs t = n;
                         t.taps = 1;
-                        t.nsplit = conv_bf16_pick_nsplit(n.Cin, n.Cout, n.Hout, n.Wout, n.B, c->chip_share, 1);
+                        t.nsplit = conv_bf16_pick_nsplit(n.Cin, n.Cout, n.Hout, n.Wout, n.B, c->chip_share, 1, c->lanes_active);
                         const long per_probe = (long)((n.Hout * n.Wout) / conv_bf16_tile_pixels(t)) * ((n.Cout + 127) / 128);
                         const long total = per_probe * n.B, r = total % 256;
                         if (t.nsplit == 1 && (total <= 256 || r == 0 || r > 160) && conv_lowp_can_fuse_stats(t) && op.n1.sx_off >= 0 &&
@@ -2640,15 +2641,17 @@ int run_lanes(loco_ctx* c, int B, hipStream_t st, F body) {      // body(first s
     const size_t pf = c->partial_floats;
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     c->partial_floats = pf / 2;                    // lane 0 keeps the lower half of the split-K workspace
+    c->lanes_active = 2;
     int rc = body(0, nA, st);
     c->partial_floats = pf;
-    if (rc) return rc;
+    if (rc) { c->lanes_active = 1; return rc; }
     hipStream_t s2 = c->st2_user ? c->st2_user : c->st2;
-    HIPCHK(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+    if (hipStreamWaitEvent(s2, c->ev_fork, 0) != hipSuccess) { c->lanes_active = 1; c->err = "run_lanes: hipStreamWaitEvent"; return -1; }
     {
         LaneSwap sw(c, nA);
         rc = body(nA, B - nA, s2);
     }
+    c->lanes_active = 1;
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev_join, s2));
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));

@@ -157,7 +157,7 @@ const char* conv_variant_name(const ConvArgs& a, int taps, int prec);
 // workspace (floats) a conv launch with these args needs for split-K partials
 size_t conv_partial_floats(const ConvArgs& a);
 int conv_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int taps);
-int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip_share = 1, int taps = 9);   // chip_share: launches running side by side (loco_set_chip_share)
+int conv_bf16_pick_nsplit(int Cin, int Cout, int Hout, int Wout, int B, int chip_share = 1, int taps = 9, int lanes = 1);   // chip_share: launches running side by side (loco_set_chip_share)
 int conv_bf16_pick_tile(int Cout, int HW, int Bsplit);
 int conv_bf16_tile_pixels(const ConvArgs& a);
 
